@@ -1,0 +1,224 @@
+"""TEST INFRASTRUCTURE ONLY -- imports the *real* reference (read-only mount at /root/reference).
+
+This module exists only in the build container: /root/reference does not exist on the GPU box,
+so nothing under tests/ (-m gpu), bench.py or __graft_entry__.smoke() may import it.  It is used
+by oracle/make_golden.py (fixture generation) and oracle/validate_restatement.py (pins
+oracle/restate.py against the reference's own nn.Modules).
+
+What it does:
+  * installs a sys.meta_path finder that returns MagicMock packages for third-party modules
+    the reference imports but that are absent here (torchvision, cv2, apex, mediapipe, ...);
+  * puts /root/reference on sys.path and aliases the `EmoPortraits` package name
+    (models/stage_1/volumetric_avatar/va_arguments.py:5 imports `EmoPortraits.networks`);
+  * builds the argparse namespace = va_arguments defaults + the released launch command
+    (experiments/args.txt), as notebooks/infer.py:74-81 would get it from logs/<exp>/args.txt;
+  * builds a holder nn.Module with exactly the hot-path sub-networks of
+    models/stage_1/volumetric_avatar/va.py:126-279 (same attribute names, same init order:
+    weight_init -> spectral norm -> weight standardisation, va.py:86,113-118) and binds
+    Model.predict_embed (va.py:813-885).
+"""
+import argparse
+import importlib.abc
+import importlib.machinery
+import os
+import shlex
+import sys
+import types
+from unittest.mock import MagicMock
+
+REF_ROOT = os.environ.get("EMO_REFERENCE_ROOT", "/root/reference")
+
+_STUBBED = {
+    "repos", "ibug", "torchvision", "cv2", "skimage", "apex", "mediapipe", "albumentations", "lmdb",
+    "wandb", "face_alignment", "facenet_pytorch", "sklearn", "tensorboardX", "pytorch_msssim", "lpips",
+    "kornia", "imageio", "dlib", "face_parsing", "face_detection", "matplotlib", "tensorboard",
+    "seaborn", "insightface", "onnxruntime", "mmcv", "decord", "av", "ffmpeg", "librosa", "IPython",
+}
+
+
+class _StubLoader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__name__ = spec.name
+        m.__path__ = []
+        m.__spec__ = spec
+        m.__loader__ = self
+        m.__file__ = None
+        return m
+
+    def exec_module(self, module):
+        return None
+
+
+class _StubFinder(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path=None, target=None):
+        if name.split(".")[0] in _STUBBED:
+            return importlib.machinery.ModuleSpec(name, _StubLoader(), is_package=True)
+        return None
+
+
+_installed = False
+
+
+def install():
+    """Idempotently install the import hook and the reference on sys.path."""
+    global _installed
+    if _installed:
+        return
+    if not os.path.isdir(REF_ROOT):
+        raise RuntimeError(f"reference tree not found at {REF_ROOT}; this harness only runs in the build container")
+    sys.meta_path.insert(0, _StubFinder())
+    sys.path.insert(0, REF_ROOT)
+    pkg = types.ModuleType("EmoPortraits")
+    pkg.__path__ = [REF_ROOT]
+    sys.modules["EmoPortraits"] = pkg
+    _installed = True
+
+
+def released_args(image_size=512, overrides=None):
+    """Namespace = va_arguments.py:11-357 defaults + tokens of experiments/args.txt (F4 of SURVEY.md)."""
+    install()
+    from models.stage_1.volumetric_avatar.va_arguments import VolumetricAvatarConfig
+
+    p = argparse.ArgumentParser(conflict_handler="resolve")
+    p.add_argument("--num_gpus", default=1, type=int)
+    p.add_argument("--image_size", default=256, type=int)
+    p.add_argument("--aug_warp_size", default=256, type=int)
+    p.add_argument("--num_source_frames", default=1, type=int)
+    p.add_argument("--num_target_frames", default=1, type=int)
+    p.add_argument("--project_dir", default=REF_ROOT, type=str)
+    p = VolumetricAvatarConfig.add_argparse_args(p)
+    toks = shlex.split(open(os.path.join(REF_ROOT, "experiments", "args.txt")).read())
+    toks = toks[toks.index("../train.py") + 1:]
+    args, _unknown = p.parse_known_args(toks)
+    args.image_size = image_size
+    args.aug_warp_size = image_size
+    args.num_gpus = 1
+    args.num_source_frames = 1
+    args.num_target_frames = 1
+    args.print_norms = False
+    for k, v in (overrides or {}).items():
+        setattr(args, k, v)
+    return args
+
+
+def build_holder(args, nets=("local_encoder_nw", "pose_unsqueeze_nw", "warp_embed_head_orig_nw", "xy_generator_nw",
+                             "uv_generator_nw", "volume_source_nw", "volume_process_nw", "decoder_nw"), seed=0):
+    """The hot-path subset of va.Model (va.py:41-124,126-279) on a plain holder module."""
+    install()
+    import torch
+    from torch import nn
+    import torch.nn.functional as F
+    from networks import volumetric_avatar
+    from models.stage_1.volumetric_avatar import va as va_mod
+    from models.stage_1.volumetric_avatar.va_arguments import VolumetricAvatarConfig
+    from utils import weight_init, spectral_norm
+
+    torch.manual_seed(seed)
+
+    class Holder(nn.Module):
+        predict_embed = va_mod.Model.predict_embed  # va.py:813-885, unbound
+
+        def __init__(self):
+            super().__init__()
+            self.args = args
+            self.rank = 0
+            self.num_source_frames = 1
+            self.num_target_frames = 1
+            self.embed_size = args.gen_embed_size
+            self.pred_mixing = args.gen_pred_mixing
+            cfg = VolumetricAvatarConfig(args)
+            self.va_config = cfg
+            if "local_encoder_nw" in nets:
+                self.local_encoder_nw = volumetric_avatar.LocalEncoder(cfg.local_encoder_cfg)            # va.py:133
+            if "pose_unsqueeze_nw" in nets:
+                self.pose_unsqueeze_nw = nn.Linear(args.lpe_output_channels_expression,
+                                                   args.gen_max_channels * self.embed_size ** 2, bias=False)  # va.py:172
+            if "warp_embed_head_orig_nw" in nets:
+                self.warp_embed_head_orig_nw = nn.Conv2d(args.gen_max_channels * (2 if args.cat_em else 1),
+                                                         args.gen_max_channels, (1, 1), bias=False)      # va.py:177
+            if "xy_generator_nw" in nets:
+                self.xy_generator_nw = volumetric_avatar.WarpGenerator(cfg.warp_generator_cfg)          # va.py:184
+            if "uv_generator_nw" in nets:
+                self.uv_generator_nw = volumetric_avatar.WarpGenerator(cfg.warp_generator_cfg)          # va.py:185
+            if "volume_source_nw" in nets:
+                self.volume_source_nw = volumetric_avatar.VPN_ResBlocks(cfg.VPN_resblocks_source_cfg)   # va.py:200
+            if "volume_process_nw" in nets:
+                self.volume_process_nw = volumetric_avatar.Unet3D(cfg.unet3d_cfg)                       # va.py:212
+            if "decoder_nw" in nets:
+                self.decoder_nw = volumetric_avatar.Decoder(cfg.decoder_cfg)                            # va.py:226
+            self.grid_sample = lambda inputs, grid: F.grid_sample(                                      # va.py:264
+                inputs.float(), grid.float(), padding_mode=args.grid_sample_padding_mode)
+            grid_s = torch.linspace(-1, 1, args.latent_volume_size)                                      # va.py:101-105
+            grid_z = torch.linspace(-1, 1, args.latent_volume_depth)
+            w, v, u = torch.meshgrid(grid_z, grid_s, grid_s, indexing="ij")
+            e = torch.ones_like(u)
+            self.register_buffer("identity_grid_3d", torch.stack([u, v, w, e], dim=3).view(1, -1, 4),
+                                 persistent=False)
+            self.resize_warp = args.warp_output_size != args.gen_latent_texture_size
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        h = Holder()
+        h.apply(weight_init.weight_init(args.init_type, args.init_gain))   # va.py:86
+        if args.use_sn:
+            spectral_norm.apply_sp_to_nets(h)                               # va.py:113-114
+        if args.use_ws:
+            volumetric_avatar.utils.apply_ws_to_nets(h)                     # va.py:117-118
+    h.eval()
+    return h
+
+
+def randomize_affines(holder, seed=123, scale=0.2):
+    """Random-init leaves every norm affine at (1,0), every bias at 0 and the WS-replaced convs at
+    torch's default init; perturb them so that parity tests exercise every parameter."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in holder.named_parameters():
+            if p.dim() == 1:
+                p.add_(scale * torch.randn(p.shape, generator=g))
+    return holder
+
+
+def reference_source_pass(h, source_latents_in, idt_embed, source_pose_embed, theta_src):
+    """Replays notebooks/infer.py:433-507 on synthetic inputs (no crop/mask/embedders).
+    source_latents_in = masked source image [1,3,S,S]."""
+    import torch
+    a = h.args
+    c, d, s = a.latent_volume_channels, a.latent_volume_depth, a.latent_volume_size
+    with torch.no_grad():
+        latents = h.local_encoder_nw(source_latents_in)                                   # infer.py:433
+        grid = h.identity_grid_3d.repeat_interleave(1, dim=0)                             # infer.py:441
+        inv = theta_src.float().inverse().type(theta_src.type())                         # infer.py:443
+        source_rotation_warp = grid.bmm(inv[:, :3].transpose(1, 2)).view(-1, d, s, s, 3)  # infer.py:444
+        dd = {"source_img": source_latents_in, "target_img": source_latents_in, "idt_embed": idt_embed,
+              "source_pose_embed": source_pose_embed, "target_pose_embed": source_pose_embed}
+        src_embed, _, _, embed_dict = h.predict_embed(dd)                                 # infer.py:459
+        xy_warp = h.xy_generator_nw(src_embed)[0]                                         # infer.py:462
+        vol = latents.view(1, c, d, s, s)                                                 # infer.py:485
+        vol = h.volume_source_nw(vol)                                                     # infer.py:491
+        tv = h.grid_sample(h.grid_sample(vol, source_rotation_warp), xy_warp)             # infer.py:499-500
+        canonical = h.volume_process_nw(tv, embed_dict)                                   # infer.py:507
+    return dict(latents=latents, source_rotation_warp=source_rotation_warp, xy_warp=xy_warp,
+                source_volume=vol, pre_canonical=tv, canonical=canonical, warp_embed=src_embed["orig"])
+
+
+def reference_driver_pass(h, canonical, idt_embed, target_pose_embed, theta_drv, image_like):
+    """Replays notebooks/infer.py:583-637 for ONE driver frame (batch 1, as the reference does, F5)."""
+    import torch
+    a = h.args
+    c, d, s = a.latent_volume_channels, a.latent_volume_depth, a.latent_volume_size
+    with torch.no_grad():
+        grid = h.identity_grid_3d.repeat_interleave(1, dim=0)                             # infer.py:583
+        target_rotation_warp = grid.bmm(theta_drv[:, :3].transpose(1, 2)).view(-1, d, s, s, 3)  # infer.py:586
+        dd = {"source_img": image_like, "target_img": image_like, "idt_embed": idt_embed,
+              "source_pose_embed": target_pose_embed, "target_pose_embed": target_pose_embed}
+        _, tgt_embed, _, embed_dict = h.predict_embed(dd)                                 # infer.py:609
+        uv_warp, delta_uv = h.uv_generator_nw(tgt_embed)                                  # infer.py:612
+        aligned = h.grid_sample(h.grid_sample(canonical, uv_warp), target_rotation_warp)  # infer.py:618-619
+        feat = aligned.view(1, c * d, s, s)                                               # infer.py:627
+        img, _, deep_f, img_f = h.decoder_nw(dd, embed_dict, feat, False, stage_two=True)  # infer.py:637
+    return dict(target_rotation_warp=target_rotation_warp, uv_warp=uv_warp, delta_uv=delta_uv,
+                aligned=aligned, img=img, deep_f=deep_f, img_f=img_f, warp_embed=tgt_embed["orig"])
