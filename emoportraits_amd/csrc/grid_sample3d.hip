@@ -1,0 +1,367 @@
+// 3-D trilinear grid_sample (align_corners=False) for gfx950 -- SURVEY.md section 8 rows a1 + a2.
+//
+// Replaces  F.grid_sample(inputs.float(), grid.float(), padding_mode=...)  on 5-D tensors
+// (reference: models/stage_1/volumetric_avatar/va.py:264-265; call sites notebooks/infer.py:499-500,
+// :618-619).  The arithmetic restated here is ATen's CPU grid_sampler_3d (ATen/native/GridSampler.h:
+// grid_sampler_unnormalize :27-36, clip_coordinates :58-60, reflect_coordinates :89-106) and is kept
+// bit-identical to it: all coordinate/weight math is fp32 with explicit round-to-nearest intrinsics (no FMA
+// contraction), corner weights are (wx*wy)*wz, corners accumulate in the order tnw,tne,tsw,tse,bnw,bne,
+// bsw,bse with separate multiply and add, and out-of-range corners contribute nothing (zeros padding).
+//
+// Two data layouts:
+//   NCDHW (reference layout): one lane per output voxel, loop over a chunk of channels.  Taps/weights are
+//     computed once per voxel and reused for every channel; output stores are coalesced along x.
+//   NDHWC (channels-last, internal): the C channels of a voxel are contiguous, so every corner is ONE
+//     contiguous C*4-byte read (384 B for C=96) regardless of how the warp scatters neighbouring voxels --
+//     each lane owns 4 channels (float4) of one voxel.  The canonical volume is repacked once per identity.
+//
+// The analytic variant (theta != NULL) fuses the head-pose affine of the identity lattice into the sampler
+// (row a2: notebooks/infer.py:441-444, :583-588), removing the 0.79 MB grid tensor from HBM.
+#include "common.h"
+
+namespace {
+
+struct Taps {
+  int off[8];      // spatial offset (z*H + y)*W + x of each corner, 0 when the corner is out of range
+  float w[8];      // corner weights, reference order tnw,tne,tsw,tse,bnw,bne,bsw,bse
+  unsigned inb;    // bit k set <=> corner k is inside the volume
+};
+
+template <int PAD>
+__device__ __forceinline__ float source_index(float g, int size) {
+  // grid_sampler_unnormalize, align_corners=False: ((coord + 1) * size - 1) / 2
+  float c = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(g, 1.0f), (float)size), 1.0f), 2.0f);
+  if (PAD == EMO_PAD_BORDER) {
+    const float lim = (float)(size - 1);
+    c = (c < 0.0f) ? 0.0f : c;           // std::max(in, 0)
+    c = (c < lim) ? c : lim;             // std::min(lim, .)
+  } else if (PAD == EMO_PAD_REFLECTION) {
+    // reflect_coordinates(c, twice_low=-1, twice_high=2*size-1)
+    const float mn = -0.5f;
+    const float span = (float)size;
+    float in = fabsf(__fsub_rn(c, mn));
+    float extra = fmodf(in, span);
+    int flips = (int)floorf(__fdiv_rn(in, span));
+    c = (flips % 2 == 0) ? __fadd_rn(extra, mn) : __fadd_rn(__fsub_rn(span, extra), mn);
+    const float lim = (float)(size - 1);
+    c = (c < 0.0f) ? 0.0f : c;
+    c = (c < lim) ? c : lim;
+  }
+  return c;
+}
+
+template <int PAD>
+__device__ __forceinline__ void compute_taps(float gx, float gy, float gz, int D, int H, int W, Taps& t) {
+  float ix = source_index<PAD>(gx, W);
+  float iy = source_index<PAD>(gy, H);
+  float iz = source_index<PAD>(gz, D);
+  // non-finite / absurdly large coordinates: every corner out of range (ATen's int cast would be UB there)
+  const bool sane = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
+  if (!sane) { ix = -100.0f; iy = -100.0f; iz = -100.0f; }
+  const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+  const float x1f = __fadd_rn(x0f, 1.0f), y1f = __fadd_rn(y0f, 1.0f), z1f = __fadd_rn(z0f, 1.0f);
+  const float wx0 = __fsub_rn(x1f, ix), wx1 = __fsub_rn(ix, x0f);
+  const float wy0 = __fsub_rn(y1f, iy), wy1 = __fsub_rn(iy, y0f);
+  const float wz0 = __fsub_rn(z1f, iz), wz1 = __fsub_rn(iz, z0f);
+  const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+  const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+  const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+  const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
+  const bool vz0 = (unsigned)z0 < (unsigned)D, vz1 = (unsigned)z1 < (unsigned)D;
+  const float wxy00 = __fmul_rn(wx0, wy0), wxy10 = __fmul_rn(wx1, wy0);
+  const float wxy01 = __fmul_rn(wx0, wy1), wxy11 = __fmul_rn(wx1, wy1);
+  t.w[0] = __fmul_rn(wxy00, wz0); t.w[1] = __fmul_rn(wxy10, wz0);
+  t.w[2] = __fmul_rn(wxy01, wz0); t.w[3] = __fmul_rn(wxy11, wz0);
+  t.w[4] = __fmul_rn(wxy00, wz1); t.w[5] = __fmul_rn(wxy10, wz1);
+  t.w[6] = __fmul_rn(wxy01, wz1); t.w[7] = __fmul_rn(wxy11, wz1);
+  const bool v[8] = {vz0 && vy0 && vx0, vz0 && vy0 && vx1, vz0 && vy1 && vx0, vz0 && vy1 && vx1,
+                     vz1 && vy0 && vx0, vz1 && vy0 && vx1, vz1 && vy1 && vx0, vz1 && vy1 && vx1};
+  const int HW = H * W;
+  const int o[8] = {z0 * HW + y0 * W + x0, z0 * HW + y0 * W + x1, z0 * HW + y1 * W + x0, z0 * HW + y1 * W + x1,
+                    z1 * HW + y0 * W + x0, z1 * HW + y0 * W + x1, z1 * HW + y1 * W + x0, z1 * HW + y1 * W + x1};
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    t.off[k] = v[k] ? o[k] : 0;
+    m |= v[k] ? (1u << k) : 0u;
+  }
+  t.inb = m;
+}
+
+// identity_grid_3d.bmm(theta[:, :3]^T): k-ordered fma chain starting from 0 (what the reference's GEMM does)
+__device__ __forceinline__ float affine_row(const float* __restrict__ t, float u, float v, float w) {
+  float acc = __fmul_rn(u, t[0]);
+  acc = __fmaf_rn(v, t[1], acc);
+  acc = __fmaf_rn(w, t[2], acc);
+  acc = __fmaf_rn(1.0f, t[3], acc);
+  return acc;
+}
+
+template <bool ANALYTIC>
+__device__ __forceinline__ void load_coord(const float* __restrict__ grid, const float* __restrict__ theta,
+                                           const float* __restrict__ lin_x, const float* __restrict__ lin_y,
+                                           const float* __restrict__ lin_z, int n, int vox, int nvox, int Ho, int Wo,
+                                           float& gx, float& gy, float& gz) {
+  if (ANALYTIC) {
+    const int x = vox % Wo;
+    const int y = (vox / Wo) % Ho;
+    const int z = vox / (Wo * Ho);
+    const float u = lin_x[x], v = lin_y[y], w = lin_z[z];
+    const float* t = theta + (long)n * 12;
+    gx = affine_row(t + 0, u, v, w);
+    gy = affine_row(t + 4, u, v, w);
+    gz = affine_row(t + 8, u, v, w);
+  } else {
+    const float* g = grid + ((long)n * nvox + vox) * 3;
+    gx = g[0]; gy = g[1]; gz = g[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// NCDHW -> NCDHW.  grid = (ceil(nvox/256), channel chunks, N); one lane per output voxel.
+// ------------------------------------------------------------------------------------------------------
+template <int PAD, bool ANALYTIC>
+__global__ __launch_bounds__(256) void gs3d_ncdhw_kernel(
+    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
+    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int c_per_block) {
+  const int nvox = Do * Ho * Wo;
+  const int vox = blockIdx.x * 256 + threadIdx.x;
+  if (vox >= nvox) return;
+  const int n = blockIdx.z;
+  const int c0 = blockIdx.y * c_per_block;
+  const int c1 = min(c0 + c_per_block, C);
+  float gx, gy, gz;
+  load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+  Taps t;
+  compute_taps<PAD>(gx, gy, gz, D, H, W, t);
+  const long DHW = (long)D * H * W;
+  const float* vp = vol + (long)n * vol_bstride + (long)c0 * DHW;
+  float* op = out + ((long)n * C + c0) * nvox + vox;
+  int c = c0;
+  for (; c + 4 <= c1; c += 4) {
+    float v[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[j][k] = vp[j * DHW + t.off[k]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float val = ((t.inb >> k) & 1u) ? v[j][k] : 0.0f;
+        acc = __fadd_rn(acc, __fmul_rn(val, t.w[k]));
+      }
+      op[(long)j * nvox] = acc;
+    }
+    vp += 4 * DHW;
+    op += 4L * nvox;
+  }
+  for (; c < c1; ++c) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float raw = vp[t.off[k]];
+      const float val = ((t.inb >> k) & 1u) ? raw : 0.0f;
+      acc = __fadd_rn(acc, __fmul_rn(val, t.w[k]));
+    }
+    op[0] = acc;
+    vp += DHW;
+    op += nvox;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// NDHWC -> NDHWC.  item = (voxel, channel quad); lanes of a voxel are adjacent so that each corner is read
+// as LPV consecutive float4 (C*4 contiguous bytes).  grid = (ceil(nvox*LPV/256), 1, N)
+// ------------------------------------------------------------------------------------------------------
+template <int PAD, bool ANALYTIC>
+__global__ __launch_bounds__(256) void gs3d_cl_kernel(
+    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
+    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
+  const int LPV = C >> 2;
+  const int nvox = Do * Ho * Wo;
+  const long item = (long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= (long)nvox * LPV) return;
+  const int vox = (int)(item / LPV);
+  const int q = (int)(item - (long)vox * LPV);
+  const int n = blockIdx.z;
+  float gx, gy, gz;
+  load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+  Taps t;
+  compute_taps<PAD>(gx, gy, gz, D, H, W, t);
+  const float4* vp = reinterpret_cast<const float4*>(vol + (long)n * vol_bstride) + q;
+  float4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = vp[(long)t.off[k] * LPV];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool in = (t.inb >> k) & 1u;
+    const float w = t.w[k];
+    acc.x = __fadd_rn(acc.x, __fmul_rn(in ? v[k].x : 0.0f, w));
+    acc.y = __fadd_rn(acc.y, __fmul_rn(in ? v[k].y : 0.0f, w));
+    acc.z = __fadd_rn(acc.z, __fmul_rn(in ? v[k].z : 0.0f, w));
+    acc.w = __fadd_rn(acc.w, __fmul_rn(in ? v[k].w : 0.0f, w));
+  }
+  reinterpret_cast<float4*>(out)[((long)n * nvox + vox) * LPV + q] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// NDHWC -> NCDHW.  One block per output row (n, z, y): Wo voxels x LPV quads, results transposed through
+// LDS so that the NCDHW stores are full 256-byte rows.  dynamic LDS = C * (Wo + 1) floats.
+// ------------------------------------------------------------------------------------------------------
+template <int PAD, bool ANALYTIC>
+__global__ __launch_bounds__(256) void gs3d_cl2ncdhw_kernel(
+    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
+    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][Wo + 1]
+  const int LPV = C >> 2;
+  const int nvox = Do * Ho * Wo;
+  const int row = blockIdx.x;              // z * Ho + y
+  const int n = blockIdx.z;
+  const int ld = Wo + 1;
+  const float4* vbase = reinterpret_cast<const float4*>(vol + (long)n * vol_bstride);
+  for (int item = threadIdx.x; item < Wo * LPV; item += 256) {
+    const int x = item / LPV;
+    const int q = item - x * LPV;
+    const int vox = row * Wo + x;
+    float gx, gy, gz;
+    load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+    Taps t;
+    compute_taps<PAD>(gx, gy, gz, D, H, W, t);
+    const float4* vp = vbase + q;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = vp[(long)t.off[k] * LPV];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool in = (t.inb >> k) & 1u;
+      const float w = t.w[k];
+      acc.x = __fadd_rn(acc.x, __fmul_rn(in ? v[k].x : 0.0f, w));
+      acc.y = __fadd_rn(acc.y, __fmul_rn(in ? v[k].y : 0.0f, w));
+      acc.z = __fadd_rn(acc.z, __fmul_rn(in ? v[k].z : 0.0f, w));
+      acc.w = __fadd_rn(acc.w, __fmul_rn(in ? v[k].w : 0.0f, w));
+    }
+    const int c = q * 4;
+    tile[(c + 0) * ld + x] = acc.x;
+    tile[(c + 1) * ld + x] = acc.y;
+    tile[(c + 2) * ld + x] = acc.z;
+    tile[(c + 3) * ld + x] = acc.w;
+  }
+  __syncthreads();
+  float* obase = out + (long)n * C * nvox + (long)row * Wo;
+  for (int i = threadIdx.x; i < C * Wo; i += 256) {
+    const int c = i / Wo;
+    const int x = i - c * Wo;
+    obase[(long)c * nvox + x] = tile[c * ld + x];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// layout repack [N][C][S] <-> [N][S][C] through a 64x64 LDS tile
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     int R, int Ccols) {
+  // in: [n][R][Ccols] -> out: [n][Ccols][R]
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const float* ip = in + (long)n * R * Ccols;
+  float* op = out + (long)n * R * Ccols;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < R && c < Ccols) tile[i][tx] = ip[(long)r * Ccols + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < Ccols) op[(long)c * R + r] = tile[tx][i];
+  }
+}
+
+template <int PAD, bool ANALYTIC>
+int launch(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
+           const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+           long vol_bstride, int in_layout, int out_layout, int variant, hipStream_t s) {
+  const int nvox = Do * Ho * Wo;
+  if (in_layout == EMO_LAYOUT_NCDHW && out_layout == EMO_LAYOUT_NCDHW) {
+    int cpb = variant > 0 ? variant : 8;
+    if (cpb > C) cpb = C;
+    dim3 g(emo_cdiv(nvox, 256), emo_cdiv(C, cpb), N);
+    hipLaunchKernelGGL((gs3d_ncdhw_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
+                       out, C, D, H, W, Do, Ho, Wo, vol_bstride, cpb);
+  } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NDHWC) {
+    if (C % 4) return EMO_ERR_UNSUPPORTED;
+    dim3 g(emo_cdiv((long)nvox * (C / 4), 256), 1, N);
+    hipLaunchKernelGGL((gs3d_cl_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z, out,
+                       C, D, H, W, Do, Ho, Wo, vol_bstride);
+  } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NCDHW) {
+    if (C % 4) return EMO_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)C * (Wo + 1) * sizeof(float);
+    if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
+    dim3 g(Do * Ho, 1, N);
+    hipLaunchKernelGGL((gs3d_cl2ncdhw_kernel<PAD, ANALYTIC>), g, dim3(256), lds, s, vol, grid, theta, lin_x, lin_y,
+                       lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+  } else {
+    return EMO_ERR_UNSUPPORTED;
+  }
+  return emo_launch_status();
+}
+
+template <int PAD>
+int launch_pad(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
+               const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+               long vol_bstride, int in_layout, int out_layout, int variant, hipStream_t s) {
+  if (theta)
+    return launch<PAD, true>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                             in_layout, out_layout, variant, s);
+  return launch<PAD, false>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                            in_layout, out_layout, variant, s);
+}
+
+}  // namespace
+
+extern "C" int emo_grid_sample3d_f32(const float* vol, const float* grid, const float* theta, const float* lin_x,
+                                     const float* lin_y, const float* lin_z, float* out, int N, int C, int D, int H,
+                                     int W, int Do, int Ho, int Wo, int64_t vol_batch_stride, int padding_mode,
+                                     int in_layout, int out_layout, int variant, void* stream) {
+  if (!vol || !out || (!grid && !theta)) return EMO_ERR_BAD_ARG;
+  if (theta && (!lin_x || !lin_y || !lin_z)) return EMO_ERR_BAD_ARG;
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return EMO_ERR_BAD_ARG;
+  if (vol_batch_stride < 0) return EMO_ERR_BAD_ARG;
+  if (N > 65535) return EMO_ERR_UNSUPPORTED;
+  if ((long)D * H * W >= (1L << 31) / 4 || (long)Do * Ho * Wo >= (1L << 31) / 4) return EMO_ERR_UNSUPPORTED;
+  if (!emo_aligned16(vol) || !emo_aligned16(out)) return EMO_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  switch (padding_mode) {
+    case EMO_PAD_ZEROS:
+      return launch_pad<EMO_PAD_ZEROS>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
+                                       vol_batch_stride, in_layout, out_layout, variant, s);
+    case EMO_PAD_BORDER:
+      return launch_pad<EMO_PAD_BORDER>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
+                                        vol_batch_stride, in_layout, out_layout, variant, s);
+    case EMO_PAD_REFLECTION:
+      return launch_pad<EMO_PAD_REFLECTION>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
+                                            vol_batch_stride, in_layout, out_layout, variant, s);
+    default:
+      return EMO_ERR_BAD_ARG;
+  }
+}
+
+extern "C" int emo_volume_repack_f32(const float* in, float* out, int N, int C, int DHW, int to_channels_last,
+                                     void* stream) {
+  if (!in || !out || N <= 0 || C <= 0 || DHW <= 0) return EMO_ERR_BAD_ARG;
+  if (N > 65535) return EMO_ERR_UNSUPPORTED;
+  const int R = to_channels_last ? C : DHW;       // rows of the input matrix
+  const int Ccols = to_channels_last ? DHW : C;   // columns of the input matrix
+  dim3 g(emo_cdiv(Ccols, 64), emo_cdiv(R, 64), N);
+  if (g.y > 65535) return EMO_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(repack_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, R, Ccols);
+  return emo_launch_status();
+}

@@ -1,0 +1,92 @@
+"""ctypes binding of libemoportraits_hip.so -- the C ABI declared in include/emo_hip.h.
+
+The product path has NO fallback: if the library is missing or a kernel call fails, a RuntimeError is raised.
+PyTorch is only plumbing here (device memory, streams): tensors are passed as raw device pointers.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libemoportraits_hip.so")
+
+PAD_MODES = {"zeros": 0, "border": 1, "reflection": 2}
+LAYOUT_NCDHW, LAYOUT_NDHWC = 0, 1
+ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+
+_c_int, _c_i64, _c_void, _c_float = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
+
+# name -> argtypes; restype is int unless listed in _RESTYPES.  Mirrors include/emo_hip.h one to one
+# (tests/test_abi.py checks header <-> this table <-> exported symbols).
+SIGNATURES = {
+    "emo_abi_version": [],
+    "emo_build_info": [],
+    "emo_grid_sample3d_f32": [_c_void] * 7 + [_c_int] * 8 + [_c_i64] + [_c_int] * 4 + [_c_void],
+    "emo_volume_repack_f32": [_c_void, _c_void, _c_int, _c_int, _c_int, _c_int, _c_void],
+}
+_RESTYPES = {"emo_build_info": ctypes.c_char_p}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (idempotent).  Raises HipLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m emoportraits_amd.build` (there is no CPU/eager fallback)")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _c_int)
+    from . import _abi_version
+    v = lib.emo_abi_version()
+    if v != _abi_version.EMO_ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library {v}, python {_abi_version.EMO_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "EMO_ERR_BAD_ARG", -2: "EMO_ERR_UNSUPPORTED", -3: "EMO_ERR_ALIGN"}
+
+
+def check(rc, what):
+    if rc != 0:
+        name = _ERR.get(rc, f"hipError {rc}" if rc > 0 else f"error {rc}")
+        raise RuntimeError(f"{what} failed: {name}")
+
+
+def ptr(t):
+    """device pointer of a tensor (or None)"""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda_f32(*tensors):
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("emoportraits_amd ops run on the GPU only (got a %s tensor); there is no CPU path"
+                               % t.device.type)
+        if t.dtype != torch.float32:
+            raise RuntimeError("expected float32, got %s" % t.dtype)
+        if not t.is_contiguous():
+            raise RuntimeError("expected a contiguous tensor")

@@ -1,0 +1,147 @@
+"""GPU parity tests of the HIP 3-D grid_sample through the C ABI.
+Bar: bit-exact against torch's CPU F.grid_sample / the C oracle (integer+fp32 index arithmetic and the
+accumulation order are restated exactly)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import c_oracle  # noqa: E402
+import restate as O  # noqa: E402
+
+from emoportraits_amd import ops  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+PADS = ["zeros", "border", "reflection"]
+DEV = "cuda:0"
+
+
+def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=False):
+    """run every (in_layout, out_layout) combination; return dict name -> NCDHW cpu tensor"""
+    vol = vol_cpu.to(DEV)
+    grid = None if grid_cpu is None else grid_cpu.to(DEV)
+    theta = None if theta_cpu is None else theta_cpu.to(DEV)
+    res = {}
+    res["ncdhw"] = ops.grid_sample3d(vol, grid, theta, pm).cpu()
+    for cpb in (1, 5, 96):
+        res[f"ncdhw_cpb{cpb}"] = ops.grid_sample3d(vol, grid, theta, pm, variant=cpb).cpu()
+    if vol.shape[1] % 4 == 0:
+        vcl = ops.volume_to_channels_last(vol)
+        assert torch.equal(vcl.cpu(), vol_cpu.permute(0, 2, 3, 4, 1).contiguous())
+        ocl = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc")
+        res["cl"] = ops.volume_to_channels_first(ocl).cpu()
+        assert torch.equal(res["cl"], ocl.cpu().permute(0, 4, 1, 2, 3).contiguous())
+        res["cl2ncdhw"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw").cpu()
+    return res
+
+
+@pytest.mark.parametrize("pm", PADS)
+def test_kat_golden_bit_exact(golden_dir, pm):
+    k = dict(np.load(os.path.join(golden_dir, "sampler_kat.npz")))
+    vol, grid = torch.from_numpy(k["vol"]), torch.from_numpy(k["grid"])
+    for name, got in _all_layouts(vol, grid, pm=pm).items():
+        assert torch.equal(got, torch.from_numpy(k["out_" + pm])), f"{name} {pm}"
+    for name, got in _all_layouts(vol[:1].contiguous(), grid, pm=pm).items():
+        assert torch.equal(got, torch.from_numpy(k["out_shared_" + pm])), f"shared {name} {pm}"
+
+
+@pytest.mark.parametrize("pm", PADS)
+@pytest.mark.parametrize("shape", [((1, 8, 3, 5, 7), (2, 4, 6)), ((3, 4, 16, 9, 33), (5, 17, 70)), ((2, 12, 1, 1, 1), (1, 1, 1))])
+def test_random_shapes_vs_torch_cpu(pm, shape):
+    (N, C, D, H, W), (Do, Ho, Wo) = shape
+    g = torch.Generator().manual_seed(N * 100 + C)
+    vol = torch.randn(N, C, D, H, W, generator=g)
+    grid = torch.rand(N, Do, Ho, Wo, 3, generator=g) * 3 - 1.5
+    ref = F.grid_sample(vol, grid, padding_mode=pm, align_corners=False)
+    for name, got in _all_layouts(vol, grid, pm=pm).items():
+        assert torch.equal(got, ref), f"{name} {pm} {shape}"
+
+
+def test_odd_channel_count_ncdhw_only():
+    g = torch.Generator().manual_seed(3)
+    vol = torch.randn(2, 7, 3, 4, 5, generator=g)
+    grid = torch.rand(2, 3, 4, 5, 3, generator=g) * 2.4 - 1.2
+    got = ops.grid_sample3d(vol.to(DEV), grid.to(DEV)).cpu()
+    assert torch.equal(got, F.grid_sample(vol, grid, align_corners=False))
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        ops.grid_sample3d(vol.permute(0, 2, 3, 4, 1).contiguous().to(DEV), grid.to(DEV), in_layout="ndhwc", out_layout="ndhwc")
+
+
+def test_non_finite_coordinates_sample_nothing():
+    vol = torch.randn(1, 4, 2, 3, 4)
+    grid = torch.tensor([float("nan"), 0, 0, float("inf"), 0, 0, 0, -float("inf"), 0, 1e30, 0, 0]).view(1, 1, 1, 4, 3)
+    for name, got in _all_layouts(vol, grid).items():
+        assert torch.all(got == 0), name
+
+
+@pytest.mark.parametrize("pm", ["zeros", "reflection"])
+def test_full_size_released_shape_bit_exact(pm):
+    """[N,96,16,64,64] (the released latent volume), realistic warp = identity + 0.05*tanh(randn) and a hard one."""
+    g = torch.Generator().manual_seed(1)
+    C, D, S = 96, 16, 64
+    vol = torch.randn(1, C, D, S, S, generator=g)
+    ident = O.identity_grid_3d(D, S)[..., :3].view(1, D, S, S, 3)
+    warps = torch.cat([ident + 0.05 * torch.tanh(torch.randn(1, D, S, S, 3, generator=g)),
+                       ident * 1.3 + 0.3 * torch.randn(1, D, S, S, 3, generator=g)])
+    ref = torch.from_numpy(c_oracle.grid_sample3d(vol.numpy(), warps.numpy(), pm))   # shared volume, N=2
+    torch_ref = F.grid_sample(vol.expand(2, -1, -1, -1, -1), warps, padding_mode=pm, align_corners=False)
+    assert torch.equal(ref, torch_ref)
+    for name, got in _all_layouts(vol, warps, pm=pm).items():
+        assert torch.equal(got, ref), f"{name} {pm}"
+
+
+@pytest.mark.parametrize("pm", PADS)
+def test_analytic_affine_grid_equals_explicit_rotation_warp(golden_dir, pm):
+    """a2: theta applied in-kernel to the identity lattice == sampling with the materialised rotation warp."""
+    p = dict(np.load(os.path.join(golden_dir, "pose_theta.npz")))
+    theta = torch.from_numpy(p["theta"][:4])
+    g = torch.Generator().manual_seed(8)
+    C, D, S = 8, 16, 64
+    vol = torch.randn(1, C, D, S, S, generator=g)
+    grid = torch.from_numpy(c_oracle.affine_grid3d(theta[:, :3].numpy(), p["lin_s"], p["lin_s"], p["lin_z"]))
+    # the C fma-chain grid equals the reference's bmm grid on the committed sub-lattice up to 1 ulp (tests/test_oracle.py);
+    # with the SAME grid values the analytic kernel must be bit-exact
+    ref = F.grid_sample(vol.expand(4, -1, -1, -1, -1), grid, padding_mode=pm, align_corners=False)
+    for name, got in _all_layouts(vol, theta_cpu=theta, pm=pm).items():
+        assert torch.equal(got, ref), f"{name} {pm}"
+    # and against the reference's own construction (torch CPU bmm) within fp32 coordinate rounding
+    ref_bmm = F.grid_sample(vol.expand(4, -1, -1, -1, -1), O.rotation_warp(theta, D, S), padding_mode=pm, align_corners=False)
+    got = ops.grid_sample3d(vol.to(DEV), theta=theta.to(DEV), padding_mode=pm).cpu()
+    assert (got - ref_bmm).abs().max().item() <= 1e-4 * ref_bmm.abs().max().item()
+
+
+def test_size_independent_properties_at_batch_64():
+    """BASELINE config 2 size: 64 drivers sharing one canonical volume.  Properties that need no CPU reference:
+    (i) shared-volume call == per-sample call, (ii) channel permutation commutes with sampling bit-exactly,
+    (iii) the pixel-centre identity grid reproduces the volume exactly, (iv) all layouts agree bit-exactly."""
+    g = torch.Generator().manual_seed(64)
+    C, D, S, N = 96, 16, 64, 64
+    vol = torch.randn(1, C, D, S, S, generator=g).to(DEV)
+    ident = O.identity_grid_3d(D, S)[..., :3].view(1, D, S, S, 3)
+    grid = (ident + 0.05 * torch.tanh(torch.randn(N, D, S, S, 3, generator=g))).to(DEV)
+    out = ops.grid_sample3d(vol, grid)
+    one = ops.grid_sample3d(vol, grid[17:18].contiguous())
+    assert torch.equal(out[17:18], one)
+    perm = torch.randperm(C, generator=g).to(DEV)
+    outp = ops.grid_sample3d(vol[:, perm].contiguous(), grid[:4].contiguous())
+    assert torch.equal(outp, out[:4][:, perm])
+    vcl = ops.volume_to_channels_last(vol)
+    ocl = ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ndhwc")
+    assert torch.equal(ops.volume_to_channels_first(ocl), out)
+    assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw"), out)
+    zs, ys, xs = [((2 * torch.arange(n) + 1) / n - 1) for n in (D, S, S)]
+    zz, yy, xx = torch.meshgrid(zs, ys, xs, indexing="ij")
+    centre = torch.stack([xx, yy, zz], -1)[None].to(DEV)
+    rec = ops.grid_sample3d(vol, centre)
+    assert (rec - vol).abs().max().item() <= 2e-6 * vol.abs().max().item()
+
+
+def test_empty_batch_is_rejected():
+    vol = torch.randn(1, 4, 2, 2, 2, device=DEV)
+    with pytest.raises(RuntimeError, match="BAD_ARG"):
+        ops.grid_sample3d(vol, torch.zeros(1, 0, 1, 1, 3, device=DEV))

@@ -1,0 +1,124 @@
+"""CPU tests: the oracle (oracle/restate.py, oracle/grid_sample3d.c) against the committed golden fixtures that
+oracle/make_golden.py produced by running the real reference.  No GPU needed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import c_oracle  # noqa: E402
+import restate as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "sampler_kat.npz")))
+
+
+@pytest.fixture(scope="module")
+def pose(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "pose_theta.npz")))
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return torch.load(os.path.join(golden_dir, "tiny_hotpath.pt"), weights_only=False)
+
+
+@pytest.mark.parametrize("pm", ["zeros", "border", "reflection"])
+def test_sampler_restatements_match_golden_bit_exact(kat, pm):
+    for name, fn in (("numpy", O.grid_sample3d_restated), ("C", c_oracle.grid_sample3d)):
+        got = fn(kat["vol"], kat["grid"], pm)
+        assert np.array_equal(got, kat["out_" + pm]), f"{name} restatement differs from torch CPU ({pm})"
+    got = c_oracle.grid_sample3d(kat["vol"][:1], kat["grid"], pm)
+    assert np.array_equal(got, kat["out_shared_" + pm])
+
+
+@pytest.mark.parametrize("pm", ["zeros", "border", "reflection"])
+def test_c_oracle_matches_torch_cpu_random(pm):
+    g = torch.Generator().manual_seed(99)
+    vol = torch.randn(2, 6, 4, 9, 11, generator=g)
+    grid = torch.rand(2, 5, 7, 13, 3, generator=g) * 3 - 1.5
+    ref = F.grid_sample(vol, grid, padding_mode=pm, align_corners=False).numpy()
+    assert np.array_equal(c_oracle.grid_sample3d(vol.numpy(), grid.numpy(), pm), ref)
+
+
+def test_sampler_edge_cases():
+    vol = np.random.RandomState(0).randn(1, 2, 2, 3, 4).astype(np.float32)
+    # empty output
+    out = c_oracle.grid_sample3d(vol, np.zeros((1, 0, 1, 1, 3), np.float32))
+    assert out.shape == (1, 2, 0, 1, 1)
+    # non-finite coordinates sample nothing under zeros padding
+    grid = np.array([np.nan, 0, 0, np.inf, 0, 0, 0, -np.inf, 0], np.float32).reshape(1, 1, 1, 3, 3)
+    assert np.all(c_oracle.grid_sample3d(vol, grid) == 0)
+    # identity grid of pixel centres reproduces the volume exactly
+    D, H, W = 2, 3, 4
+    zs, ys, xs = [(2 * np.arange(n) + 1) / n - 1 for n in (D, H, W)]
+    g = np.stack(np.meshgrid(zs, ys, xs, indexing="ij")[::-1], -1)[None].astype(np.float32)
+    assert np.allclose(c_oracle.grid_sample3d(vol, g), vol, atol=1e-6)
+
+
+def test_get_transform_matrix_matches_reference(pose):
+    t = lambda k: torch.from_numpy(pose[k])
+    got = O.get_transform_matrix(t("scale"), t("rotation"), t("translation"))
+    assert torch.equal(got, t("theta"))
+    got1 = O.get_transform_matrix(t("scale")[:, :1].contiguous(), t("rotation"), t("translation"))
+    assert torch.equal(got1, t("theta_scalar_scale"))
+
+
+def test_rotation_warp_matches_reference(pose):
+    theta = torch.from_numpy(pose["theta"][:3])
+    sub = (slice(None), slice(0, 16, 5), slice(0, 64, 9), slice(0, 64, 7))
+    assert torch.equal(O.rotation_warp(theta, 16, 64)[sub], torch.from_numpy(pose["warp_sub"]))
+    assert torch.equal(O.rotation_warp(theta, 16, 64, inverse=True)[sub], torch.from_numpy(pose["warp_inv_sub"]))
+    # the C statement of the same (k-ordered fma chain) is what the HIP analytic-grid variant is checked against
+    g = c_oracle.affine_grid3d(pose["theta"][:3, :3], pose["lin_s"], pose["lin_s"], pose["lin_z"])
+    np.testing.assert_allclose(g[sub], pose["warp_sub"], rtol=0, atol=2.4e-7)
+
+
+def test_lattice_is_torch_linspace(pose):
+    assert np.array_equal(pose["lin_s"], torch.linspace(-1, 1, 64).numpy())
+    assert np.array_equal(pose["lin_z"], torch.linspace(-1, 1, 16).numpy())
+
+
+def _close(a, b, rtol=1e-5):
+    scale = b.abs().max().item() + 1e-30
+    return (a - b).abs().max().item() <= rtol * scale
+
+
+def test_restatement_matches_reference_tiny_hotpath(tiny):
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    sd, cfg = tiny["state_dict"], tiny["cfg"]
+    with torch.no_grad():
+        src = O.source_pass(sd, cfg, tiny["img"], tiny["idt_embed"], tiny["source_pose_embed"], tiny["theta_src"])
+        for k, ref in tiny["source"].items():
+            assert _close(src[k], ref), f"source.{k}"
+        for i in range(2):   # batch-1 calls, as the reference makes them: bit-exact
+            d1 = O.driver_pass(sd, cfg, tiny["source"]["canonical"], tiny["idt_embed"],
+                               tiny["target_pose_embed"][i:i + 1], tiny["theta_drv"][i:i + 1])
+            for k, ref in tiny["driver"][i].items():
+                assert torch.equal(d1[k], ref), f"driver[{i}].{k}"
+        # batched driver pass (the extension this repo adds) == the reference's batch-1 calls up to fp32
+        # summation-order noise of the CPU conv kernels (measured 2e-5 of max|ref|; bound 2e-4)
+        drv = O.driver_pass(sd, cfg, tiny["source"]["canonical"], tiny["idt_embed"], tiny["target_pose_embed"],
+                            tiny["theta_drv"])
+        for i in range(2):
+            for k, ref in tiny["driver"][i].items():
+                assert _close(drv[k][i:i + 1], ref, rtol=2e-4), f"driver[{i}].{k}"
+
+
+def test_ada_group_norm_double_affine_quirk(tiny):
+    """AdaptiveGroupNorm applies its static affine twice (utils.py:302-325): the restatement must too."""
+    sd = tiny["state_dict"]
+    p = "uv_generator_nw.blocks_3d.0.block_feats.0"
+    C = sd[p + ".weight"].numel()
+    x = torch.randn(2, C, 2, 3, 3)
+    dg, db = torch.randn(2, C), torch.randn(2, C)
+    y = O.ada_group_norm(x, sd, p, (dg, db))
+    base = F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+    want = base * (sd[p + ".weight"][None] + dg)[:, :, None, None, None] + (sd[p + ".bias"][None] + db)[:, :, None, None, None]
+    assert torch.allclose(y, want)
