@@ -263,6 +263,142 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------
+// v2 channels-last kernels: taps are computed ONCE per voxel (64 voxels per block, one lane each), parked in
+// LDS, and every (voxel, channel-quad) item then only does: 5 broadcast LDS reads, 8 x 16-byte gathers,
+// 64 mul/add.  v1 recomputed the ~150-instruction tap math in each of the C/4 lanes of a voxel and was
+// VALU-bound (15 us/sample vs a 5 us L1-bandwidth bound).  Out-of-range corners are handled by a wave-uniform
+// branch: the common all-in-range wave takes a path with no per-component selects.
+// ------------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) TapRec {
+  int off[8];
+  float w[8];
+  unsigned inb;
+  unsigned pad[3];
+};
+constexpr int VPB = 64;   // voxels per block
+
+template <int PAD, bool ANALYTIC>
+__device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const float* __restrict__ grid,
+                                           const float* __restrict__ theta, const float* __restrict__ lin_x,
+                                           const float* __restrict__ lin_y, const float* __restrict__ lin_z, int n,
+                                           int vox0, int nvox, int D, int H, int W, int Ho, int Wo) {
+  if (threadIdx.x < VPB) {
+    const int vox = vox0 + threadIdx.x;
+    Taps t;
+    if (vox < nvox) {
+      float gx, gy, gz;
+      load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+      compute_taps<PAD>(gx, gy, gz, D, H, W, t);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { t.off[k] = 0; t.w[k] = 0.0f; }
+      t.inb = 0;
+    }
+    TapRec r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { r.off[k] = t.off[k]; r.w[k] = t.w[k]; }
+    r.inb = t.inb; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    recs[threadIdx.x] = r;
+  }
+}
+
+__device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, const TapRec& r, unsigned row_bytes,
+                                              unsigned qbyte) {
+  float4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    v[k] = *reinterpret_cast<const float4*>(vbytes + ((unsigned)r.off[k] * row_bytes + qbyte));
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // wave-uniform: does every lane of this wave have all 8 corners in range?
+  if (__all(r.inb == 0xffu)) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = r.w[k];
+      acc.x = __fadd_rn(acc.x, __fmul_rn(v[k].x, w));
+      acc.y = __fadd_rn(acc.y, __fmul_rn(v[k].y, w));
+      acc.z = __fadd_rn(acc.z, __fmul_rn(v[k].z, w));
+      acc.w = __fadd_rn(acc.w, __fmul_rn(v[k].w, w));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool in = (r.inb >> k) & 1u;
+      const float w = r.w[k];
+      acc.x = __fadd_rn(acc.x, __fmul_rn(in ? v[k].x : 0.0f, w));
+      acc.y = __fadd_rn(acc.y, __fmul_rn(in ? v[k].y : 0.0f, w));
+      acc.z = __fadd_rn(acc.z, __fmul_rn(in ? v[k].z : 0.0f, w));
+      acc.w = __fadd_rn(acc.w, __fmul_rn(in ? v[k].w : 0.0f, w));
+    }
+  }
+  return acc;
+}
+
+// NDHWC -> NDHWC, grid = (ceil(nvox/64), 1, N)
+template <int PAD, bool ANALYTIC>
+__global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
+    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
+    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
+  __shared__ TapRec recs[VPB];
+  const int LPV = C >> 2;
+  const int nvox = Do * Ho * Wo;
+  const int n = blockIdx.z;
+  const int vox0 = blockIdx.x * VPB;
+  stage_taps<PAD, ANALYTIC>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
+  __syncthreads();
+  const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
+  const unsigned row_bytes = (unsigned)C * 4u;
+  const int nitems = min(VPB, nvox - vox0) * LPV;
+  float4* obase = reinterpret_cast<float4*>(out) + ((long)n * nvox + vox0) * LPV;
+  for (int item = threadIdx.x; item < nitems; item += 256) {
+    const int v = item / LPV;
+    const int q = item - v * LPV;
+    const TapRec r = recs[v];
+    obase[item] = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
+  }
+}
+
+// NDHWC -> NCDHW, grid = (ceil(nvox/64), 1, N); dynamic LDS = C * 65 floats (transpose tile)
+template <int PAD, bool ANALYTIC>
+__global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
+    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
+    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  TapRec* recs = reinterpret_cast<TapRec*>(smem);                 // VPB * 80 B
+  float* tile = smem + VPB * (sizeof(TapRec) / 4);                 // [C][VPB + 1]
+  constexpr int LD = VPB + 1;
+  const int LPV = C >> 2;
+  const int nvox = Do * Ho * Wo;
+  const int n = blockIdx.z;
+  const int vox0 = blockIdx.x * VPB;
+  stage_taps<PAD, ANALYTIC>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
+  __syncthreads();
+  const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
+  const unsigned row_bytes = (unsigned)C * 4u;
+  const int nv = min(VPB, nvox - vox0);
+  const int nitems = nv * LPV;
+  for (int item = threadIdx.x; item < nitems; item += 256) {
+    const int v = item / LPV;
+    const int q = item - v * LPV;
+    const TapRec r = recs[v];
+    const float4 acc = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
+    const int c = q * 4;
+    tile[(c + 0) * LD + v] = acc.x;
+    tile[(c + 1) * LD + v] = acc.y;
+    tile[(c + 2) * LD + v] = acc.z;
+    tile[(c + 3) * LD + v] = acc.w;
+  }
+  __syncthreads();
+  float* obase = out + (long)n * C * nvox + vox0;
+  for (int i = threadIdx.x; i < C * VPB; i += 256) {
+    const int c = i >> 6;
+    const int v = i & 63;
+    if (v < nv) obase[(long)c * nvox + v] = tile[c * LD + v];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // layout repack [N][C][S] <-> [N][S][C] through a 64x64 LDS tile
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -298,16 +434,32 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
                        out, C, D, H, W, Do, Ho, Wo, vol_bstride, cpb);
   } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NDHWC) {
     if (C % 4) return EMO_ERR_UNSUPPORTED;
-    dim3 g(emo_cdiv((long)nvox * (C / 4), 256), 1, N);
-    hipLaunchKernelGGL((gs3d_cl_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z, out,
-                       C, D, H, W, Do, Ho, Wo, vol_bstride);
+    if ((long)D * H * W * C * 4 >= (1L << 32)) return EMO_ERR_UNSUPPORTED;   // 32-bit byte offsets
+    if (variant == 1) {
+      dim3 g(emo_cdiv((long)nvox * (C / 4), 256), 1, N);
+      hipLaunchKernelGGL((gs3d_cl_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
+                         out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+    } else {
+      dim3 g(emo_cdiv(nvox, VPB), 1, N);
+      hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y,
+                         lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+    }
   } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NCDHW) {
     if (C % 4) return EMO_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)C * (Wo + 1) * sizeof(float);
-    if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
-    dim3 g(Do * Ho, 1, N);
-    hipLaunchKernelGGL((gs3d_cl2ncdhw_kernel<PAD, ANALYTIC>), g, dim3(256), lds, s, vol, grid, theta, lin_x, lin_y,
-                       lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+    if ((long)D * H * W * C * 4 >= (1L << 32)) return EMO_ERR_UNSUPPORTED;
+    if (variant == 1) {
+      const size_t lds = (size_t)C * (Wo + 1) * sizeof(float);
+      if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
+      dim3 g(Do * Ho, 1, N);
+      hipLaunchKernelGGL((gs3d_cl2ncdhw_kernel<PAD, ANALYTIC>), g, dim3(256), lds, s, vol, grid, theta, lin_x, lin_y,
+                         lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+    } else {
+      const size_t lds = VPB * sizeof(TapRec) + (size_t)C * (VPB + 1) * sizeof(float);
+      if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
+      dim3 g(emo_cdiv(nvox, VPB), 1, N);
+      hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, ANALYTIC>), g, dim3(256), lds, s, vol, grid, theta, lin_x,
+                         lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+    }
   } else {
     return EMO_ERR_UNSUPPORTED;
   }

@@ -37,6 +37,10 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
         res["cl"] = ops.volume_to_channels_first(ocl).cpu()
         assert torch.equal(res["cl"], ocl.cpu().permute(0, 4, 1, 2, 3).contiguous())
         res["cl2ncdhw"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw").cpu()
+        # variant 1 = the first-generation channels-last kernels (kept for A/B measurements)
+        ocl1 = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=1)
+        res["cl_v1"] = ocl1.cpu().permute(0, 4, 1, 2, 3).contiguous()
+        res["cl2ncdhw_v1"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw", variant=1).cpu()
     return res
 
 
