@@ -1,0 +1,60 @@
+// C ABI of the implicit-GEMM convolution (include/emo_hip.h: emo_conv_igemm_f32, emo_conv_pack_info).
+#include "conv_dispatch.h"
+
+conv_launch_fn conv_lookup_3x3_A(int, int);
+conv_launch_fn conv_lookup_3x3_B(int, int);
+conv_launch_fn conv_lookup_3x3_C(int, int);
+conv_launch_fn conv_lookup_1x1_A(int, int);
+conv_launch_fn conv_lookup_1x1_B(int, int);
+conv_launch_fn conv_lookup_1x1_C(int, int);
+
+static int shape_of_width(int Wl) {
+  if (Wl >= 128 && Wl % 128 == 0) return SHAPE_W128;
+  if (Wl == 64) return SHAPE_W64;
+  if (Wl == 32) return SHAPE_W32;
+  if (Wl == 16) return SHAPE_W16;
+  if (Wl == 8) return SHAPE_W8;
+  return -1;
+}
+
+extern "C" int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC) {
+  if (!BM || !KC) return EMO_ERR_BAD_ARG;
+  if (cfg == CFG_A) *BM = 128; else if (cfg == CFG_B) *BM = 64; else if (cfg == CFG_C) *BM = 32; else return EMO_ERR_BAD_ARG;
+  if (KH == 3 && KW == 3) *KC = EMO_CONV_KC_3X3;
+  else if (KH == 1 && KW == 1) *KC = EMO_CONV_KC_1X1;
+  else return EMO_ERR_UNSUPPORTED;
+  return EMO_OK;
+}
+
+extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias, const float* scale,
+                                  const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
+                                  int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
+                                  int cfg, void* stream) {
+  if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return EMO_ERR_BAD_ARG;
+  if (KD != 1 && KD != 3) return EMO_ERR_UNSUPPORTED;
+  if (KD == 3 && !(KH == 3 && KW == 3)) return EMO_ERR_UNSUPPORTED;
+  if (cfg < 0 || cfg >= N_CFGS) return EMO_ERR_BAD_ARG;
+  if (!emo_aligned16(wpk)) return EMO_ERR_ALIGN;
+  if (ups && D != 1) return EMO_ERR_UNSUPPORTED;
+  if ((long)Cin * D * H * W >= (1L << 31)) return EMO_ERR_UNSUPPORTED;   // 32-bit per-sample element offsets
+  ConvArgs a;
+  a.x = x; a.wpk = wpk; a.bias = bias; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+  a.Dl = D; a.Hl = ups ? 2 * H : H; a.Wl = ups ? 2 * W : W;
+  a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
+  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0;
+  const int shape = shape_of_width(a.Wl);
+  if (shape < 0) return EMO_ERR_UNSUPPORTED;
+  conv_launch_fn fn = nullptr;
+  if (KH == 3 && KW == 3) {
+    fn = cfg == CFG_A ? conv_lookup_3x3_A(shape, ups) : cfg == CFG_B ? conv_lookup_3x3_B(shape, ups) : conv_lookup_3x3_C(shape, ups);
+  } else if (KH == 1 && KW == 1) {
+    fn = cfg == CFG_A ? conv_lookup_1x1_A(shape, ups) : cfg == CFG_B ? conv_lookup_1x1_B(shape, ups) : conv_lookup_1x1_C(shape, ups);
+  } else {
+    return EMO_ERR_UNSUPPORTED;
+  }
+  if (!fn) return EMO_ERR_UNSUPPORTED;
+  return fn(a, (hipStream_t)stream);
+}

@@ -1,0 +1,25 @@
+// Dispatch table of the implicit-GEMM convolution instantiations (see conv_igemm.h).
+#pragma once
+#include "conv_igemm.h"
+
+// tile-shape ids: chosen from the logical output width
+enum { SHAPE_W128 = 0, SHAPE_W64 = 1, SHAPE_W32 = 2, SHAPE_W16 = 3, SHAPE_W8 = 4, N_SHAPES = 5 };
+// block configs: A = 128 co x 128 pos (waves 2x2, wave tile 64x64); B = 64 co x 128 pos (waves 1x4, wave tile 64x32);
+// C = 32 co x 128 pos (waves 1x4, wave tile 32x32)
+enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, N_CFGS = 3 };
+
+typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
+
+
+#define EMO_CONV_KC_3X3 4
+#define EMO_CONV_KC_1X1 16
+
+#define CONV_FOR_SHAPE(KH, KW, KC, TM, TP, WGM, WGP, shape, ups)                                              \
+  ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 1, 128, TM, TP, WGM, WGP, true>          \
+                                  : &conv_igemm_launch<KH, KW, KC, 1, 1, 128, TM, TP, WGM, WGP, false>)        \
+   : (ups)               ? (conv_launch_fn) nullptr                                                            \
+   : (shape) == SHAPE_W64 ? &conv_igemm_launch<KH, KW, KC, 1, 2, 64, TM, TP, WGM, WGP, false>                 \
+   : (shape) == SHAPE_W32 ? &conv_igemm_launch<KH, KW, KC, 1, 4, 32, TM, TP, WGM, WGP, false>                 \
+   : (shape) == SHAPE_W16 ? &conv_igemm_launch<KH, KW, KC, 1, 8, 16, TM, TP, WGM, WGP, false>                 \
+   : (shape) == SHAPE_W8  ? &conv_igemm_launch<KH, KW, KC, 2, 8, 8, TM, TP, WGM, WGP, false>                  \
+                          : (conv_launch_fn) nullptr)

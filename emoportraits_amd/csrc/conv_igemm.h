@@ -1,0 +1,304 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a
+// k-ordered fmaf chain, 64 FLOP/clk/SIMD = 157 TF/chip) -- SURVEY.md section 8 rows a5, a9, a10 (and a6-a8).
+//
+// Replaces the F.conv2d / F.conv3d calls inside ResBlock / ConvBlock of the reference
+// (networks/volumetric_avatar/utils.py:661-788) together with the pointwise work around them:
+//   * the GroupNorm-apply + ReLU that precedes every conv of a ResBlock (utils.py:711-731) is folded into the
+//     conv's input staging as a per-(sample, channel) affine  x*scale + shift  followed by max(.,0)
+//     (scale/shift come from emo_groupnorm_affine_f32); zero padding is applied AFTER that transform, exactly
+//     as F.conv does on the normalised tensor;
+//   * the nearest-neighbour x2 upsampling of the decoder's up-blocks (utils.py:684-688,764-781) is folded
+//     into the input gather (source index = logical index >> 1);
+//   * bias, the residual/skip addition (utils.py:783) and tanh/sigmoid heads are applied in the epilogue.
+// Spectral norm / weight standardisation are folded into the weights once at load time.
+//
+// GEMM view: D[co][p] = sum_k A[co][k] * B[k][p],  k = (ci, kd, kh, kw), p = output position.
+//   rows (MFMA "i") = output channels, columns (MFMA "j") = positions => NC(D)HW stores are coalesced.
+//   One stage = KC input channels x one depth tap x all KHxKW taps.  The raw input patch
+//   [KC][TZ][TR+KH-1][TW+KW-1] is staged in LDS once and the B operand is read straight from it (no im2col
+//   expansion): lane (half=l>>5, j=l&31) reads patch[2*pair+half][.. + r][.. + s], i.e. the two k-values of an
+//   MFMA step are two CHANNELS at the same tap, so every LDS address is lane_base + compile-time immediate.
+//   Weights are pre-packed on the host as [co_tile][stage][pair][tap][half][BM] so a stage's A tile is one
+//   contiguous block copied with 16-byte loads.
+// Block = 256 threads = 4 waves; wave tile = (TM x 32) x (TP x 32); LDS double-buffered, one barrier/stage.
+#pragma once
+#include "common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x;      // [N, Cin, D, H, W]  (source dims; logical dims are (D, 2H, 2W) when UPS)
+  const float* wpk;    // packed weights
+  const float* bias;   // [Cout] or null
+  const float* scale;  // [N, Cin] or null: input transform x*scale + shift (GroupNorm folded)
+  const float* shift;  // [N, Cin]
+  const float* res;    // residual added in the epilogue (shape of out; pre-upsample shape if res_ups) or null
+  float* out;          // [N, Cout, Dl, Hl, Wl]
+  int N, Cin, Cout;
+  int D, H, W;         // source dims
+  int Dl, Hl, Wl;      // logical = output dims
+  int KD;              // depth taps (1 or 3), padding KD/2
+  int relu_in;         // relu after the input affine (also usable without scale)
+  int act;             // EMO_ACT_*
+  int res_ups;         // residual is read at (z, y>>1, x>>1) from a [N,Cout,Dl,Hl/2,Wl/2] tensor
+  int n_cchunks;       // ceil(Cin / KC)
+  int tiles_x, tiles_y, tiles_z;
+};
+
+template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
+struct ConvCfg {
+  static constexpr int BM = WGM * TM * 32;
+  static constexpr int BP = WGP * TP * 32;
+  static constexpr int TAPS = KH * KW;
+  static constexpr int KLOC = KC * TAPS;
+  static constexpr int PR = TR + KH - 1;
+  static constexpr int PW = TW + KW - 1;
+  static constexpr int CHS = TZ * PR * PW;          // patch floats per input channel
+  static constexpr int PATCH = KC * CHS;
+  static constexpr int ASZ = KLOC * BM;             // floats of one stage's weight tile
+  static constexpr int BUF = ASZ + ((PATCH + 3) & ~3);
+  static constexpr int NPE = (PATCH + 255) / 256;   // patch elements per thread
+  static constexpr int NA4 = (ASZ / 4 + 255) / 256; // float4 weight loads per thread
+  static_assert(WGM * WGP == 4, "4 waves per block");
+  static_assert(TZ * TR * TW == BP, "position tile must equal BP");
+  static_assert(KC % 2 == 0, "channels are consumed in pairs");
+  static_assert(ASZ % 4 == 0, "weight tile must be float4-copyable");
+  static_assert(TM * TP <= 4, "accumulator budget");
+};
+
+__device__ __forceinline__ float emo_act(float v, int act) {
+  if (act == EMO_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == EMO_ACT_TANH) return tanhf(v);
+  if (act == EMO_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+  using Cfg = ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
+  constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS;
+  constexpr int PATCH = Cfg::PATCH, ASZ = Cfg::ASZ, BUF = Cfg::BUF, NPE = Cfg::NPE, NA4 = Cfg::NA4;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_scale = smem + 2 * BUF;          // [Cin] (only when a.scale)
+  float* s_shift = s_scale + a.Cin;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm = wave / WGP, wp = wave % WGP;
+  const int m0 = wm * TM * 32, p0 = wp * TP * 32;
+
+  const int n = blockIdx.z;
+  const int cotile = blockIdx.y;
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+  const int tz = bx;
+  const int x0 = tx * TW, y0 = ty * TR, z0 = tz * TZ;
+
+  const int HW = a.H * a.W;
+  const long DHW = (long)a.D * HW;
+  const float* xn = a.x + (long)n * a.Cin * DHW;
+  const bool has_affine = a.scale != nullptr;
+  const bool relu_in = a.relu_in != 0;
+  const int padD = a.KD >> 1;
+
+  if (has_affine) {
+    for (int c = tid; c < a.Cin; c += 256) {
+      s_scale[c] = a.scale[(long)n * a.Cin + c];
+      s_shift[c] = a.shift[(long)n * a.Cin + c];
+    }
+  }
+
+  // ---- per-thread description of the patch elements this thread stages (constant over stages) ----
+  int p_goff[NPE];     // ci*DHW + ys*W + xs   (z term added per stage)
+  int p_ci[NPE];       // channel within the chunk
+  int p_pz[NPE];       // z within the tile
+  bool p_ok[NPE];      // (y, x) inside the logical image and element index inside the patch
+#pragma unroll
+  for (int i = 0; i < NPE; ++i) {
+    const int e = tid + i * 256;
+    const int ci = e / CHS;
+    const int rem = e - ci * CHS;
+    const int pz = rem / (PR * PW);
+    const int rem2 = rem - pz * (PR * PW);
+    const int pr = rem2 / PW;
+    const int pc = rem2 - pr * PW;
+    const int yl = y0 + pr - (KH >> 1);
+    const int xl = x0 + pc - (KW >> 1);
+    p_ok[i] = (e < PATCH) && ((unsigned)yl < (unsigned)a.Hl) && ((unsigned)xl < (unsigned)a.Wl);
+    const int ys = UPS ? (yl >> 1) : yl;
+    const int xs = UPS ? (xl >> 1) : xl;
+    p_goff[i] = (int)(ci * DHW) + ys * a.W + xs;
+    p_ci[i] = ci;
+    p_pz[i] = pz;
+  }
+
+  const int nstages = a.n_cchunks * a.KD;
+  const float4* wsrc = reinterpret_cast<const float4*>(a.wpk) + ((long)cotile * nstages) * (ASZ / 4);
+
+  float pv[NPE];
+  bool pvok[NPE];
+  float4 av[NA4];
+
+// Both staging halves are macros (not lambdas / conditionals) so that pv[] / av[] are unconditionally defined
+// straight-line values and stay in VGPRs (a conditional or lambda-captured definition sent them to scratch).
+#define EMO_ISSUE_LOADS(stage_)                                                                       \
+  {                                                                                                   \
+    const int cc_ = (stage_) / a.KD;                                                                  \
+    const int t_ = (stage_) - cc_ * a.KD;                                                             \
+    const int ci0_ = cc_ * KC;                                                                        \
+    const float* xc_ = xn + (long)ci0_ * DHW;                                                         \
+    _Pragma("unroll") for (int i = 0; i < NPE; ++i) {                                                 \
+      const int zi = z0 + p_pz[i] + t_ - padD;                                                        \
+      const bool ok = p_ok[i] && ((unsigned)zi < (unsigned)a.D) && (ci0_ + p_ci[i] < a.Cin);          \
+      pvok[i] = ok;                                                                                   \
+      pv[i] = ok ? xc_[p_goff[i] + zi * HW] : 0.0f;                                                   \
+    }                                                                                                 \
+    const float4* ws_ = wsrc + (long)(stage_) * (ASZ / 4);                                            \
+    _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                 \
+      const int idx = tid + i * 256;                                                                  \
+      av[i] = ws_[idx < ASZ / 4 ? idx : ASZ / 4 - 1];                                                 \
+    }                                                                                                 \
+  }
+
+#define EMO_STORE_STAGE(stage_, buf_)                                                                 \
+  {                                                                                                   \
+    const int ci0_ = ((stage_) / a.KD) * KC;                                                          \
+    float4* As4_ = reinterpret_cast<float4*>(buf_);                                                   \
+    _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                 \
+      const int idx = tid + i * 256;                                                                  \
+      if (idx < ASZ / 4) As4_[idx] = av[i];                                                           \
+    }                                                                                                 \
+    float* Ps_ = (buf_) + ASZ;                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NPE; ++i) {                                                 \
+      const int e = tid + i * 256;                                                                    \
+      if (e < PATCH) {                                                                                \
+        float v = pv[i];                                                                              \
+        if (has_affine) {                                                                             \
+          const int c = ci0_ + p_ci[i];                                                               \
+          const int cs = c < a.Cin ? c : 0;                                                           \
+          v = __fmaf_rn(v, s_scale[cs], s_shift[cs]);                                                 \
+        }                                                                                             \
+        if (relu_in) v = fmaxf(v, 0.0f);                                                              \
+        Ps_[e] = pvok[i] ? v : 0.0f; /* zero padding applies to the transformed tensor */            \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+
+  floatx16 acc[TM][TP];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // lane bases into the LDS tiles
+  const int a_base = half * BM + m0 + l32;
+  int b_base[TP];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int p = p0 + j * 32 + l32;
+    const int col = p % TW;
+    const int row = (p / TW) % TR;
+    const int pz = p / (TW * TR);
+    b_base[j] = half * CHS + pz * (PR * PW) + row * PW + col;
+  }
+
+  __syncthreads();                 // s_scale / s_shift visible
+  EMO_ISSUE_LOADS(0);
+  EMO_STORE_STAGE(0, smem);
+  __syncthreads();
+
+  for (int st = 0; st < nstages; ++st) {
+    float* cur = smem + (st & 1) * BUF;
+    float* nxt = smem + ((st + 1) & 1) * BUF;
+    // prefetch the next stage while this one computes; on the last stage the (clamped) prefetch re-reads the
+    // last stage and its LDS write lands in the idle buffer -- harmless, and it keeps the loop branch-free
+    const int stn = (st + 1) < nstages ? (st + 1) : st;
+    EMO_ISSUE_LOADS(stn);
+
+    const float* As = cur;
+    const float* Ps = cur + ASZ;
+#pragma unroll
+    for (int pair = 0; pair < KC / 2; ++pair) {
+#pragma unroll
+      for (int r = 0; r < KH; ++r) {
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+          const int tap = r * KW + s;
+          float av_[TM], bv_[TP];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av_[i] = As[a_base + ((pair * TAPS + tap) * 2) * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < TP; ++j) bv_[j] = Ps[b_base[j] + (pair * 2) * CHS + r * PW + s];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    EMO_STORE_STAGE(stn, nxt);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+  const long plane = (long)a.Hl * a.Wl;
+  const long ovol = (long)a.Dl * plane;
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int p = p0 + j * 32 + l32;
+    const int col = p % TW;
+    const int row = (p / TW) % TR;
+    const int pz = p / (TW * TR);
+    const int z = z0 + pz, y = y0 + row, x = x0 + col;
+    const long sp = (long)z * plane + (long)y * a.Wl + x;
+    long rsp = sp;
+    long rvol = ovol;
+    if (a.res_ups) {
+      const int Wr = a.Wl >> 1, Hr = a.Hl >> 1;
+      rsp = ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
+      rvol = (long)a.Dl * Hr * Wr;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cotile * BM + m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a.Cout) {
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[co];
+          if (a.res) v += a.res[((long)n * a.Cout + co) * rvol + rsp];
+          v = emo_act(v, a.act);
+          a.out[((long)n * a.Cout + co) * ovol + sp] = v;
+        }
+      }
+    }
+  }
+}
+
+#undef EMO_ISSUE_LOADS
+#undef EMO_STORE_STAGE
+
+// host-side launcher for one instantiation
+template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
+int conv_igemm_launch(ConvArgs a, hipStream_t s) {
+  using Cfg = ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
+  if (a.Wl % TW || a.Hl % TR || a.Dl % TZ) return EMO_ERR_UNSUPPORTED;
+  a.tiles_x = a.Wl / TW;
+  a.tiles_y = a.Hl / TR;
+  a.tiles_z = a.Dl / TZ;
+  a.n_cchunks = (a.Cin + KC - 1) / KC;
+  const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+  if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
+  const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
+  const size_t lds = (size_t)(2 * Cfg::BUF + (a.scale ? 2 * a.Cin : 0)) * sizeof(float);
+  if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
+  dim3 g((unsigned)nt, cot, a.N);
+  hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>), g, dim3(256), lds, s, a);
+  return emo_launch_status();
+}

@@ -1,0 +1,5 @@
+// instantiations of conv_igemm_kernel: 3x3 taps, block config B
+#include "conv_dispatch.h"
+conv_launch_fn conv_lookup_3x3_B(int shape, int ups) {
+  return CONV_FOR_SHAPE(3, 3, EMO_CONV_KC_3X3, 2, 1, 1, 4, shape, ups);
+}

@@ -97,30 +97,43 @@ __device__ __forceinline__ float affine_row(const float* __restrict__ t, float u
   return acc;
 }
 
-template <bool ANALYTIC>
+// where the sampling coordinate of output voxel `vox` comes from
+enum { MODE_GRID = 0,    // explicit grid [N,Do,Ho,Wo,3]
+       MODE_THETA = 1,   // head-pose affine of the identity lattice (a2)
+       MODE_DELTA = 2 }; // identity lattice + planar deltas [N,3,Do,Ho,Wo]: WarpGenerator's
+                         // warp = (identity_grid + deltas).permute(0,2,3,4,1)  (warp_generator_resnet.py:178)
+
+template <int MODE>
 __device__ __forceinline__ void load_coord(const float* __restrict__ grid, const float* __restrict__ theta,
                                            const float* __restrict__ lin_x, const float* __restrict__ lin_y,
                                            const float* __restrict__ lin_z, int n, int vox, int nvox, int Ho, int Wo,
                                            float& gx, float& gy, float& gz) {
-  if (ANALYTIC) {
+  if (MODE == MODE_GRID) {
+    const float* g = grid + ((long)n * nvox + vox) * 3;
+    gx = g[0]; gy = g[1]; gz = g[2];
+  } else {
     const int x = vox % Wo;
     const int y = (vox / Wo) % Ho;
     const int z = vox / (Wo * Ho);
     const float u = lin_x[x], v = lin_y[y], w = lin_z[z];
-    const float* t = theta + (long)n * 12;
-    gx = affine_row(t + 0, u, v, w);
-    gy = affine_row(t + 4, u, v, w);
-    gz = affine_row(t + 8, u, v, w);
-  } else {
-    const float* g = grid + ((long)n * nvox + vox) * 3;
-    gx = g[0]; gy = g[1]; gz = g[2];
+    if (MODE == MODE_THETA) {
+      const float* t = theta + (long)n * 12;
+      gx = affine_row(t + 0, u, v, w);
+      gy = affine_row(t + 4, u, v, w);
+      gz = affine_row(t + 8, u, v, w);
+    } else {
+      const float* d = grid + (long)n * 3 * nvox + vox;
+      gx = __fadd_rn(u, d[0]);
+      gy = __fadd_rn(v, d[nvox]);
+      gz = __fadd_rn(w, d[2L * nvox]);
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // NCDHW -> NCDHW.  grid = (ceil(nvox/256), channel chunks, N); one lane per output voxel.
 // ------------------------------------------------------------------------------------------------------
-template <int PAD, bool ANALYTIC>
+template <int PAD, int MODE>
 __global__ __launch_bounds__(256) void gs3d_ncdhw_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256) void gs3d_ncdhw_kernel(
   const int c0 = blockIdx.y * c_per_block;
   const int c1 = min(c0 + c_per_block, C);
   float gx, gy, gz;
-  load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+  load_coord<MODE>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
   Taps t;
   compute_taps<PAD>(gx, gy, gz, D, H, W, t);
   const long DHW = (long)D * H * W;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void gs3d_ncdhw_kernel(
 // NDHWC -> NDHWC.  item = (voxel, channel quad); lanes of a voxel are adjacent so that each corner is read
 // as LPV consecutive float4 (C*4 contiguous bytes).  grid = (ceil(nvox*LPV/256), 1, N)
 // ------------------------------------------------------------------------------------------------------
-template <int PAD, bool ANALYTIC>
+template <int PAD, int MODE>
 __global__ __launch_bounds__(256) void gs3d_cl_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_kernel(
   const int q = (int)(item - (long)vox * LPV);
   const int n = blockIdx.z;
   float gx, gy, gz;
-  load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+  load_coord<MODE>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
   Taps t;
   compute_taps<PAD>(gx, gy, gz, D, H, W, t);
   const float4* vp = reinterpret_cast<const float4*>(vol + (long)n * vol_bstride) + q;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_kernel(
 // NDHWC -> NCDHW.  One block per output row (n, z, y): Wo voxels x LPV quads, results transposed through
 // LDS so that the NCDHW stores are full 256-byte rows.  dynamic LDS = C * (Wo + 1) floats.
 // ------------------------------------------------------------------------------------------------------
-template <int PAD, bool ANALYTIC>
+template <int PAD, int MODE>
 __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_kernel(
     const int q = item - x * LPV;
     const int vox = row * Wo + x;
     float gx, gy, gz;
-    load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+    load_coord<MODE>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
     Taps t;
     compute_taps<PAD>(gx, gy, gz, D, H, W, t);
     const float4* vp = vbase + q;
@@ -277,7 +290,7 @@ struct __attribute__((aligned(16))) TapRec {
 };
 constexpr int VPB = 64;   // voxels per block
 
-template <int PAD, bool ANALYTIC>
+template <int PAD, int MODE>
 __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const float* __restrict__ grid,
                                            const float* __restrict__ theta, const float* __restrict__ lin_x,
                                            const float* __restrict__ lin_y, const float* __restrict__ lin_z, int n,
@@ -287,7 +300,7 @@ __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const floa
     Taps t;
     if (vox < nvox) {
       float gx, gy, gz;
-      load_coord<ANALYTIC>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+      load_coord<MODE>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
       compute_taps<PAD>(gx, gy, gz, D, H, W, t);
     } else {
 #pragma unroll
@@ -334,7 +347,7 @@ __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, c
 }
 
 // NDHWC -> NDHWC, grid = (ceil(nvox/64), 1, N)
-template <int PAD, bool ANALYTIC>
+template <int PAD, int MODE>
 __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
   const int nvox = Do * Ho * Wo;
   const int n = blockIdx.z;
   const int vox0 = blockIdx.x * VPB;
-  stage_taps<PAD, ANALYTIC>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
+  stage_taps<PAD, MODE>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
   __syncthreads();
   const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
   const unsigned row_bytes = (unsigned)C * 4u;
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
 }
 
 // NDHWC -> NCDHW, grid = (ceil(nvox/64), 1, N); dynamic LDS = C * 65 floats (transpose tile)
-template <int PAD, bool ANALYTIC>
+template <int PAD, int MODE>
 __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   const int nvox = Do * Ho * Wo;
   const int n = blockIdx.z;
   const int vox0 = blockIdx.x * VPB;
-  stage_taps<PAD, ANALYTIC>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
+  stage_taps<PAD, MODE>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
   __syncthreads();
   const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
   const unsigned row_bytes = (unsigned)C * 4u;
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ i
   }
 }
 
-template <int PAD, bool ANALYTIC>
+template <int PAD, int MODE>
 int launch(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
            const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
            long vol_bstride, int in_layout, int out_layout, int variant, hipStream_t s) {
@@ -430,18 +443,18 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
     int cpb = variant > 0 ? variant : 8;
     if (cpb > C) cpb = C;
     dim3 g(emo_cdiv(nvox, 256), emo_cdiv(C, cpb), N);
-    hipLaunchKernelGGL((gs3d_ncdhw_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
+    hipLaunchKernelGGL((gs3d_ncdhw_kernel<PAD, MODE>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
                        out, C, D, H, W, Do, Ho, Wo, vol_bstride, cpb);
   } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NDHWC) {
     if (C % 4) return EMO_ERR_UNSUPPORTED;
     if ((long)D * H * W * C * 4 >= (1L << 32)) return EMO_ERR_UNSUPPORTED;   // 32-bit byte offsets
     if (variant == 1) {
       dim3 g(emo_cdiv((long)nvox * (C / 4), 256), 1, N);
-      hipLaunchKernelGGL((gs3d_cl_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
+      hipLaunchKernelGGL((gs3d_cl_kernel<PAD, MODE>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
                          out, C, D, H, W, Do, Ho, Wo, vol_bstride);
     } else {
       dim3 g(emo_cdiv(nvox, VPB), 1, N);
-      hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, ANALYTIC>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y,
+      hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y,
                          lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
     }
   } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NCDHW) {
@@ -451,13 +464,13 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
       const size_t lds = (size_t)C * (Wo + 1) * sizeof(float);
       if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
       dim3 g(Do * Ho, 1, N);
-      hipLaunchKernelGGL((gs3d_cl2ncdhw_kernel<PAD, ANALYTIC>), g, dim3(256), lds, s, vol, grid, theta, lin_x, lin_y,
+      hipLaunchKernelGGL((gs3d_cl2ncdhw_kernel<PAD, MODE>), g, dim3(256), lds, s, vol, grid, theta, lin_x, lin_y,
                          lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
     } else {
       const size_t lds = VPB * sizeof(TapRec) + (size_t)C * (VPB + 1) * sizeof(float);
       if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
       dim3 g(emo_cdiv(nvox, VPB), 1, N);
-      hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, ANALYTIC>), g, dim3(256), lds, s, vol, grid, theta, lin_x,
+      hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE>), g, dim3(256), lds, s, vol, grid, theta, lin_x,
                          lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
     }
   } else {
@@ -469,12 +482,15 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
 template <int PAD>
 int launch_pad(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
-               long vol_bstride, int in_layout, int out_layout, int variant, hipStream_t s) {
+               long vol_bstride, int in_layout, int out_layout, int variant, int grid_kind, hipStream_t s) {
   if (theta)
-    return launch<PAD, true>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
-                             in_layout, out_layout, variant, s);
-  return launch<PAD, false>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
-                            in_layout, out_layout, variant, s);
+    return launch<PAD, MODE_THETA>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                   in_layout, out_layout, variant, s);
+  if (grid_kind == 1)
+    return launch<PAD, MODE_DELTA>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                   in_layout, out_layout, variant, s);
+  return launch<PAD, MODE_GRID>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                in_layout, out_layout, variant, s);
 }
 
 }  // namespace
@@ -482,9 +498,11 @@ int launch_pad(const float* vol, const float* grid, const float* theta, const fl
 extern "C" int emo_grid_sample3d_f32(const float* vol, const float* grid, const float* theta, const float* lin_x,
                                      const float* lin_y, const float* lin_z, float* out, int N, int C, int D, int H,
                                      int W, int Do, int Ho, int Wo, int64_t vol_batch_stride, int padding_mode,
-                                     int in_layout, int out_layout, int variant, void* stream) {
+                                     int in_layout, int out_layout, int variant, int grid_kind, void* stream) {
   if (!vol || !out || (!grid && !theta)) return EMO_ERR_BAD_ARG;
-  if (theta && (!lin_x || !lin_y || !lin_z)) return EMO_ERR_BAD_ARG;
+  if (grid_kind != 0 && grid_kind != 1) return EMO_ERR_BAD_ARG;
+  if ((theta || grid_kind == 1) && (!lin_x || !lin_y || !lin_z)) return EMO_ERR_BAD_ARG;
+  if (theta && grid_kind == 1) return EMO_ERR_BAD_ARG;
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return EMO_ERR_BAD_ARG;
   if (vol_batch_stride < 0) return EMO_ERR_BAD_ARG;
   if (N > 65535) return EMO_ERR_UNSUPPORTED;
@@ -494,13 +512,13 @@ extern "C" int emo_grid_sample3d_f32(const float* vol, const float* grid, const 
   switch (padding_mode) {
     case EMO_PAD_ZEROS:
       return launch_pad<EMO_PAD_ZEROS>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
-                                       vol_batch_stride, in_layout, out_layout, variant, s);
+                                       vol_batch_stride, in_layout, out_layout, variant, grid_kind, s);
     case EMO_PAD_BORDER:
       return launch_pad<EMO_PAD_BORDER>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
-                                        vol_batch_stride, in_layout, out_layout, variant, s);
+                                        vol_batch_stride, in_layout, out_layout, variant, grid_kind, s);
     case EMO_PAD_REFLECTION:
       return launch_pad<EMO_PAD_REFLECTION>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
-                                            vol_batch_stride, in_layout, out_layout, variant, s);
+                                            vol_batch_stride, in_layout, out_layout, variant, grid_kind, s);
     default:
       return EMO_ERR_BAD_ARG;
   }

@@ -1,0 +1,115 @@
+// Resampling + pointwise helpers of the hot path for gfx950 (all HBM-bound, one pass each).
+//
+//   emo_upsample_trilinear_f32  F.interpolate(x, scale_factor=(sd,sh,sw), mode='trilinear') with align_corners=False,
+//                               scale factors 1 or 2 per axis: WarpGenerator.forward
+//                               (networks/volumetric_avatar/warp_generator_resnet.py:163-166) and Unet3D.forward
+//                               (unet_3d.py:223,269-272).
+//   emo_avgpool_f32             nn.AvgPool3d / AvgPool2d with kernel == stride in {1,2} per axis
+//                               (downsampling_layers['avgpool'(_3d)], utils.py:962-967; warp_generator_resnet.py:118,
+//                               unet_3d.py:84-86,192-193, local_encoder.py via ResBlock stride 2).
+//   emo_add_f32                 out = (a + b[i % period]) * alpha  (Unet3D skip sum unet_3d.py:281; embed mix va.py:857).
+#include "common.h"
+
+namespace {
+
+// ATen area_pixel_compute_source_index(scale = 1/scale_factor, dst, align_corners=False, cubic=False):
+//   src = scale * (dst + 0.5) - 0.5, clamped below at 0
+__device__ __forceinline__ void lin_coeff(int o, int in_size, int factor, int& i0, int& i1, float& l0, float& l1) {
+  if (factor == 1) { i0 = o; i1 = o; l0 = 1.0f; l1 = 0.0f; return; }
+  float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample_trilinear_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                  long NC, int D, int H, int W, int fd, int fh, int fw) {
+  const int Do = D * fd, Ho = H * fh, Wo = W * fw;
+  const long total = NC * Do * Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xo = (int)(i % Wo);
+    long r = i / Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const long nc = r / Do;
+    int z0, z1, y0, y1, x0, x1;
+    float lz0, lz1, ly0, ly1, lx0, lx1;
+    lin_coeff(zo, D, fd, z0, z1, lz0, lz1);
+    lin_coeff(yo, H, fh, y0, y1, ly0, ly1);
+    lin_coeff(xo, W, fw, x0, x1, lx0, lx1);
+    const float* p = x + nc * (long)D * H * W;
+    const long HW = (long)H * W;
+    const float v000 = p[z0 * HW + y0 * W + x0], v001 = p[z0 * HW + y0 * W + x1];
+    const float v010 = p[z0 * HW + y1 * W + x0], v011 = p[z0 * HW + y1 * W + x1];
+    const float v100 = p[z1 * HW + y0 * W + x0], v101 = p[z1 * HW + y0 * W + x1];
+    const float v110 = p[z1 * HW + y1 * W + x0], v111 = p[z1 * HW + y1 * W + x1];
+    // ATen upsample_trilinear3d: t0 * (h0 * (w0 * v000 + w1 * v001) + h1 * (w0 * v010 + w1 * v011)) + t1 * (...)
+    const float a = lz0 * (ly0 * (lx0 * v000 + lx1 * v001) + ly1 * (lx0 * v010 + lx1 * v011));
+    const float b = lz1 * (ly0 * (lx0 * v100 + lx1 * v101) + ly1 * (lx0 * v110 + lx1 * v111));
+    out[i] = a + b;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ out, long NC,
+                                                      int D, int H, int W, int kd, int kh, int kw) {
+  const int Do = D / kd, Ho = H / kh, Wo = W / kw;
+  const long total = NC * Do * Ho * Wo;
+  const float inv = 1.0f / (float)(kd * kh * kw);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xo = (int)(i % Wo);
+    long r = i / Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const long nc = r / Do;
+    const float* p = x + nc * (long)D * H * W;
+    float s = 0.0f;
+    for (int a = 0; a < kd; ++a)
+      for (int b = 0; b < kh; ++b)
+        for (int c = 0; c < kw; ++c) s += p[((long)(zo * kd + a) * H + (yo * kh + b)) * W + (xo * kw + c)];
+    out[i] = s * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n, long period, float alpha) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = (a[i] + b[i % period]) * alpha;
+}
+
+inline int grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int fd, int fh,
+                                          int fw, void* stream) {
+  if (!x || !out || NC <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
+  if ((fd != 1 && fd != 2) || (fh != 1 && fh != 2) || (fw != 1 && fw != 2)) return EMO_ERR_UNSUPPORTED;
+  const long total = NC * D * fd * H * fh * W * fw;
+  hipLaunchKernelGGL(upsample_trilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (long)NC, D, H, W, fd, fh, fw);
+  return emo_launch_status();
+}
+
+extern "C" int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int kd, int kh, int kw,
+                               void* stream) {
+  if (!x || !out || NC <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
+  if (kd < 1 || kh < 1 || kw < 1 || kd > 2 || kh > 2 || kw > 2) return EMO_ERR_UNSUPPORTED;
+  if (D % kd || H % kh || W % kw) return EMO_ERR_UNSUPPORTED;
+  const long total = NC * (D / kd) * (H / kh) * (W / kw);
+  hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, (long)NC, D, H,
+                     W, kd, kh, kw);
+  return emo_launch_status();
+}
+
+extern "C" int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, float alpha,
+                           void* stream) {
+  if (!a || !b || !out || n <= 0 || period <= 0) return EMO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n,
+                     (long)period, alpha);
+  return emo_launch_status();
+}

@@ -20,10 +20,22 @@ _c_int, _c_i64, _c_void, _c_float = ctypes.c_int, ctypes.c_int64, ctypes.c_void_
 SIGNATURES = {
     "emo_abi_version": [],
     "emo_build_info": [],
-    "emo_grid_sample3d_f32": [_c_void] * 7 + [_c_int] * 8 + [_c_i64] + [_c_int] * 4 + [_c_void],
+    "emo_grid_sample3d_f32": [_c_void] * 7 + [_c_int] * 8 + [_c_i64] + [_c_int] * 5 + [_c_void],
     "emo_volume_repack_f32": [_c_void, _c_void, _c_int, _c_int, _c_int, _c_int, _c_void],
+    "emo_groupnorm_workspace_bytes": [_c_int, _c_int],
+    "emo_groupnorm_affine_f32": [_c_void, _c_int, _c_int, _c_i64, _c_int, _c_float] + [_c_void] * 4 + [_c_i64]
+                                + [_c_void] * 5 + [_c_i64, _c_void],
+    "emo_conv_pack_info": [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
+    "emo_conv_igemm_f32": [_c_void] * 7 + [_c_int] * 14 + [_c_void],
+    "emo_upsample_trilinear_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
+    "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
+    "emo_add_f32": [_c_void, _c_void, _c_void, _c_i64, _c_i64, _c_float, _c_void],
+    "emo_small_gemm_f32": [_c_void] * 3 + [_c_int] * 4 + [_c_i64, _c_i64, _c_void],
+    "emo_projector_finalize_f32": [_c_void] * 7 + [_c_int] * 3 + [_c_void],
+    "emo_pose_theta_f32": [_c_void, _c_int, _c_void, _c_void, _c_void, _c_int, _c_void],
+    "emo_pack_rgb8": [_c_void, _c_void, _c_int, _c_int, _c_int, _c_void],
 }
-_RESTYPES = {"emo_build_info": ctypes.c_char_p}
+_RESTYPES = {"emo_build_info": ctypes.c_char_p, "emo_groupnorm_workspace_bytes": _c_i64}
 
 _lib = None
 

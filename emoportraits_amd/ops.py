@@ -18,15 +18,17 @@ def _lattice(n, device_index):
 
 
 def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="ncdhw", out_layout="ncdhw",
-                  batch=None, variant=0, out=None):
+                  variant=0, out=None, delta=None):
     """5-D trilinear grid_sample, align_corners=False  (== F.grid_sample(vol, grid, padding_mode=...)).
 
     vol    [Nv,C,D,H,W] ('ncdhw') or [Nv,D,H,W,C] ('ndhwc'); Nv == N or 1 (volume shared by all N samples).
     grid   [N,Do,Ho,Wo,3]; or None with theta [N,3,4] / [N,4,4]: the sampling grid is then the head-pose affine of
            the identity lattice (notebooks/infer.py:583-588), generated inside the kernel, output size = D,H,W.
+    delta  [N,3,Do,Ho,Wo] planar deltas: grid = identity lattice + delta (WarpGenerator output,
+           warp_generator_resnet.py:178) without materialising the grid.
     """
     lib = hip.load()
-    hip.require_cuda_f32(vol, grid, theta)
+    hip.require_cuda_f32(vol, grid, theta, delta)
     cl_in = in_layout == "ndhwc"
     cl_out = out_layout == "ndhwc"
     if cl_in:
@@ -34,15 +36,24 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     else:
         Nv, C, D, H, W = vol.shape
     lx = ly = lz = None
-    if theta is not None:
+    grid_kind = 0
+    idx = vol.device.index if vol.device.index is not None else torch.cuda.current_device()
+    if delta is not None:
+        if grid is not None or theta is not None:
+            raise ValueError("pass exactly one of grid / theta / delta")
+        if delta.dim() != 5 or delta.shape[1] != 3:
+            raise ValueError("delta must be [N,3,Do,Ho,Wo]")
+        N, _, Do, Ho, Wo = delta.shape
+        lx, ly, lz = _lattice(Wo, idx), _lattice(Ho, idx), _lattice(Do, idx)
+        grid, grid_kind = delta, 1
+    elif theta is not None:
         if grid is not None:
-            raise ValueError("pass either grid or theta")
+            raise ValueError("pass exactly one of grid / theta / delta")
         if theta.dim() != 3 or theta.shape[1] not in (3, 4) or theta.shape[2] != 4:
             raise ValueError("theta must be [N,3,4] or [N,4,4]")
         theta = theta[:, :3].contiguous()
         N = theta.shape[0]
         Do, Ho, Wo = D, H, W
-        idx = vol.device.index if vol.device.index is not None else torch.cuda.current_device()
         lx, ly, lz = _lattice(Wo, idx), _lattice(Ho, idx), _lattice(Do, idx)
     else:
         if grid is None or grid.dim() != 5 or grid.shape[-1] != 3:
@@ -60,7 +71,7 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
             raise ValueError("bad out shape")
     rc = lib.emo_grid_sample3d_f32(hip.ptr(vol), hip.ptr(grid), hip.ptr(theta), hip.ptr(lx), hip.ptr(ly), hip.ptr(lz),
                                    hip.ptr(out), N, C, D, H, W, Do, Ho, Wo, stride, hip.PAD_MODES[padding_mode],
-                                   int(cl_in), int(cl_out), int(variant), hip.current_stream())
+                                   int(cl_in), int(cl_out), int(variant), grid_kind, hip.current_stream())
     hip.check(rc, "emo_grid_sample3d_f32")
     return out
 
@@ -84,4 +95,185 @@ def volume_to_channels_first(vol):
     out = torch.empty((N, C, D, H, W), device=vol.device, dtype=torch.float32)
     hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, C, D * H * W, 0, hip.current_stream()),
               "emo_volume_repack_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GroupNorm -> per-(sample, channel) affine
+# ----------------------------------------------------------------------------------------------------------------
+_gn_ws = {}
+
+
+def _gn_workspace(N, G, device):
+    lib = hip.load()
+    need = lib.emo_groupnorm_workspace_bytes(N, G)
+    key = device.index
+    buf = _gn_ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _gn_ws[key] = buf
+    return buf, need
+
+
+def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, groups=32, eps=1e-5, want_stats=False):
+    """scale, shift [N,C] such that GroupNorm(x) == x*scale + shift (per sample and channel).
+    ada_gamma / ada_beta: [N, C] views (row stride arbitrary, unit column stride) of the adaptive weights."""
+    lib = hip.load()
+    hip.require_cuda_f32(x, gamma, beta)
+    N, C = x.shape[0], x.shape[1]
+    S = x.numel() // (N * C)
+    ada_stride = 0
+    if ada_gamma is not None:
+        for t in (ada_gamma, ada_beta):
+            if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1 or t.shape != (N, C):
+                raise RuntimeError("ada_gamma/ada_beta must be float32 cuda [N,C] with unit inner stride")
+        if ada_gamma.stride(0) != ada_beta.stride(0):
+            raise RuntimeError("ada_gamma/ada_beta must share the row stride")
+        ada_stride = ada_gamma.stride(0)
+    scale = torch.empty((N, C), device=x.device, dtype=torch.float32)
+    shift = torch.empty((N, C), device=x.device, dtype=torch.float32)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty((N, groups), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((N, groups), device=x.device, dtype=torch.float32)
+    ws, need = _gn_workspace(N, groups, x.device)
+    rc = lib.emo_groupnorm_affine_f32(hip.ptr(x), N, C, S, groups, eps, hip.ptr(gamma), hip.ptr(beta),
+                                      hip.ptr(ada_gamma), hip.ptr(ada_beta), ada_stride, hip.ptr(scale),
+                                      hip.ptr(shift), hip.ptr(mean), hip.ptr(rstd), hip.ptr(ws), ws.numel(),
+                                      hip.current_stream())
+    hip.check(rc, "emo_groupnorm_affine_f32")
+    if want_stats:
+        return scale, shift, mean, rstd
+    return scale, shift
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# implicit-GEMM convolution
+# ----------------------------------------------------------------------------------------------------------------
+def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=None, res_ups=False, act="none",
+               out=None):
+    """layer: emoportraits_amd.pack.PackedConv.  x [N,Cin,H,W] or [N,Cin,D,H,W]."""
+    lib = hip.load()
+    hip.require_cuda_f32(x, scale, shift, res)
+    three_d = x.dim() == 5
+    if three_d:
+        N, Cin, D, H, W = x.shape
+    else:
+        N, Cin, H, W = x.shape
+        D = 1
+    if Cin != layer.cin:
+        raise ValueError(f"conv expects {layer.cin} input channels, got {Cin}")
+    if (layer.kd == 3) != three_d and layer.kd == 3:
+        raise ValueError("3x3x3 conv needs a 5-D input")
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    shape = (N, layer.cout, D, Hl, Wl) if three_d else (N, layer.cout, Hl, Wl)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape:
+        raise ValueError("bad out shape")
+    if res is not None:
+        want = (N, layer.cout, D, H, W) if res_ups else (N, layer.cout, D, Hl, Wl)
+        if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
+            raise ValueError("bad residual shape")
+    rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.wpk), hip.ptr(layer.bias), hip.ptr(scale), hip.ptr(shift),
+                                hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd, layer.kh, layer.kw,
+                                int(ups), int(relu_in), hip.ACT[act], int(res_ups), layer.cfg, hip.current_stream())
+    hip.check(rc, f"emo_conv_igemm_f32[{layer.name}]")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# resampling / pointwise
+# ----------------------------------------------------------------------------------------------------------------
+def upsample_trilinear(x, factors):
+    """F.interpolate(x, scale_factor=factors, mode='trilinear') for 5-D x, factors in {1,2}^3"""
+    lib = hip.load()
+    hip.require_cuda_f32(x)
+    N, C, D, H, W = x.shape
+    fd, fh, fw = factors
+    out = torch.empty((N, C, D * fd, H * fh, W * fw), device=x.device, dtype=torch.float32)
+    hip.check(lib.emo_upsample_trilinear_f32(hip.ptr(x), hip.ptr(out), N * C, D, H, W, fd, fh, fw, hip.current_stream()),
+              "emo_upsample_trilinear_f32")
+    return out
+
+
+def avgpool(x, kernel):
+    """nn.AvgPool3d(kernel, stride=kernel) (5-D, kernel=(kd,kh,kw)) or nn.AvgPool2d (4-D, kernel=(kh,kw))"""
+    lib = hip.load()
+    hip.require_cuda_f32(x)
+    if x.dim() == 5:
+        N, C, D, H, W = x.shape
+        kd, kh, kw = kernel
+        oshape = (N, C, D // kd, H // kh, W // kw)
+    else:
+        N, C, H, W = x.shape
+        D, kd = 1, 1
+        kh, kw = kernel
+        oshape = (N, C, H // kh, W // kw)
+    out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    hip.check(lib.emo_avgpool_f32(hip.ptr(x), hip.ptr(out), N * C, D, H, W, kd, kh, kw, hip.current_stream()),
+              "emo_avgpool_f32")
+    return out
+
+
+def add(a, b, alpha=1.0, out=None):
+    """(a + b) * alpha; b is broadcast over the leading dimension when it is smaller (period = b.numel())"""
+    lib = hip.load()
+    hip.require_cuda_f32(a, b)
+    if a.numel() % b.numel():
+        raise ValueError("b does not tile a")
+    if out is None:
+        out = torch.empty_like(a)
+    hip.check(lib.emo_add_f32(hip.ptr(a), hip.ptr(b), hip.ptr(out), a.numel(), b.numel(), float(alpha), hip.current_stream()),
+              "emo_add_f32")
+    return out
+
+
+def small_gemm(A, B, NN):
+    """C[b][m][:NN] = sum_k A[m][k] * B[b][k][:NN];  A [M,K], B [batch,K,NN] -> [batch,M,NN]"""
+    lib = hip.load()
+    hip.require_cuda_f32(A, B)
+    M, K = A.shape
+    batch = B.shape[0]
+    if B.numel() != batch * K * NN:
+        raise ValueError("bad B shape")
+    C = torch.empty((batch, M, NN), device=A.device, dtype=torch.float32)
+    hip.check(lib.emo_small_gemm_f32(hip.ptr(A), hip.ptr(B), hip.ptr(C), M, K, NN, batch, K * NN, M * NN, hip.current_stream()),
+              "emo_small_gemm_f32")
+    return C
+
+
+def projector_finalize(T, V, norm_of_row, gamma, beta):
+    """T [B,R,E], V [n,E,2], norm_of_row [R] int32, gamma/beta [R] -> ada_gamma, ada_beta [B,R]"""
+    lib = hip.load()
+    hip.require_cuda_f32(T, V, gamma, beta)
+    B, R, E = T.shape
+    ag = torch.empty((B, R), device=T.device, dtype=torch.float32)
+    ab = torch.empty((B, R), device=T.device, dtype=torch.float32)
+    hip.check(lib.emo_projector_finalize_f32(hip.ptr(T), hip.ptr(V), hip.ptr(norm_of_row), hip.ptr(gamma), hip.ptr(beta),
+                                             hip.ptr(ag), hip.ptr(ab), B, R, E, hip.current_stream()),
+              "emo_projector_finalize_f32")
+    return ag, ab
+
+
+def pose_theta(scale, rotation, translation):
+    """utils/point_transforms.py:188-242 get_transform_matrix on the device -> [B,4,4]"""
+    lib = hip.load()
+    hip.require_cuda_f32(scale, rotation, translation)
+    B = scale.shape[0]
+    theta = torch.empty((B, 4, 4), device=scale.device, dtype=torch.float32)
+    hip.check(lib.emo_pose_theta_f32(hip.ptr(scale), scale.shape[1], hip.ptr(rotation), hip.ptr(translation),
+                                     hip.ptr(theta), B, hip.current_stream()), "emo_pose_theta_f32")
+    return theta
+
+
+def pack_rgb8(img):
+    """[N,3,H,W] fp32 -> [N,H,W,3] uint8 = clamp(0,1)*255 truncated (notebooks/infer.py:641-644 + ToPILImage)"""
+    lib = hip.load()
+    hip.require_cuda_f32(img)
+    N, C, H, W = img.shape
+    if C != 3:
+        raise ValueError("expected 3 channels")
+    out = torch.empty((N, H, W, 3), device=img.device, dtype=torch.uint8)
+    hip.check(lib.emo_pack_rgb8(hip.ptr(img), hip.ptr(out), N, H, W, hip.current_stream()), "emo_pack_rgb8")
     return out

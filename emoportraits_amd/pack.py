@@ -1,0 +1,101 @@
+"""Load-time weight preparation: spectral-norm / weight-standardisation folding and packing of conv
+weights into the layout the implicit-GEMM kernel stages with 16-byte copies (emoportraits_amd/csrc/conv_igemm.h).
+
+Everything here runs once per checkpoint, on the host, in plain torch fp32 -- it is data preparation, not the hot
+path.  The folding formulas restate what the reference recomputes on every forward:
+  spectral norm  utils/spectral_norm.py:96-168 (eval: no power iteration)   W / (u . (W_mat v))
+  weight std     networks/volumetric_avatar/utils.py:893-900, :908-914      (W - mean) / (std_unbiased + 1e-5)
+"""
+import ctypes
+
+import torch
+
+from . import hip
+
+CFG_A, CFG_B, CFG_C = 0, 1, 2
+_BM = {CFG_A: 128, CFG_B: 64, CFG_C: 32}
+
+
+def fold_sn(weight_orig, u, v):
+    w_mat = weight_orig.reshape(weight_orig.shape[0], -1)
+    sigma = torch.dot(u, torch.mv(w_mat, v))
+    return weight_orig / sigma
+
+
+def fold_ws(w):
+    m = w
+    for dim in range(1, w.dim()):
+        m = m.mean(dim=dim, keepdim=True)
+    w = w - m
+    std = w.view(w.size(0), -1).std(dim=1).view(-1, *([1] * (w.dim() - 1))) + 1e-5
+    return w / std.expand_as(w)
+
+
+def folded_conv(sd, prefix, kind):
+    """(weight, bias) of the conv at `prefix` in a raw reference state_dict; kind in {'sn','ws','plain'}"""
+    if kind == "sn":
+        w = fold_sn(sd[prefix + ".weight_orig"].float(), sd[prefix + ".weight_u"].float(), sd[prefix + ".weight_v"].float())
+    elif kind == "ws":
+        w = fold_ws(sd[prefix + ".weight"].float())
+    elif kind == "plain":
+        w = sd[prefix + ".weight"].float()
+    else:
+        raise ValueError(kind)
+    b = sd.get(prefix + ".bias")
+    return w, (None if b is None else b.float())
+
+
+def choose_cfg(cout):
+    """block config minimising padded output channels; ties go to the larger tile"""
+    best = None
+    for cfg in (CFG_A, CFG_B, CFG_C):
+        bm = _BM[cfg]
+        padded = -(-cout // bm) * bm
+        if best is None or padded < best[0]:
+            best = (padded, cfg)
+    return best[1]
+
+
+def conv_pack_info(kh, kw, cfg):
+    lib = hip.load()
+    bm, kc = ctypes.c_int(), ctypes.c_int()
+    hip.check(lib.emo_conv_pack_info(kh, kw, cfg, ctypes.byref(bm), ctypes.byref(kc)), "emo_conv_pack_info")
+    return bm.value, kc.value
+
+
+def pack_weight(w, cfg):
+    """w [Cout, Cin, KH, KW] or [Cout, Cin, KD, KH, KW] -> flat fp32 tensor
+    [co_tile][cin chunk][kd][pair][tap][half][BM]   (stage index = chunk*KD + kd; k-local = (pair*TAPS+tap)*2+half)"""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, kd, kh, kw = w.shape
+    bm, kc = conv_pack_info(kh, kw, cfg)
+    n_cot = -(-cout // bm)
+    n_cc = -(-cin // kc)
+    wp = torch.zeros((n_cot * bm, n_cc * kc, kd, kh * kw), dtype=torch.float32)
+    wp[:cout, :cin] = w.reshape(cout, cin, kd, kh * kw).float()
+    # [cot, BM, cc, pair, half, kd, tap] -> [cot, cc, kd, pair, tap, half, BM]
+    wp = wp.view(n_cot, bm, n_cc, kc // 2, 2, kd, kh * kw).permute(0, 2, 5, 3, 6, 4, 1).contiguous()
+    return wp.view(-1)
+
+
+class PackedConv:
+    """One convolution of the hot path, ready for emo_conv_igemm_f32."""
+
+    def __init__(self, name, weight, bias, device, cfg=None):
+        if weight.dim() == 4:
+            cout, cin, kh, kw = weight.shape
+            kd = 1
+        else:
+            cout, cin, kd, kh, kw = weight.shape
+        self.name = name
+        self.cin, self.cout, self.kd, self.kh, self.kw = cin, cout, kd, kh, kw
+        self.cfg = choose_cfg(cout) if cfg is None else cfg
+        self.wpk = pack_weight(weight, self.cfg).to(device)
+        self.bias = None if bias is None else bias.float().contiguous().to(device)
+        self.macs_per_position = cout * cin * kd * kh * kw
+
+    @classmethod
+    def from_state_dict(cls, sd, prefix, kind, device, cfg=None):
+        w, b = folded_conv(sd, prefix, kind)
+        return cls(prefix, w, b, device, cfg)

@@ -65,7 +65,11 @@ const char* emo_build_info(void);
  *         which is what identity_grid_3d.bmm(theta[:, :3].transpose(1, 2)) computes
  *         (va.py:101-105 + notebooks/infer.py:441-444,583-588) without materialising the 0.79 MB grid.
  *   lin_x [Wo], lin_y [Ho], lin_z [Do]  the identity lattice (torch.linspace(-1, 1, n) values); required
- *         with theta, ignored otherwise.
+ *         with theta or grid_kind 1, ignored otherwise.
+ *   grid_kind  0: `grid` holds coordinates [N,Do,Ho,Wo,3].  1: `grid` holds planar deltas [N,3,Do,Ho,Wo] and the
+ *         coordinate is lattice + delta -- the WarpGenerator output  warp = (identity_grid + deltas).permute(0,2,3,4,1)
+ *         (networks/volumetric_avatar/warp_generator_resnet.py:178) consumed without materialising `warp`.
+ *   variant    0 = default kernels; other values select alternative tunings (kept for A/B measurements).
  *   out   [N, C, Do, Ho, Wo] or [N, Do, Ho, Wo, C] according to out_layout.
  *   vol_batch_stride  elements between consecutive volumes (0 = shared volume).
  * NDHWC paths require C % 4 == 0.
@@ -75,11 +79,86 @@ int emo_grid_sample3d_f32(const float* vol, const float* grid, const float* thet
                           float* out,
                           int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                           int64_t vol_batch_stride, int padding_mode,
-                          int in_layout, int out_layout, int variant, void* stream);
+                          int in_layout, int out_layout, int variant, int grid_kind, void* stream);
 
 /* NCDHW <-> NDHWC repack of a 5-D volume (used once per identity on the cached canonical volume,
  * notebooks/infer.py:507 `self.target_latent_volume`).  to_channels_last != 0: NCDHW -> NDHWC. */
 int emo_volume_repack_f32(const float* in, float* out, int N, int C, int DHW, int to_channels_last, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a10 -- GroupNorm statistics folded to a per-(sample, channel) affine.
+ * Replaces the nn.GroupNorm(32, C) / AdaptiveGroupNorm in front of every conv of the reference's ResBlock
+ * (networks/volumetric_avatar/utils.py:711-731 block_feats; registries :953-957; AdaptiveGroupNorm :302-325):
+ * the normalised tensor is never written, the consumer conv applies x*scale+shift (+ReLU) while staging.
+ *   x [N, C, S] (S = product of spatial dims), G groups, eps as nn.GroupNorm (1e-5).
+ *   gamma/beta [C] or NULL (=1/0).  ada_gamma/ada_beta [N rows, ada_stride apart] or NULL: the per-sample
+ *   weights assigned by assign_adaptive_norm_params (utils.py:983-995); y = (xhat*gamma+beta)*ada_gamma+ada_beta.
+ *   scale/shift [N, C] out.  mean_out/rstd_out [N, G] optional (both or neither).
+ *   workspace: device buffer of at least emo_groupnorm_workspace_bytes(N, G) bytes.
+ */
+int64_t emo_groupnorm_workspace_bytes(int N, int G);
+int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S, int G, float eps,
+                             const float* gamma, const float* beta,
+                             const float* ada_gamma, const float* ada_beta, int64_t ada_stride,
+                             float* scale, float* shift, float* mean_out, float* rstd_out,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a5/a9/a10 -- implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ * Replaces F.conv2d / F.conv3d inside ResBlock / ConvBlock (networks/volumetric_avatar/utils.py:661-788;
+ * Conv2d_ws/Conv3d_ws :887-915; spectral-norm hook utils/spectral_norm.py:96-168 -- both folded into the packed
+ * weights at load time), stride 1, "same" zero padding, kernel 1x1(x1) or 3x3 (2-D: KD=1) or 3x3x3 (KD=3).
+ *   x     [N, Cin, D, H, W]            (D = 1 for 2-D convs)
+ *   wpk   weights packed by the host for block config `cfg`: [co_tile][Cin chunk][kd][pair][tap][half][BM]
+ *         (emoportraits_amd/pack.py; BM / KC from emo_conv_pack_info)
+ *   bias  [Cout] or NULL.
+ *   scale/shift [N, Cin] or NULL: input transform x*scale+shift (GroupNorm folded, see above);
+ *         relu_in != 0 applies max(.,0) after it (ReLU of block_feats, utils.py:717,731).  Zero padding is applied
+ *         to the transformed tensor, as F.conv does.
+ *   ups   != 0: the conv input is the nearest-neighbour x2 upsampling of x in H and W (ResBlock
+ *         resize_layer_type='nearest', utils.py:684-688,764-781); out is [N, Cout, D, 2H, 2W].  2-D only.
+ *   res   residual added before `act` (ResBlock skip, utils.py:783); same shape as out, or the pre-upsample
+ *         shape when res_ups != 0.  May alias `out`.
+ *   act   EMO_ACT_* applied last (tanh head warp_generator_resnet.py:99-107; sigmoid head decoder.py:347-358).
+ *   cfg   0: 128 output channels x 128 positions per block, 1: 64 x 128, 2: 32 x 128.
+ * Supported output widths: multiples of 128, or 64 / 32 / 16 / 8 (with H resp. D divisible by the tile).
+ */
+int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC);
+int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias,
+                       const float* scale, const float* shift, const float* res, float* out,
+                       int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
+                       int ups, int relu_in, int act, int res_ups, int cfg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * resampling / pointwise helpers (HBM-bound, one pass)
+ *   emo_upsample_trilinear_f32: F.interpolate(x, scale_factor=(fd,fh,fw), mode='trilinear'), factors in {1,2}
+ *       (warp_generator_resnet.py:163-166; unet_3d.py:223,269-272).  x [NC, D, H, W] -> [NC, D*fd, H*fh, W*fw]
+ *   emo_avgpool_f32: nn.AvgPool2d/3d with kernel == stride in {1,2} per axis (utils.py:962-967)
+ *   emo_add_f32: out[i] = (a[i] + b[i % period]) * alpha   (unet_3d.py:281; va.py:857)
+ */
+int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC, int D, int H, int W,
+                               int fd, int fh, int fw, void* stream);
+int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int kd, int kh, int kw, void* stream);
+int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3/a4/a5 -- small wave-reduced kernels
+ *   emo_small_gemm_f32: C[b][m][0..NN) = sum_k A[m][k] * B[b][k][0..NN), NN in {1,2,4,16}: pose_unsqueeze_nw Linear
+ *       (va.py:172-173,820-823), warp_embed_head_orig_nw 1x1 conv on 4x4 (va.py:177-181,857), WarpGenerator.first_conv
+ *       (warp_generator_resnet.py:70,141), ProjectorNorm u @ embed (utils.py:1137-1151).
+ *   emo_projector_finalize_f32: (u@embed) @ v -> (d_gamma, d_beta), then ada_gamma = gamma + d_gamma, ada_beta = beta +
+ *       d_beta (utils.py:1146-1149 + assign_adaptive_norm_params :983-995) for all adaptive norms of a net at once:
+ *       T [B, R, E], V [n_norms, E, 2], norm_of_row [R] int32, gamma/beta [R] -> ada_gamma/ada_beta [B, R].
+ *   emo_pose_theta_f32: utils/point_transforms.py:188-242 get_transform_matrix -> theta [B,4,4]; scale [B,scale_cols].
+ *   emo_pack_rgb8: notebooks/infer.py:641-644 clamp(0,1) + ToPILImage: [N,3,H,W] fp32 -> [N,H,W,3] uint8.
+ */
+int emo_small_gemm_f32(const float* A, const float* B, float* C, int M, int K, int NN, int batch,
+                       int64_t b_stride, int64_t c_stride, void* stream);
+int emo_projector_finalize_f32(const float* T, const float* V, const int* norm_of_row, const float* gamma,
+                               const float* beta, float* ada_gamma, float* ada_beta, int B, int R, int E, void* stream);
+int emo_pose_theta_f32(const float* scale, int scale_cols, const float* rotation, const float* translation,
+                       float* theta, int B, void* stream);
+int emo_pack_rgb8(const float* img, uint8_t* out, int N, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,266 @@
+"""GPU parity tests of the conv / GroupNorm / resampling / small kernels against torch CPU fp32 (same op, same
+inputs).  Tolerances are stated relative to max|reference| of each tensor: the kernels accumulate in fp32 (exact-fp32
+MFMA = fmaf chain), in a different summation order than the CPU library, so agreement is to fp32 rounding:
+  conv:  2e-5 * max|ref|   (K up to 4608 products per output)
+  norm:  1e-5 * max|ref|   (statistics reduced in fp64 on the GPU)
+"""
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import restate as O  # noqa: E402
+
+from emoportraits_amd import ops, pack  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(got, ref):
+    return (got.cpu().double() - ref.double()).abs().max().item() / (ref.double().abs().max().item() + 1e-30)
+
+
+def run_conv(N, Cin, Cout, dims, k, cfg, affine=False, relu_in=False, ups=False, res=False, res_ups=False,
+             bias=True, act="none", seed=0):
+    g = torch.Generator().manual_seed(seed)
+    three_d = len(dims) == 3
+    x = torch.randn(N, Cin, *dims, generator=g)
+    kd = k if three_d else 1
+    wshape = (Cout, Cin, k, k, k) if three_d else (Cout, Cin, k, k)
+    w = torch.randn(*wshape, generator=g) / math.sqrt(Cin * k * k * kd)
+    b = torch.randn(Cout, generator=g) if bias else None
+    scale = shift = None
+    xin = x
+    if affine:
+        scale = torch.rand(N, Cin, generator=g) + 0.5
+        shift = torch.randn(N, Cin, generator=g) * 0.3
+        bshape = (N, Cin) + (1,) * len(dims)
+        xin = x * scale.view(bshape) + shift.view(bshape)
+    if relu_in:
+        xin = F.relu(xin)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = (F.conv3d if three_d else F.conv2d)(xin, w, b, padding=k // 2)
+    r = None
+    if res:
+        rshape = list(ref.shape)
+        if res_ups:
+            rshape[-1] //= 2
+            rshape[-2] //= 2
+        r = torch.randn(*rshape, generator=g)
+        ref = ref + (F.interpolate(r, scale_factor=2, mode="nearest") if res_ups else r)
+    if act == "tanh":
+        ref = torch.tanh(ref)
+    elif act == "sigmoid":
+        ref = torch.sigmoid(ref)
+    elif act == "relu":
+        ref = F.relu(ref)
+    layer = pack.PackedConv("test", w, b, DEV, cfg=cfg)
+    got = ops.conv_igemm(x.to(DEV), layer, None if scale is None else scale.to(DEV),
+                         None if shift is None else shift.to(DEV), relu_in=relu_in, ups=ups,
+                         res=None if r is None else r.to(DEV), res_ups=res_ups, act=act)
+    return rel_err(got, ref), got, ref
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("hw", [16, 32, 64, 128, 256])
+def test_conv2d_3x3_all_tile_shapes(cfg, hw):
+    e, got, ref = run_conv(2, 8, 40, (hw, hw), 3, cfg, seed=hw + cfg)
+    assert got.shape == ref.shape
+    assert e < 2e-5, e
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("hw", [16, 64, 128])
+def test_conv2d_1x1(cfg, hw):
+    e, _, _ = run_conv(2, 40, 70, (hw, hw), 1, cfg, seed=3 * hw + cfg)
+    assert e < 2e-5, e
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 16, 16), (8, 32, 32), (4, 64, 64), (2, 128, 128)])
+def test_conv3d_3x3x3(cfg, dims):
+    e, _, _ = run_conv(1, 6, 33, dims, 3, cfg, seed=sum(dims) + cfg)
+    assert e < 2e-5, e
+
+
+def test_conv3d_1x1x1():
+    e, _, _ = run_conv(2, 20, 12, (8, 16, 16), 1, 2, seed=5)
+    assert e < 2e-5, e
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 3), (5, 1), (17, 129), (4, 320), (96, 96)])
+def test_conv_ragged_channel_counts(cin, cout):
+    for cfg in (0, 1, 2):
+        e, _, _ = run_conv(1, cin, cout, (64, 64), 3, cfg, seed=cin * 7 + cout)
+        assert e < 2e-5, (cfg, e)
+
+
+def test_conv_fused_groupnorm_affine_relu_and_padding_semantics():
+    # padding must be zero AFTER the affine+relu: with shift > 0 a wrong order shows up at the border
+    for k in (1, 3):
+        e, _, _ = run_conv(2, 12, 24, (64, 64), k, 1, affine=True, relu_in=True, seed=11 + k)
+        assert e < 2e-5, e
+    e, _, _ = run_conv(2, 12, 24, (8, 16, 16), 3, 2, affine=True, relu_in=True, seed=13)
+    assert e < 2e-5, e
+    e, _, _ = run_conv(1, 12, 24, (64, 64), 3, 0, affine=True, relu_in=False, seed=14)
+    assert e < 2e-5, e
+    e, _, _ = run_conv(1, 12, 24, (64, 64), 3, 0, affine=False, relu_in=True, seed=15)
+    assert e < 2e-5, e
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_conv_fused_nearest_upsample(k):
+    for cfg in (0, 1, 2):
+        e, got, ref = run_conv(2, 10, 36, (64, 64), k, cfg, affine=True, relu_in=True, ups=True, seed=21 + k + cfg)
+        assert got.shape == ref.shape == (2, 36, 128, 128)
+        assert e < 2e-5, (cfg, e)
+    e, _, _ = run_conv(1, 6, 8, (128, 128), 3, 2, ups=True, seed=29)
+    assert e < 2e-5, e
+
+
+def test_conv_epilogue_residual_bias_activations():
+    e, _, _ = run_conv(2, 8, 20, (64, 64), 3, 1, res=True, seed=31)
+    assert e < 2e-5, e
+    e, _, _ = run_conv(2, 8, 20, (64, 64), 3, 1, ups=True, res=True, res_ups=True, seed=32)
+    assert e < 2e-5, e
+    e, _, _ = run_conv(1, 8, 20, (4, 32, 32), 3, 2, res=True, bias=False, seed=33)
+    assert e < 2e-5, e
+    for act in ("tanh", "sigmoid", "relu"):
+        e, _, _ = run_conv(1, 16, 3, (4, 64, 64), 3, 2, act=act, seed=34)
+        assert e < 2e-5, (act, e)
+
+
+def test_conv_residual_may_alias_output():
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(1, 8, 64, 64, generator=g)
+    w = torch.randn(16, 8, 3, 3, generator=g) * 0.1
+    r = torch.randn(1, 16, 64, 64, generator=g)
+    ref = F.conv2d(x, w, padding=1) + r
+    layer = pack.PackedConv("alias", w, None, DEV)
+    buf = r.to(DEV).clone()
+    ops.conv_igemm(x.to(DEV), layer, res=buf, out=buf)
+    assert rel_err(buf, ref) < 2e-5
+
+
+def test_conv_released_decoder_layer_shapes():
+    """the heaviest released shapes, batch 1: K=4608 trunk conv and the 512^2 conv"""
+    e, _, _ = run_conv(1, 512, 512, (64, 64), 3, 0, affine=True, relu_in=True, res=True, seed=51)
+    assert e < 2e-5, e
+    e, _, _ = run_conv(1, 192, 128, (256, 256), 3, 0, affine=True, relu_in=True, ups=True, seed=52)
+    assert e < 2e-5, e
+    e, _, _ = run_conv(1, 1536, 512, (64, 64), 1, 0, seed=53)
+    assert e < 2e-5, e
+
+
+def test_conv_unsupported_width_is_reported():
+    layer = pack.PackedConv("bad", torch.randn(4, 4, 3, 3), None, DEV)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        ops.conv_igemm(torch.randn(1, 4, 12, 12, device=DEV), layer)
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8), (3, 96, 16, 64, 64), (1, 128, 512, 512), (2, 32, 5, 7, 3)])
+def test_groupnorm_affine(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) * 3 + 1.5
+    C = shape[1]
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, 1e-5)
+    scale, shift, mean, rstd = ops.groupnorm_affine(x.to(DEV), gamma.to(DEV), beta.to(DEV), want_stats=True)
+    bshape = (shape[0], C) + (1,) * (len(shape) - 2)
+    got = x * scale.cpu().view(bshape) + shift.cpu().view(bshape)
+    assert rel_err(got, ref) < 1e-5
+    xg = x.view(shape[0], 32, -1).double()
+    assert torch.allclose(mean.cpu().double(), xg.mean(-1), atol=1e-5)
+    assert torch.allclose(rstd.cpu().double(), 1 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5), rtol=1e-5)
+    # no affine
+    s2, h2 = ops.groupnorm_affine(x.to(DEV))
+    got2 = x * s2.cpu().view(bshape) + h2.cpu().view(bshape)
+    assert rel_err(got2, F.group_norm(x, 32, None, None, 1e-5)) < 1e-5
+
+
+def test_groupnorm_large_mean_is_stable():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 32, 64, 64, generator=g) * 0.01 + 1000.0
+    s, h = ops.groupnorm_affine(x.to(DEV))
+    got = x * s.cpu().view(1, 32, 1, 1) + h.cpu().view(1, 32, 1, 1)
+    ref = F.group_norm(x.double(), 32).float()
+    assert (got - ref).abs().max().item() < 0.05   # fp32 x*scale+shift cancellation bound at |x|=1e3, rstd=1e2
+
+
+def test_adaptive_groupnorm_matches_reference_quirk():
+    g = torch.Generator().manual_seed(6)
+    N, C = 3, 64
+    x = torch.randn(N, C, 4, 8, 8, generator=g)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dg, db = torch.randn(N, C, generator=g), torch.randn(N, C, generator=g)
+    sd = {"p.weight": gamma, "p.bias": beta}
+    ref = O.ada_group_norm(x, sd, "p", (dg, db))
+    big_g = torch.zeros(N, 200)
+    big_b = torch.zeros(N, 200)
+    big_g[:, 100:100 + C] = gamma[None] + dg
+    big_b[:, 100:100 + C] = beta[None] + db
+    big_g, big_b = big_g.to(DEV), big_b.to(DEV)
+    s, h = ops.groupnorm_affine(x.to(DEV), gamma.to(DEV), beta.to(DEV), big_g[:, 100:100 + C], big_b[:, 100:100 + C])
+    got = x * s.cpu().view(N, C, 1, 1, 1) + h.cpu().view(N, C, 1, 1, 1)
+    assert rel_err(got, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("factors", [(2, 2, 2), (1, 2, 2), (2, 1, 1)])
+def test_upsample_trilinear(factors):
+    x = torch.randn(2, 5, 4, 6, 7, generator=torch.Generator().manual_seed(1))
+    ref = F.interpolate(x, scale_factor=tuple(float(f) for f in factors), mode="trilinear")
+    got = ops.upsample_trilinear(x.to(DEV), factors)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-6
+
+
+@pytest.mark.parametrize("kernel", [(2, 1, 1), (1, 2, 2), (2, 2, 2)])
+def test_avgpool3d(kernel):
+    x = torch.randn(2, 3, 4, 6, 8, generator=torch.Generator().manual_seed(2))
+    assert rel_err(ops.avgpool(x.to(DEV), kernel), F.avg_pool3d(x, kernel, kernel)) < 1e-6
+
+
+def test_avgpool2d_and_add():
+    x = torch.randn(2, 3, 6, 8, generator=torch.Generator().manual_seed(3))
+    assert rel_err(ops.avgpool(x.to(DEV), (2, 2)), F.avg_pool2d(x, 2)) < 1e-6
+    y = torch.randn(3, 6, 8)
+    assert rel_err(ops.add(x.to(DEV), y.to(DEV), 0.5), (x + y[None]) * 0.5) < 1e-7
+
+
+def test_small_gemm_and_projector():
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(70, 300, generator=g)
+    for NN in (1, 2, 4, 16):
+        B = torch.randn(3, 300, NN, generator=g)
+        got = ops.small_gemm(A.to(DEV), B.to(DEV), NN)
+        assert rel_err(got, torch.einsum("mk,bkn->bmn", A, B)) < 1e-5
+    T = torch.randn(2, 10, 16, generator=g)
+    V = torch.randn(3, 16, 2, generator=g)
+    nor = torch.tensor([0, 0, 0, 1, 1, 1, 1, 2, 2, 2], dtype=torch.int32)
+    gamma, beta = torch.randn(10, generator=g), torch.randn(10, generator=g)
+    ag, ab = ops.projector_finalize(T.to(DEV), V.to(DEV), nor.to(DEV), gamma.to(DEV), beta.to(DEV))
+    P = torch.einsum("brk,rkj->brj", T, V[nor.long()])
+    assert rel_err(ag, gamma[None] + P[..., 0]) < 1e-5
+    assert rel_err(ab, beta[None] + P[..., 1]) < 1e-5
+
+
+def test_pose_theta_and_pack(golden_dir):
+    import numpy as np
+    p = dict(np.load(os.path.join(golden_dir, "pose_theta.npz")))
+    t = lambda k: torch.from_numpy(p[k]).to(DEV)
+    got = ops.pose_theta(t("scale"), t("rotation"), t("translation")).cpu()
+    assert (got - torch.from_numpy(p["theta"])).abs().max().item() < 2e-6
+    got1 = ops.pose_theta(t("scale")[:, :1].contiguous(), t("rotation"), t("translation")).cpu()
+    assert (got1 - torch.from_numpy(p["theta_scalar_scale"])).abs().max().item() < 2e-6
+    img = torch.rand(2, 3, 16, 24, generator=torch.Generator().manual_seed(9)) * 1.4 - 0.2
+    ref = img.clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1)
+    assert torch.equal(ops.pack_rgb8(img.to(DEV)).cpu(), ref)

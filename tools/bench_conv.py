@@ -1,0 +1,80 @@
+"""Micro-benchmark: hand-written implicit-GEMM conv (fp32 MFMA) vs stock PyTorch-ROCm (MIOpen) on the released
+decoder / WarpGenerator layer shapes.  In-process A/B, HIP events on the launch stream.  JSON lines."""
+import json
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emoportraits_amd import ops, pack  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    torch.backends.cudnn.benchmark = True
+    # (Cin, Cout, dims, k, ups)
+    shapes = [(1536, 512, (64, 64), 1, False), (512, 512, (64, 64), 3, False),
+              (512, 320, (64, 64), 3, True), (320, 320, (128, 128), 3, False), (512, 320, (64, 64), 1, True),
+              (320, 192, (128, 128), 3, True), (192, 192, (256, 256), 3, False),
+              (192, 128, (256, 256), 3, True), (128, 128, (512, 512), 3, False), (192, 128, (256, 256), 1, True),
+              (128, 3, (512, 512), 1, False),
+              (512, 256, (8, 8, 8), 3, False), (256, 128, (16, 16, 16), 3, False), (128, 64, (32, 32, 32), 3, False),
+              (64, 32, (32, 64, 64), 3, False), (32, 32, (32, 64, 64), 3, False), (32, 3, (16, 64, 64), 3, False)]
+    for cin, cout, dims, k, ups in shapes:
+        three_d = len(dims) == 3
+        x = torch.randn(B, cin, *dims, device=DEV)
+        kd = k if three_d else 1
+        w = torch.randn(cout, cin, *([k] * len(dims))) / math.sqrt(cin * k * k * kd)
+        scale = torch.rand(B, cin, device=DEV) + 0.5
+        shift = torch.randn(B, cin, device=DEV) * 0.1
+        odims = tuple(d * 2 for d in dims) if ups else dims
+        flops = 2.0 * B * cout * cin * (k ** len(dims)) * math.prod(odims)
+        wd = w.to(DEV)
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        conv = F.conv3d if three_d else F.conv2d
+        ms_t = timeit(lambda: conv(xin, wd, padding=k // 2))
+        rec = dict(B=B, cin=cin, cout=cout, dims=dims, k=k, ups=ups, torch_ms=round(ms_t, 3),
+                   torch_tflops=round(flops / ms_t / 1e9, 1))
+        for cfg in (0, 1, 2):
+            bm = {0: 128, 1: 64, 2: 32}[cfg]
+            if cfg == 2 and cout > 96:
+                continue
+            if -(-cout // bm) * bm > 1.5 * cout and cfg != pack.choose_cfg(cout):
+                continue
+            layer = pack.PackedConv("b", w, None, DEV, cfg=cfg)
+            out = ops.conv_igemm(x, layer, scale, shift, relu_in=True, ups=ups)
+            ms = timeit(lambda: ops.conv_igemm(x, layer, scale, shift, relu_in=True, ups=ups, out=out))
+            rec[f"hip_cfg{cfg}_ms"] = round(ms, 3)
+            rec[f"hip_cfg{cfg}_tflops"] = round(flops / ms / 1e9, 1)
+        rec["auto_cfg"] = pack.choose_cfg(cout)
+        print(json.dumps(rec), flush=True)
+    # GroupNorm statistics kernel vs torch group_norm+relu (which the conv staging makes unnecessary)
+    for c, h in [(512, 64), (320, 128), (192, 256), (128, 512)]:
+        x = torch.randn(B, c, h, h, device=DEV)
+        g, b = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+        ms = timeit(lambda: ops.groupnorm_affine(x, g, b))
+        ms_t = timeit(lambda: F.relu(F.group_norm(x, 32, g, b)))
+        print(json.dumps(dict(op="gn_stats", B=B, c=c, hw=h, hip_ms=round(ms, 4), read_GBps=round(x.numel() * 4 / ms / 1e6, 1),
+                              torch_gn_relu_ms=round(ms_t, 4))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
