@@ -7,6 +7,8 @@ conv_launch_fn conv_lookup_3x3_C(int, int);
 conv_launch_fn conv_lookup_1x1_A(int, int);
 conv_launch_fn conv_lookup_1x1_B(int, int);
 conv_launch_fn conv_lookup_1x1_C(int, int);
+conv_launch_fn conv_lookup_1x7_A(int, int);
+conv_launch_fn conv_lookup_1x7_B(int, int);
 
 static int shape_of_width(int Wl) {
   if (Wl >= 128 && Wl % 128 == 0) return SHAPE_W128;
@@ -22,6 +24,7 @@ extern "C" int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC) {
   if (cfg == CFG_A) *BM = 128; else if (cfg == CFG_B) *BM = 64; else if (cfg == CFG_C) *BM = 32; else return EMO_ERR_BAD_ARG;
   if (KH == 3 && KW == 3) *KC = EMO_CONV_KC_3X3;
   else if (KH == 1 && KW == 1) *KC = EMO_CONV_KC_1X1;
+  else if (KH == 1 && KW == 7) *KC = EMO_CONV_KC_1X7;
   else return EMO_ERR_UNSUPPORTED;
   return EMO_OK;
 }
@@ -33,8 +36,9 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
   if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMO_ERR_BAD_ARG;
-  if (KD != 1 && KD != 3) return EMO_ERR_UNSUPPORTED;
+  if (KD != 1 && KD != 3 && KD != 7) return EMO_ERR_UNSUPPORTED;
   if (KD == 3 && !(KH == 3 && KW == 3)) return EMO_ERR_UNSUPPORTED;
+  if ((KD == 7) != (KH == 1 && KW == 7)) return EMO_ERR_UNSUPPORTED;   // 7x7 2-D conv = KD 7 over rows x 1x7 taps
   if (cfg < 0 || cfg >= N_CFGS) return EMO_ERR_BAD_ARG;
   if (!emo_aligned16(wpk)) return EMO_ERR_ALIGN;
   if (ups && D != 1) return EMO_ERR_UNSUPPORTED;
@@ -52,6 +56,8 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
     fn = cfg == CFG_A ? conv_lookup_3x3_A(shape, ups) : cfg == CFG_B ? conv_lookup_3x3_B(shape, ups) : conv_lookup_3x3_C(shape, ups);
   } else if (KH == 1 && KW == 1) {
     fn = cfg == CFG_A ? conv_lookup_1x1_A(shape, ups) : cfg == CFG_B ? conv_lookup_1x1_B(shape, ups) : conv_lookup_1x1_C(shape, ups);
+  } else if (KH == 1 && KW == 7) {
+    fn = cfg == CFG_A ? conv_lookup_1x7_A(shape, ups) : cfg == CFG_B ? conv_lookup_1x7_B(shape, ups) : nullptr;
   } else {
     return EMO_ERR_UNSUPPORTED;
   }

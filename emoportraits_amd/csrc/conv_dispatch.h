@@ -12,7 +12,8 @@ typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 
 
 #define EMO_CONV_KC_3X3 4
-#define EMO_CONV_KC_1X1 16
+#define EMO_CONV_KC_1X1 32
+#define EMO_CONV_KC_1X7 4
 
 #define CONV_FOR_SHAPE(KH, KW, KC, TM, TP, WGM, WGP, shape, ups)                                              \
   ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 1, 128, TM, TP, WGM, WGP, true>          \

@@ -297,8 +297,19 @@ int conv_igemm_launch(ConvArgs a, hipStream_t s) {
   if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
   const size_t lds = (size_t)(2 * Cfg::BUF + (a.scale ? 2 * a.Cin : 0)) * sizeof(float);
-  if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
+  if (lds > 160 * 1024) return EMO_ERR_UNSUPPORTED;
+  auto kern = conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
+  if (lds > 64 * 1024) {
+    // opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU); idempotent, so a benign race
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      raised = true;
+    }
+  }
   dim3 g((unsigned)nt, cot, a.N);
-  hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>), g, dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, g, dim3(256), lds, s, a);
   return emo_launch_status();
 }

@@ -288,15 +288,25 @@ struct __attribute__((aligned(16))) TapRec {
   unsigned inb;
   unsigned pad[3];
 };
-constexpr int VPB = 64;   // voxels per block
+// XCD-aware block order (cdna_hip_programming.md T1).  The dispatcher places block b on XCD b % 8, each XCD has a
+// private 4 MiB L2, and the 8 corner rows of neighbouring output rows / slices overlap: with the default order
+// the 8 XCDs each pull (almost) the whole 25 MB volume through their own L2.  Remapped, XCD k walks one
+// contiguous eighth of the (sample, z, y, x) ordered work, so a corner row is fetched from HBM / Infinity Cache
+// once and re-used out of that XCD's L2 by the following rows and the next z-slice.  Bijective for any total.
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
 
-template <int PAD, int MODE>
+template <int PAD, int MODE, int VPB>
 __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const float* __restrict__ grid,
                                            const float* __restrict__ theta, const float* __restrict__ lin_x,
                                            const float* __restrict__ lin_y, const float* __restrict__ lin_z, int n,
                                            int vox0, int nvox, int D, int H, int W, int Ho, int Wo) {
-  if (threadIdx.x < VPB) {
-    const int vox = vox0 + threadIdx.x;
+  for (int i = threadIdx.x; i < VPB; i += 256) {
+    const int vox = vox0 + i;
     Taps t;
     if (vox < nvox) {
       float gx, gy, gz;
@@ -311,7 +321,7 @@ __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const floa
 #pragma unroll
     for (int k = 0; k < 8; ++k) { r.off[k] = t.off[k]; r.w[k] = t.w[k]; }
     r.inb = t.inb; r.pad[0] = r.pad[1] = r.pad[2] = 0;
-    recs[threadIdx.x] = r;
+    recs[i] = r;
   }
 }
 
@@ -346,18 +356,19 @@ __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, c
   return acc;
 }
 
-// NDHWC -> NDHWC, grid = (ceil(nvox/64), 1, N)
-template <int PAD, int MODE>
+// NDHWC -> NDHWC, 1-D grid of N * ceil(nvox/VPB) blocks
+template <int PAD, int MODE, int VPB, bool REMAP>
 __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
-    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int bps) {
   __shared__ TapRec recs[VPB];
   const int LPV = C >> 2;
   const int nvox = Do * Ho * Wo;
-  const int n = blockIdx.z;
-  const int vox0 = blockIdx.x * VPB;
-  stage_taps<PAD, MODE>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
+  const int L = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int n = L / bps;
+  const int vox0 = (L - n * bps) * VPB;
+  stage_taps<PAD, MODE, VPB>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
   __syncthreads();
   const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
   const unsigned row_bytes = (unsigned)C * 4u;
@@ -371,21 +382,22 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
   }
 }
 
-// NDHWC -> NCDHW, grid = (ceil(nvox/64), 1, N); dynamic LDS = C * 65 floats (transpose tile)
-template <int PAD, int MODE>
+// NDHWC -> NCDHW, 1-D grid; dynamic LDS = VPB tap records + C * (VPB + 1) floats (transpose tile)
+template <int PAD, int MODE, int VPB, bool REMAP>
 __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
-    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int bps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TapRec* recs = reinterpret_cast<TapRec*>(smem);                 // VPB * 80 B
   float* tile = smem + VPB * (sizeof(TapRec) / 4);                 // [C][VPB + 1]
   constexpr int LD = VPB + 1;
   const int LPV = C >> 2;
   const int nvox = Do * Ho * Wo;
-  const int n = blockIdx.z;
-  const int vox0 = blockIdx.x * VPB;
-  stage_taps<PAD, MODE>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
+  const int L = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int n = L / bps;
+  const int vox0 = (L - n * bps) * VPB;
+  stage_taps<PAD, MODE, VPB>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
   __syncthreads();
   const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
   const unsigned row_bytes = (unsigned)C * 4u;
@@ -405,10 +417,51 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   __syncthreads();
   float* obase = out + (long)n * C * nvox + vox0;
   for (int i = threadIdx.x; i < C * VPB; i += 256) {
-    const int c = i >> 6;
-    const int v = i & 63;
+    const int c = i / VPB;
+    const int v = i - c * VPB;
     if (v < nv) obase[(long)c * nvox + v] = tile[c * LD + v];
   }
+}
+
+template <int PAD, int MODE, int VPB, bool REMAP>
+int launch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
+                 const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                 long vol_bstride, bool out_cl, hipStream_t s) {
+  const int nvox = Do * Ho * Wo;
+  const int bps = emo_cdiv(nvox, VPB);
+  const long total = (long)bps * N;
+  if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  if (out_cl) {
+    hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, VPB, REMAP>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
+                       theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
+  } else {
+    const size_t lds = VPB * sizeof(TapRec) + (size_t)C * (VPB + 1) * sizeof(float);
+    if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, VPB, REMAP>), dim3((unsigned)total), dim3(256), lds, s, vol,
+                       grid, theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
+  }
+  return emo_launch_status();
+}
+
+// variant: 0 / 2 = XCD-remapped, 64 voxels per block (default); 3 = no remap; 4 / 5 = 128 voxels (remap / not);
+//          6 / 7 = 256 voxels (NDHWC output only).  Kept selectable for in-process A/B measurements.
+template <int PAD, int MODE>
+int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
+                   const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                   long vol_bstride, bool out_cl, int variant, hipStream_t s) {
+#define EMO_CLV2(VPB_, REMAP_)                                                                                   \
+  return launch_cl_v2<PAD, MODE, VPB_, REMAP_>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, \
+                                               Wo, vol_bstride, out_cl, s)
+  switch (variant) {
+    case 0: case 2: EMO_CLV2(64, true);
+    case 3: EMO_CLV2(64, false);
+    case 4: EMO_CLV2(128, true);
+    case 5: EMO_CLV2(128, false);
+    case 6: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, true);
+    case 7: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, false);
+    default: return EMO_ERR_BAD_ARG;
+  }
+#undef EMO_CLV2
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -453,9 +506,8 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
       hipLaunchKernelGGL((gs3d_cl_kernel<PAD, MODE>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
                          out, C, D, H, W, Do, Ho, Wo, vol_bstride);
     } else {
-      dim3 g(emo_cdiv(nvox, VPB), 1, N);
-      hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y,
-                         lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+      return dispatch_cl_v2<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
+                                       vol_bstride, true, variant, s);
     }
   } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NCDHW) {
     if (C % 4) return EMO_ERR_UNSUPPORTED;
@@ -467,11 +519,8 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
       hipLaunchKernelGGL((gs3d_cl2ncdhw_kernel<PAD, MODE>), g, dim3(256), lds, s, vol, grid, theta, lin_x, lin_y,
                          lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
     } else {
-      const size_t lds = VPB * sizeof(TapRec) + (size_t)C * (VPB + 1) * sizeof(float);
-      if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
-      dim3 g(emo_cdiv(nvox, VPB), 1, N);
-      hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE>), g, dim3(256), lds, s, vol, grid, theta, lin_x,
-                         lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
+      return dispatch_cl_v2<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
+                                       vol_bstride, false, variant, s);
     }
   } else {
     return EMO_ERR_UNSUPPORTED;

@@ -1,0 +1,299 @@
+"""Host-side executors of the hot-path networks on top of the HIP kernels (emoportraits_amd/ops.py).
+
+Each class mirrors one reference module (same constructor inputs: a RAW reference state_dict + key prefix, so
+released checkpoints drop in), folds spectral norm / weight standardisation once, packs the conv weights for the
+implicit-GEMM kernel, and replays the module's forward as a sequence of kernel launches:
+
+    reference module (file:line)                                               here
+    ResBlock                networks/volumetric_avatar/utils.py:661-788         ResBlock
+    WarpGenerator           networks/volumetric_avatar/warp_generator_resnet.py WarpGenerator
+    Decoder + ImageDecoder  networks/volumetric_avatar/decoder.py:20-410        Decoder
+    LocalEncoder            networks/volumetric_avatar/local_encoder.py:26-125  LocalEncoder
+    VPN_ResBlocks           vpn_resblocks.py:22-49, resblocks_3d.py:9-62        VPNResBlocks
+    Unet3D                  networks/volumetric_avatar/unet_3d.py:18-290        Unet3D
+    Model.predict_embed     models/stage_1/volumetric_avatar/va.py:813-885      WarpEmbed
+
+There is no torch compute here: torch only owns the buffers.  Every op raises if the HIP library is missing.
+"""
+import math
+
+import torch
+
+from . import ops
+from .pack import PackedConv, fold_sn
+
+
+def _dev(t, device):
+    return t.detach().float().contiguous().to(device)
+
+
+class ResBlock:
+    """GN -> ReLU -> conv3 -> GN -> ReLU -> conv3 (+ skip), utils.py:661-788.
+
+    first_kind: 'ws' where the reference's WS replacement hit block_feats.2 (utils.py:1061-1096), else 'sn'.
+    The GroupNorm-apply + ReLU in front of each conv is folded into the conv's input staging; nearest x2
+    upsampling (decoder up-blocks) is folded into the conv's gather; the skip sum is the conv epilogue."""
+
+    def __init__(self, sd, prefix, first_kind, device):
+        self.prefix = prefix
+        self.conv1 = PackedConv.from_state_dict(sd, prefix + ".block_feats.2", first_kind, device)
+        self.conv2 = PackedConv.from_state_dict(sd, prefix + ".block.0", "sn", device)
+        self.skip = None
+        if (prefix + ".skip.0.weight_orig") in sd:
+            self.skip = PackedConv.from_state_dict(sd, prefix + ".skip.0", "sn", device)
+        self.g1, self.b1 = _dev(sd[prefix + ".block_feats.0.weight"], device), _dev(sd[prefix + ".block_feats.0.bias"], device)
+        self.g2, self.b2 = _dev(sd[prefix + ".block_feats.3.weight"], device), _dev(sd[prefix + ".block_feats.3.bias"], device)
+
+    def __call__(self, x, ups=False, ada1=None, ada2=None, down=None):
+        """x: block input (pre-upsample when ups).  ada1/ada2: (ada_gamma, ada_beta) [N,C] views or None.
+        down: avg-pool kernel applied to the block output.  The reference pools the main and the skip branch
+        separately before adding them (utils.py:744-760); pooling is linear, so pool(main + skip) is the same
+        function evaluated with one pooling pass instead of two."""
+        a1 = ada1 or (None, None)
+        a2 = ada2 or (None, None)
+        # GroupNorm statistics are invariant under nearest x2 upsampling (every element is replicated 4x),
+        # so they are reduced on the small pre-upsample tensor
+        s1, h1 = ops.groupnorm_affine(x, self.g1, self.b1, a1[0], a1[1])
+        h = ops.conv_igemm(x, self.conv1, s1, h1, relu_in=True, ups=ups)
+        s2, h2 = ops.groupnorm_affine(h, self.g2, self.b2, a2[0], a2[1])
+        if self.skip is not None:
+            r = ops.conv_igemm(x, self.skip, ups=ups)
+            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, out=r)
+        else:
+            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=x, res_ups=ups)
+        return ops.avgpool(out, down) if down is not None else out
+
+
+class WarpEmbed:
+    """Model.predict_embed, warp-embedding branch (va.py:813-885): Linear(pose) -> (+idt)*0.5 -> 1x1 conv."""
+
+    def __init__(self, sd, cfg, device):
+        self.es = cfg["gen_embed_size"]
+        self.w_lin = _dev(sd["pose_unsqueeze_nw.weight"], device)                       # [C*es*es, E]
+        w = fold_sn(sd["warp_embed_head_orig_nw.weight_orig"].float(), sd["warp_embed_head_orig_nw.weight_u"].float(),
+                    sd["warp_embed_head_orig_nw.weight_v"].float())
+        self.w_head = _dev(w.reshape(w.shape[0], w.shape[1]), device)                   # [C, C]
+
+    def __call__(self, pose_embed, idt_embed):
+        """pose_embed [B,E], idt_embed [1,C,es,es] -> warp embed [B, C, es*es]"""
+        B = pose_embed.shape[0]
+        nn = self.es * self.es
+        e = ops.small_gemm(self.w_lin, pose_embed.reshape(B, -1, 1), 1)                  # [B, C*nn, 1]
+        x = ops.add(e, idt_embed.reshape(-1), 0.5)                                       # (e + idt) * 0.5
+        return ops.small_gemm(self.w_head, x.view(B, -1, nn), nn)                        # [B, C, nn]
+
+
+class WarpGenerator:
+    """warp_generator_resnet.py:38-181.  __call__ returns the planar deltas [B,3,d,s,s]; the sampler adds the
+    identity lattice itself (grid_kind=1), so `warp` is never materialised."""
+
+    def __init__(self, sd, prefix, cfg, device):
+        self.prefix = prefix
+        nb = int(math.log(cfg["warp_output_size"] // cfg["gen_embed_size"], 2))
+        f = lambda i: min(int(cfg["gen_num_channels"] * cfg["warp_channel_mult"] * 2 ** i), cfg["gen_max_channels"]) // 32 * 32
+        self.chans = [f(nb)] + [f(i) for i in range(nb - 1, -1, -1)]
+        self.inp = cfg["gen_embed_size"]
+        self.out_depth = cfg["gen_latent_texture_depth"]
+        self.n_depth_resize = int(math.log(cfg["gen_latent_texture_size"] // self.inp, 2))
+        w = fold_sn(sd[prefix + ".first_conv.weight_orig"].float(), sd[prefix + ".first_conv.weight_u"].float(),
+                    sd[prefix + ".first_conv.weight_v"].float())
+        self.w_first = _dev(w.reshape(w.shape[0], w.shape[1]), device)
+        self.blocks = [ResBlock(sd, f"{prefix}.blocks_3d.{i}", "ws", device) for i in range(nb)]
+        # ProjectorNorm (utils.py:1113-1151): rows of all adaptive norms concatenated
+        us, vs, rows, gam, bet = [], [], [], [], []
+        self.slices = []
+        off = 0
+        for i in range(2 * nb):
+            u = sd[f"{prefix}.projector.u.{i}"].float()
+            us.append(u)
+            vs.append(sd[f"{prefix}.projector.v.{i}"].float())
+            rows += [i] * u.shape[0]
+            blk, which = divmod(i, 2)
+            npre = f"{prefix}.blocks_3d.{blk}.block_feats.{0 if which == 0 else 3}"
+            gam.append(sd[npre + ".weight"].float())
+            bet.append(sd[npre + ".bias"].float())
+            self.slices.append((off, off + u.shape[0]))
+            off += u.shape[0]
+        self.u_all = _dev(torch.cat(us), device)                                         # [R, 512]
+        self.v_all = _dev(torch.stack(vs), device)                                       # [2nb, E, 2]
+        self.norm_of_row = torch.tensor(rows, dtype=torch.int32, device=device)
+        self.gamma_all, self.beta_all = _dev(torch.cat(gam), device), _dev(torch.cat(bet), device)
+        self.gh, self.bh = _dev(sd[prefix + ".pre_head.0.weight"], device), _dev(sd[prefix + ".pre_head.0.bias"], device)
+        self.head = PackedConv.from_state_dict(sd, prefix + ".head.0.0", "sn", device)
+
+    def __call__(self, embed):
+        """embed [B, C, es*es] -> deltas [B, 3, d, s, s]"""
+        B = embed.shape[0]
+        nn = embed.shape[2]
+        T = ops.small_gemm(self.u_all, embed, nn)                                        # [B, R, nn]
+        ag, ab = ops.projector_finalize(T, self.v_all, self.norm_of_row, self.gamma_all, self.beta_all)
+        x = ops.small_gemm(self.w_first, embed, nn)                                      # [B, C0*inp, nn]
+        inp = self.inp
+        x = x.view(B, -1, inp, inp, inp)
+        size = [inp, inp, inp]
+        for i, blk in enumerate(self.blocks, 1):
+            size[1] *= 2
+            size[2] *= 2
+            depth_new = min(self.out_depth * 2 ** (self.n_depth_resize - i), size[1]) if i < self.n_depth_resize else self.out_depth
+            up, down = depth_new > size[0], depth_new < size[0]
+            size[0] = depth_new
+            x = ops.upsample_trilinear(x, (2, 2, 2) if up else (1, 2, 2))
+            (a0, a1), (b0, b1) = self.slices[2 * (i - 1)], self.slices[2 * (i - 1) + 1]
+            x = blk(x, ada1=(ag[:, a0:a1], ab[:, a0:a1]), ada2=(ag[:, b0:b1], ab[:, b0:b1]))
+            if down:
+                x = ops.avgpool(x, (2, 1, 1))
+        s, h = ops.groupnorm_affine(x, self.gh, self.bh)
+        return ops.conv_igemm(x, self.head, s, h, relu_in=True, act="tanh")
+
+
+class Decoder:
+    """decoder.py: res_decoder (1x1 + dec_num_blocks ResBlocks @ latent size) + ImageDecoder up-stages + sigmoid head."""
+
+    def __init__(self, sd, prefix, cfg, device):
+        nup = int(math.log(cfg["image_size"] // cfg["gen_latent_texture_size"], 2))
+        self.first = PackedConv.from_state_dict(sd, prefix + ".res_decoder.0", "sn", device)
+        self.trunk = [ResBlock(sd, f"{prefix}.res_decoder.{i + 1}", "ws", device) for i in range(cfg["dec_num_blocks"])]
+        self.up = []
+        k = 0
+        for _ in range(nup):
+            for j in range(cfg["im_dec_num_lrs_per_resolution"]):
+                self.up.append((ResBlock(sd, f"{prefix}.img_decoder.dec_img_blocks.{k}", "ws", device), j == 0))
+                k += 1
+        hp = prefix + ".img_decoder.dec_img_head"
+        self.gh, self.bh = _dev(sd[hp + ".0.weight"], device), _dev(sd[hp + ".0.bias"], device)
+        self.head = PackedConv.from_state_dict(sd, hp + ".2", "ws", device)
+
+    def __call__(self, feat_2d):
+        """feat_2d [B, c*d, s, s] -> (img [B,3,S,S], feat_2d after res_decoder, img_feat) as stage_two=True returns"""
+        x = ops.conv_igemm(feat_2d, self.first)
+        for blk in self.trunk:
+            x = blk(x)
+        feat = x
+        for blk, ups in self.up:
+            x = blk(x, ups=ups)
+        s, h = ops.groupnorm_affine(x, self.gh, self.bh)
+        img = ops.conv_igemm(x, self.head, s, h, relu_in=True, act="sigmoid")
+        return img, feat, x
+
+
+class VPNResBlocks:
+    """vpn_resblocks.py / resblocks_3d.py: plain GroupNorm => both convs keep spectral norm."""
+
+    def __init__(self, sd, prefix, cfg, device):
+        self.blocks = [ResBlock(sd, f"{prefix}.net.net.{i}", "sn", device) for i in range(cfg["source_volume_num_blocks"])]
+
+    def __call__(self, vol):
+        for b in self.blocks:
+            vol = b(vol)
+        return vol
+
+
+class Unet3D:
+    """unet_3d.py:44-290 (released flags: no adaptive layers, learned constant input, skip ResBlocks)."""
+
+    def __init__(self, sd, prefix, cfg, device):
+        self.nb = int(math.log(cfg["gen_latent_texture_size"] // cfg["gen_dummy_input_size"], 2))
+        self.depth = cfg["gen_latent_texture_depth"]
+        self.down = [ResBlock(sd, f"{prefix}.blocks_3d_down.{i}", "sn", device) for i in range(self.nb)]
+        self.up = [ResBlock(sd, f"{prefix}.blocks_3d_up.{i}", "sn", device) for i in range(self.nb)]
+        self.skipb = [ResBlock(sd, f"{prefix}.skip_blocks_3d_up.{i}", "sn", device) for i in range(self.nb)]
+        self.input_tensor = _dev(sd[prefix + ".input_tensor"], device)
+        self.gh, self.bh = _dev(sd[prefix + ".head.0.weight"], device), _dev(sd[prefix + ".head.0.bias"], device)
+        self.head = PackedConv.from_state_dict(sd, prefix + ".head.2", "sn", device)
+
+    def __call__(self, vol):
+        nb = self.nb
+        x = vol
+        feats = []
+        size = [self.depth, vol.shape[-1], vol.shape[-1]]
+        for i in range(nb):
+            up = down = False
+            if i < nb - 1:
+                size[1] //= 2
+                size[2] //= 2
+                depth_new = min(size[0] * 2, size[1])
+                up, down = depth_new > size[0], depth_new < size[0]
+                size[0] = depth_new
+                if up:
+                    x = ops.upsample_trilinear(x, (2, 1, 1))
+            x = self.down[i](x)
+            feats.append(x)
+            if i < nb - 1:
+                x = ops.avgpool(x, (2, 2, 2) if down else (1, 2, 2))
+        feats = feats[::-1]
+        B = vol.shape[0]
+        x = self.input_tensor.expand(B, -1, -1, -1, -1).contiguous()
+        size = [x.shape[2], x.shape[3], x.shape[4]]
+        for i, feat in enumerate(feats, 1):
+            size[1] *= 2
+            size[2] *= 2
+            depth_new = min(self.depth * 2 ** (nb - i), size[1])
+            up, down = depth_new > size[0], depth_new < size[0]
+            size[0] = depth_new
+            x = ops.upsample_trilinear(x, (2, 2, 2) if up else (1, 2, 2))
+            skip = self.skipb[i - 1](feat)
+            x = self.up[i - 1](ops.add(x, skip))
+            if down:
+                x = ops.avgpool(x, (2, 1, 1))
+        s, h = ops.groupnorm_affine(x, self.gh, self.bh)
+        return ops.conv_igemm(x, self.head, s, h, relu_in=True)
+
+
+class HotPath:
+    """All hot-path networks of one checkpoint, resident on one GPU.
+
+    driver_pass replays notebooks/infer.py:583-637 for a BATCH of driver frames sharing one source identity
+    (the reference loops batch-1 calls, F5).  source_pass replays infer.py:433-507."""
+
+    def __init__(self, state_dict, cfg, device="cuda:0", with_source=True):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        sd = state_dict
+        self.embed = WarpEmbed(sd, cfg, self.device)
+        self.uv_generator = WarpGenerator(sd, "uv_generator_nw", cfg, self.device)
+        self.decoder = Decoder(sd, "decoder_nw", cfg, self.device)
+        self.pad = cfg["grid_sample_padding_mode"]
+        self.c, self.d, self.s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
+        self.with_source = with_source
+        if with_source:
+            self.xy_generator = WarpGenerator(sd, "xy_generator_nw", cfg, self.device)
+            self.volume_source = VPNResBlocks(sd, "volume_source_nw", cfg, self.device)
+            self.volume_process = Unet3D(sd, "volume_process_nw", cfg, self.device)
+            from .encoder import LocalEncoder
+            self.local_encoder = LocalEncoder(sd, "local_encoder_nw", cfg, self.device)
+
+    # ---- per identity -------------------------------------------------------------------------------
+    def source_pass(self, source_img_masked, idt_embed, source_pose_embed, theta_src, keep=False):
+        """-> canonical volume [1,c,d,s,s] (NCDHW, as the reference caches it in self.target_latent_volume)"""
+        c, d, s = self.c, self.d, self.s
+        latents = self.local_encoder(source_img_masked)
+        emb = self.embed(source_pose_embed, idt_embed)
+        delta_xy = self.xy_generator(emb)
+        vol = self.volume_source(latents.view(1, c, d, s, s))
+        inv = torch.linalg.inv(theta_src.float().cpu()).to(self.device)   # 4x4 inverse on the host (infer.py:443)
+        rot = ops.grid_sample3d(vol, theta=inv, padding_mode=self.pad)
+        pre = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=self.pad)
+        canonical = self.volume_process(pre)
+        if keep:
+            return dict(latents=latents, warp_embed=emb, delta_xy=delta_xy, source_volume=vol, pre_canonical=pre,
+                        canonical=canonical)
+        return canonical
+
+    def prepare_canonical(self, canonical):
+        """channels-last copy of the cached canonical volume (done once per identity)"""
+        return ops.volume_to_channels_last(canonical)
+
+    # ---- per driver batch ---------------------------------------------------------------------------
+    def driver_pass(self, canonical_cl, idt_embed, target_pose_embed, theta_drv, keep=False):
+        B = target_pose_embed.shape[0]
+        emb = self.embed(target_pose_embed, idt_embed)
+        delta_uv = self.uv_generator(emb)
+        warped = ops.grid_sample3d(canonical_cl, delta=delta_uv, padding_mode=self.pad, in_layout="ndhwc",
+                                   out_layout="ndhwc")
+        aligned = ops.grid_sample3d(warped, theta=theta_drv, padding_mode=self.pad, in_layout="ndhwc",
+                                    out_layout="ncdhw")
+        feat = aligned.view(B, self.c * self.d, self.s, self.s)
+        img, deep_f, img_f = self.decoder(feat)
+        if keep:
+            return dict(warp_embed=emb, delta_uv=delta_uv, aligned=aligned, img=img, deep_f=deep_f, img_f=img_f)
+        return img

@@ -175,9 +175,11 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         want = (N, layer.cout, D, H, W) if res_ups else (N, layer.cout, D, Hl, Wl)
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
             raise ValueError("bad residual shape")
-    rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.wpk), hip.ptr(layer.bias), hip.ptr(scale), hip.ptr(shift),
-                                hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd, layer.kh, layer.kw,
-                                int(ups), int(relu_in), hip.ACT[act], int(res_ups), layer.cfg, hip.current_stream())
+    cfg = layer.cfg_for(N * D * Hl * Wl // 128)
+    rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
+                                hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
+                                layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg,
+                                hip.current_stream())
     hip.check(rc, f"emo_conv_igemm_f32[{layer.name}]")
     return out
 

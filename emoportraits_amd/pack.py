@@ -79,8 +79,29 @@ def pack_weight(w, cfg):
     return wp.view(-1)
 
 
+# relative MFMA efficiency of the block configs measured on MI355X (profiles/r1_conv_microbench.jsonl):
+# the 32-row tile re-stages the same input patch for a quarter of the work
+_CFG_EFF = {CFG_A: 1.0, CFG_B: 0.97, CFG_C: 0.88}
+_FILL_BLOCKS = 512   # 2 blocks per CU on 256 CUs
+
+
+def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
+    """pick the block config for one launch: enough blocks to fill 256 CUs first, then least channel padding,
+    then the larger tile"""
+    best = None
+    for cfg in allowed:
+        bm = _BM[cfg]
+        cot = -(-cout // bm)
+        blocks = cot * n_pos_tiles
+        score = min(blocks, _FILL_BLOCKS) / _FILL_BLOCKS * (cout / (cot * bm)) * _CFG_EFF[cfg]
+        if best is None or score > best[0] + 1e-9:
+            best = (score, cfg)
+    return best[1]
+
+
 class PackedConv:
-    """One convolution of the hot path, ready for emo_conv_igemm_f32."""
+    """One convolution of the hot path, ready for emo_conv_igemm_f32.  Weights are packed lazily per block config
+    (the best config depends on the batch size of the call); `cfg` pins one config (tests / benchmarks)."""
 
     def __init__(self, name, weight, bias, device, cfg=None):
         if weight.dim() == 4:
@@ -90,10 +111,24 @@ class PackedConv:
             cout, cin, kd, kh, kw = weight.shape
         self.name = name
         self.cin, self.cout, self.kd, self.kh, self.kw = cin, cout, kd, kh, kw
-        self.cfg = choose_cfg(cout) if cfg is None else cfg
-        self.wpk = pack_weight(weight, self.cfg).to(device)
+        self.device = device
+        self._weight = weight.float().contiguous()      # folded fp32 weight kept on the host for lazy packing
+        self._packed = {}
+        self.pinned_cfg = cfg
+        self.allowed = (CFG_A, CFG_B) if (kh, kw) == (1, 7) else (CFG_A, CFG_B, CFG_C)
         self.bias = None if bias is None else bias.float().contiguous().to(device)
         self.macs_per_position = cout * cin * kd * kh * kw
+        self.packed(choose_cfg(cout) if cfg is None else cfg)
+
+    def packed(self, cfg):
+        if cfg not in self._packed:
+            self._packed[cfg] = pack_weight(self._weight, cfg).to(self.device)
+        return self._packed[cfg]
+
+    def cfg_for(self, n_pos_tiles):
+        if self.pinned_cfg is not None:
+            return self.pinned_cfg
+        return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
     @classmethod
     def from_state_dict(cls, sd, prefix, kind, device, cfg=None):

@@ -37,6 +37,11 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
         res["cl"] = ops.volume_to_channels_first(ocl).cpu()
         assert torch.equal(res["cl"], ocl.cpu().permute(0, 4, 1, 2, 3).contiguous())
         res["cl2ncdhw"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw").cpu()
+        for var in (3, 4, 5, 6, 7):   # block-order / voxels-per-block variants of the v2 kernels
+            o = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=var)
+            res[f"cl_var{var}"] = o.cpu().permute(0, 4, 1, 2, 3).contiguous()
+        for var in (3, 4, 5):
+            res[f"cl2ncdhw_var{var}"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw", variant=var).cpu()
         # variant 1 = the first-generation channels-last kernels (kept for A/B measurements)
         ocl1 = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=1)
         res["cl_v1"] = ocl1.cpu().permute(0, 4, 1, 2, 3).contiguous()
@@ -143,6 +148,25 @@ def test_size_independent_properties_at_batch_64():
     centre = torch.stack([xx, yy, zz], -1)[None].to(DEV)
     rec = ops.grid_sample3d(vol, centre)
     assert (rec - vol).abs().max().item() <= 2e-6 * vol.abs().max().item()
+
+
+@pytest.mark.parametrize("pm", PADS)
+def test_delta_grid_mode_equals_materialised_warp(pm):
+    """WarpGenerator output consumed as planar deltas: lattice + delta inside the kernel == the reference's
+    warp = (identity_grid + deltas).permute(0,2,3,4,1) fed to F.grid_sample"""
+    g = torch.Generator().manual_seed(12)
+    C, D, S, N = 8, 16, 64, 3
+    vol = torch.randn(1, C, D, S, S, generator=g)
+    delta = torch.tanh(torch.randn(N, 3, D, S, S, generator=g)) * 0.4
+    ident = O.identity_grid_3d(D, S)[..., :3].view(1, D, S, S, 3).permute(0, 4, 1, 2, 3)
+    warp = (ident + delta).permute(0, 2, 3, 4, 1)
+    ref = F.grid_sample(vol.expand(N, -1, -1, -1, -1), warp, padding_mode=pm, align_corners=False)
+    v = vol.to(DEV)
+    assert torch.equal(ops.grid_sample3d(v, delta=delta.to(DEV), padding_mode=pm).cpu(), ref)
+    vcl = ops.volume_to_channels_last(v)
+    assert torch.equal(ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw").cpu(), ref)
+    o = ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ndhwc")
+    assert torch.equal(o.cpu().permute(0, 4, 1, 2, 3), ref)
 
 
 def test_empty_batch_is_rejected():

@@ -1,0 +1,157 @@
+"""GPU parity of the network executors (emoportraits_amd/nets.py) against
+  (a) the committed golden outputs of the REAL reference (tests/golden/tiny_hotpath.pt, reduced width), and
+  (b) the oracle (oracle/restate.py, pinned bit-exactly to the reference in the build container) at the released
+      architecture, R256 and R512, with seeded random checkpoints in the reference key layout.
+
+Tolerance (stated): every stage within 1e-4 .. 5e-4 * max|reference stage output| -- fp32 kernels with a different
+summation order than the CPU library, chained through up to ~40 convolutions; the sampler's index arithmetic is
+bit-exact, so there is no discontinuous error source.  The final sigmoid image is bounded in absolute terms (2e-4).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import restate as O  # noqa: E402
+
+from emoportraits_amd import config, nets, random_init  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL = 1e-4
+
+
+def rel(got, ref):
+    return (got.detach().cpu().double() - ref.double()).abs().max().item() / (ref.double().abs().max().item() + 1e-30)
+
+
+def check(stage, got, ref, tol=RTOL):
+    assert got.shape == ref.shape, (stage, got.shape, ref.shape)
+    e = rel(got, ref)
+    assert e <= tol, f"{stage}: rel err {e:.3e} > {tol:.1e}"
+    return e
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return torch.load(os.path.join(golden_dir, "tiny_hotpath.pt"), weights_only=False)
+
+
+def test_tiny_hotpath_against_reference_golden(tiny):
+    cfg = config.hot_path_config(overrides=tiny["cfg"])
+    hp = nets.HotPath(tiny["state_dict"], cfg, DEV)
+    d = lambda t: t.to(DEV)
+    src = hp.source_pass(d(tiny["img"]), d(tiny["idt_embed"]), d(tiny["source_pose_embed"]), d(tiny["theta_src"]), keep=True)
+    g = tiny["source"]
+    check("source.warp_embed", src["warp_embed"], g["warp_embed"])
+    check("source.latents", src["latents"], g["latents"])
+    check("source.source_volume", src["source_volume"], g["source_volume"])
+    check("source.pre_canonical", src["pre_canonical"], g["pre_canonical"], 5e-4)
+    check("source.canonical", src["canonical"], g["canonical"], 5e-4)
+    # driver pass on the reference's canonical volume, both frames in one batch
+    ccl = hp.prepare_canonical(d(g["canonical"]))
+    drv = hp.driver_pass(ccl, d(tiny["idt_embed"]), d(tiny["target_pose_embed"]), d(tiny["theta_drv"]), keep=True)
+    dd, ss = cfg["latent_volume_depth"], cfg["latent_volume_size"]
+    ident = O.identity_grid_3d(dd, ss)[..., :3].view(1, dd, ss, ss, 3)
+    for i in range(2):
+        r = tiny["driver"][i]
+        check(f"driver[{i}].warp_embed", drv["warp_embed"][i:i + 1], r["warp_embed"])
+        delta_ref = (r["uv_warp"] - ident).permute(0, 4, 1, 2, 3)
+        assert (drv["delta_uv"][i:i + 1].cpu() - delta_ref).abs().max().item() <= 2e-4
+        check(f"driver[{i}].aligned", drv["aligned"][i:i + 1], r["aligned"], 5e-4)
+        check(f"driver[{i}].deep_f", drv["deep_f"][i:i + 1], r["deep_f"], 5e-4)
+        check(f"driver[{i}].img_f", drv["img_f"][i:i + 1], r["img_f"], 5e-4)
+        assert (drv["img"][i:i + 1].cpu() - r["img"]).abs().max().item() <= 1e-3
+
+
+def _full_size(S, B, seed):
+    cfg = config.hot_path_config(overrides={"image_size": S})
+    sd = random_init.random_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    inputs = dict(
+        img=torch.rand(1, 3, S, S, generator=g), idt=rnd(1, 512, 4, 4), pose_s=rnd(1, 128), pose_t=rnd(B, 128),
+        th_s=O.get_transform_matrix(1 + 0.05 * rnd(1, 3), 0.3 * rnd(1, 3), 0.05 * rnd(1, 3)),
+        th_t=O.get_transform_matrix(1 + 0.05 * rnd(B, 3), 0.3 * rnd(B, 3), 0.05 * rnd(B, 3)),
+        canonical=rnd(1, 96, 16, 64, 64))
+    return cfg, sd, inputs
+
+
+@pytest.mark.parametrize("S,B", [(256, 2), (512, 1)])
+def test_driver_pass_released_architecture_vs_oracle(S, B):
+    cfg, sd, x = _full_size(S, B, seed=S)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = O.driver_pass(sd, cfg, x["canonical"], x["idt"], x["pose_t"], x["th_t"])
+    hp = nets.HotPath(sd, cfg, DEV, with_source=False)
+    d = lambda t: t.to(DEV)
+    ccl = hp.prepare_canonical(d(x["canonical"]))
+    got = hp.driver_pass(ccl, d(x["idt"]), d(x["pose_t"]), d(x["th_t"]), keep=True)
+    errs = {}
+    errs["warp_embed"] = check("warp_embed", got["warp_embed"], ref["warp_embed"])
+    errs["delta_abs"] = (got["delta_uv"].cpu() - ref["delta_uv"]).abs().max().item()
+    assert errs["delta_abs"] <= 2e-4
+    errs["aligned"] = check("aligned", got["aligned"], ref["aligned"], 5e-4)
+    errs["deep_f"] = check("deep_f", got["deep_f"], ref["deep_f"], 5e-4)
+    errs["img_f"] = check("img_f", got["img_f"], ref["img_f"], 5e-4)
+    errs["img_abs"] = (got["img"].cpu() - ref["img"]).abs().max().item()
+    assert errs["img_abs"] <= 2e-4, errs
+    print(f"PARITY R{S} B={B} driver:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
+def test_decoder_alone_is_tight():
+    """same input tensor on both sides: isolates the conv/GN kernels from warp sensitivity"""
+    cfg, sd, x = _full_size(256, 1, seed=7)
+    feat = torch.randn(2, 1536, 64, 64, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref_img, ref_feat, ref_imgf = O.decoder(sd, "decoder_nw", feat, cfg)
+    dec = nets.Decoder(sd, "decoder_nw", cfg, DEV)
+    img, f2, imgf = dec(feat.to(DEV))
+    e1 = check("deep_f", f2, ref_feat, 5e-5)
+    e2 = check("img_f", imgf, ref_imgf, 5e-5)
+    e3 = (img.cpu() - ref_img).abs().max().item()
+    assert e3 <= 5e-5
+    print("PARITY decoder alone:", e1, e2, e3)
+
+
+def test_warp_generator_alone():
+    cfg, sd, x = _full_size(256, 3, seed=9)
+    emb = torch.randn(3, 512, 16, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        _, ref_delta = O.warp_generator(sd, "uv_generator_nw", emb, cfg)
+    wg = nets.WarpGenerator(sd, "uv_generator_nw", cfg, DEV)
+    got = wg(emb.to(DEV))
+    assert got.shape == ref_delta.shape
+    e = (got.cpu() - ref_delta).abs().max().item()
+    assert e <= 1e-4, e
+    print("PARITY warp generator abs:", e)
+
+
+def test_source_pass_released_architecture_vs_oracle():
+    cfg, sd, x = _full_size(256, 1, seed=11)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = O.source_pass(sd, cfg, x["img"], x["idt"], x["pose_s"], x["th_s"])
+    hp = nets.HotPath(sd, cfg, DEV)
+    d = lambda t: t.to(DEV)
+    got = hp.source_pass(d(x["img"]), d(x["idt"]), d(x["pose_s"]), d(x["th_s"]), keep=True)
+    e = [check("latents", got["latents"], ref["latents"]),
+         check("source_volume", got["source_volume"], ref["source_volume"]),
+         check("pre_canonical", got["pre_canonical"], ref["pre_canonical"], 5e-4),
+         check("canonical", got["canonical"], ref["canonical"], 5e-4)]
+    print("PARITY source pass R256:", e)
+
+
+def test_batched_driver_equals_per_frame_calls():
+    """size-independent property: the batch dimension is embarrassingly parallel"""
+    cfg, sd, x = _full_size(256, 3, seed=13)
+    hp = nets.HotPath(sd, cfg, DEV, with_source=False)
+    d = lambda t: t.to(DEV)
+    ccl = hp.prepare_canonical(d(x["canonical"]))
+    full = hp.driver_pass(ccl, d(x["idt"]), d(x["pose_t"]), d(x["th_t"]))
+    for i in range(3):
+        one = hp.driver_pass(ccl, d(x["idt"]), d(x["pose_t"][i:i + 1]), d(x["th_t"][i:i + 1]))
+        assert (one - full[i:i + 1]).abs().max().item() <= 1e-5

@@ -1,0 +1,60 @@
+"""Stage breakdown of the HIP driver pass (per batch of B frames) at the released architecture.  JSON lines."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emoportraits_amd import config, nets, ops, random_init  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=5, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    Bs = [int(a) for a in sys.argv[2:]] or [1, 4, 8, 16]
+    cfg = config.hot_path_config(overrides={"image_size": S})
+    sd = random_init.random_state_dict(cfg, seed=0, with_source=False)
+    hp = nets.HotPath(sd, cfg, DEV, with_source=False)
+    g = torch.Generator().manual_seed(1)
+    canonical = torch.randn(1, 96, 16, 64, 64, generator=g).to(DEV)
+    ccl = hp.prepare_canonical(canonical)
+    idt = torch.randn(1, 512, 4, 4, generator=g).to(DEV)
+    for B in Bs:
+        pose = torch.randn(B, 128, generator=g).to(DEV)
+        srt = [t.to(DEV) for t in (1 + 0.05 * torch.randn(B, 3, generator=g), 0.3 * torch.randn(B, 3, generator=g),
+                                  0.05 * torch.randn(B, 3, generator=g))]
+        theta = ops.pose_theta(*srt)
+        emb = hp.embed(pose, idt)
+        delta = hp.uv_generator(emb)
+        warped = ops.grid_sample3d(ccl, delta=delta, in_layout="ndhwc", out_layout="ndhwc")
+        aligned = ops.grid_sample3d(warped, theta=theta, in_layout="ndhwc", out_layout="ncdhw")
+        feat = aligned.view(B, 96 * 16, 64, 64)
+        rec = dict(S=S, B=B)
+        rec["embed_ms"] = timeit(lambda: hp.embed(pose, idt))
+        rec["warpgen_ms"] = timeit(lambda: hp.uv_generator(emb))
+        rec["sampler_uv_ms"] = timeit(lambda: ops.grid_sample3d(ccl, delta=delta, in_layout="ndhwc", out_layout="ndhwc"))
+        rec["sampler_rot_ms"] = timeit(lambda: ops.grid_sample3d(warped, theta=theta, in_layout="ndhwc", out_layout="ncdhw"))
+        rec["decoder_ms"] = timeit(lambda: hp.decoder(feat))
+        rec["total_ms"] = timeit(lambda: hp.driver_pass(ccl, idt, pose, theta))
+        rec["fps"] = B / rec["total_ms"] * 1e3
+        rec = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rec.items()}
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
