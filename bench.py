@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X hot path: reenactment frames/sec, 1 source -> N driver frames (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--image-size 512] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the per-frame hot path (a3, a4, a5-uv, a1 x2 with a2 fused, a9, a11) over one batch of
+B synthetic driver frames that share one source identity, inputs resident in HBM.  Workload at N=1: released
+architecture at 512x512 (BASELINE configs[2]: full HIP path; configs[1]'s 64-driver batch is a sampler parity/bench case
+in tests/ + tools/bench_sampler.py).  Random-init weights in the reference key layout (the released checkpoint is not in
+the repo), synthetic embeddings/poses.  Multi-GPU: frames shard across ranks, per-GPU batch fixed ("weak"); the source
+pass runs on rank 0 and its canonical volume is broadcast over RCCL once per identity, outside the timed region
+(reported as source_pass_ms / broadcast_ms).
+
+The JSON line also carries
+  roofline      the dominant kernel (conv_igemm: fp32 MFMA implicit-GEMM conv): algorithmic FLOPs of every conv launch of
+                the timed region / its duration measured with HIP events on the launch stream, vs the 157.3 TF fp32 MFMA peak
+  roofline_sampler  the 3-D grid_sample kernels, algorithmic bytes / event time vs 8 TB/s
+  cpu_baseline  the oracle (oracle/restate.py, a port of the reference's PyTorch forward) timed on this box's host cores
+                on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from emoportraits_amd import config, nets, ops, parallel, random_init  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec; 6.29 TB/s measured copy
+
+
+class ConvMeter:
+    """Brackets every conv_igemm launch with HIP events on the launch stream and sums algorithmic FLOPs."""
+
+    def __init__(self):
+        self.events = []
+        self.flops = 0.0
+        self.launches = 0
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = ops.conv_igemm
+        meter = self
+
+        def wrapped(x, layer, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = meter._orig(x, layer, *a, **kw)
+            e1.record()
+            meter.events.append((e0, e1))
+            positions = out.numel() // layer.cout
+            meter.flops += 2.0 * positions * layer.macs_per_position
+            meter.launches += 1
+            return out
+
+        ops.conv_igemm = wrapped
+        nets.ops.conv_igemm = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        ops.conv_igemm = self._orig
+        nets.ops.conv_igemm = self._orig
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+class SamplerMeter:
+    def __init__(self):
+        self.events = []
+        self.bytes = 0.0
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = ops.grid_sample3d
+        meter = self
+
+        def wrapped(vol, grid=None, theta=None, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = meter._orig(vol, grid, theta, *a, **kw)
+            e1.record()
+            meter.events.append((e0, e1))
+            delta = kw.get("delta")
+            grid_bytes = (grid.numel() if grid is not None else 0) * 4 + (delta.numel() if delta is not None else 0) * 4
+            meter.bytes += vol.numel() * 4 + grid_bytes + out.numel() * 4   # shared volume counted once per launch
+            return out
+
+        ops.grid_sample3d = wrapped
+        nets.ops.grid_sample3d = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        ops.grid_sample3d = self._orig
+        nets.ops.grid_sample3d = self._orig
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+def cpu_baseline(cfg, sd, inputs, budget_s=25.0):
+    """oracle driver pass on the host cores, batch 1 per call as the reference does (bounded sample)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restate as O
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores // 2 if cores > 8 else cores, 64))
+    torch.set_num_threads(threads)
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        for i in range(6):
+            t0 = time.time()
+            O.driver_pass(sd, cfg, inputs["canonical"], inputs["idt"], inputs["pose"][i % inputs["pose"].shape[0]][None],
+                          inputs["theta"][i % inputs["theta"].shape[0]][None])
+            times.append(time.time() - t0)
+            if time.time() - t_start > budget_s and len(times) >= 2:
+                break
+    timed = sorted(times[1:]) if len(times) > 1 else times
+    med = timed[len(timed) // 2]
+    return dict(value=round(1.0 / med, 4), unit="frames/s", cores=threads, kind="port",
+                sample=f"{len(timed)} driver frames at {cfg['image_size']}x{cfg['image_size']}, batch 1 per call "
+                       f"(1 warm-up call excluded), oracle/restate.py on torch CPU fp32, median",
+                s_per_frame=round(med, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--image-size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=16, help="driver frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+
+    rank, world = parallel.init_distributed()
+    if world != max(1, a.gpus) and world != 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", parallel.local_device_index())
+    torch.cuda.set_device(dev)
+
+    cfg = config.hot_path_config(overrides={"image_size": a.image_size})
+    sd = random_init.random_state_dict(cfg, seed=a.seed)
+    hp = nets.HotPath(sd, cfg, dev, with_source=(rank == 0))
+    c, d, s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
+    S, B = a.image_size, a.batch
+
+    # ---- per identity: source pass on rank 0 (synthetic masked image + embeddings), RCCL broadcast ----
+    g = torch.Generator().manual_seed(a.seed + 1)
+    idt_cpu = torch.randn(1, cfg["gen_max_channels"], 4, 4, generator=g)
+    cache = {"canonical": None, "idt_embed": None, "theta_src": None}
+    source_ms = None
+    if rank == 0:
+        img = torch.rand(1, 3, S, S, generator=g).to(dev)
+        pose_s = torch.randn(1, cfg["lpe_output_channels_expression"], generator=g).to(dev)
+        srt_s = [t.to(dev) for t in (1 + 0.05 * torch.randn(1, 3, generator=g), 0.3 * torch.randn(1, 3, generator=g),
+                                    0.05 * torch.randn(1, 3, generator=g))]
+        th_s = ops.pose_theta(*srt_s)
+        hp.source_pass(img, idt_cpu.to(dev), pose_s, th_s)          # warm-up (lazy weight packing, allocator)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        canonical = hp.source_pass(img, idt_cpu.to(dev), pose_s, th_s)
+        torch.cuda.synchronize()
+        source_ms = (time.time() - t0) * 1e3
+        cache = {"canonical": canonical, "idt_embed": idt_cpu.to(dev), "theta_src": th_s}
+    t0 = time.time()
+    cache = parallel.broadcast_source_cache(
+        cache, dict(canonical=(1, c, d, s, s), idt_embed=(1, cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4)),
+        src=0, device=dev, world=world, rank=rank)
+    torch.cuda.synchronize()
+    broadcast_ms = (time.time() - t0) * 1e3
+    ccl = hp.prepare_canonical(cache["canonical"])
+    idt = cache["idt_embed"]
+
+    # ---- this rank's shard of synthetic driver frames (weak scaling: B per GPU per step) ----
+    gd = torch.Generator().manual_seed(a.seed + 100 + rank)
+    pose = torch.randn(B, cfg["lpe_output_channels_expression"], generator=gd).to(dev)
+    srt = [t.to(dev) for t in (1 + 0.05 * torch.randn(B, 3, generator=gd), 0.3 * torch.randn(B, 3, generator=gd),
+                              0.05 * torch.randn(B, 3, generator=gd))]
+
+    def step():
+        theta = ops.pose_theta(*srt)                                        # a3
+        img = hp.driver_pass(ccl, idt, pose, theta)                         # a4, a5, a1 x2 (+a2), a9
+        return ops.pack_rgb8(img)                                           # a11 (device-side uint8 packing)
+
+    for _ in range(a.warmup):
+        step()
+    conv_meter, samp_meter = ConvMeter(), SamplerMeter()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with conv_meter, samp_meter:
+        for _ in range(a.steps):
+            out = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+
+    if rank != 0:
+        return
+    frames = world * B * a.steps
+    fps = frames / elapsed
+    conv_ms = conv_meter.total_ms()
+    samp_ms = samp_meter.total_ms()
+    conv_tflops = conv_meter.flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    samp_gbps = samp_meter.bytes / (samp_ms * 1e-3) / 1e9 if samp_ms > 0 else 0.0
+    pmc = None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_conv_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            pmc = None
+    rec = {
+        "metric": "reenactment frames/sec @512x512, 1-src->N-driver" if S == 512 else f"reenactment frames/sec @{S}x{S}, 1-src->N-driver",
+        "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"released stage-1 architecture R{S}, full HIP driver pass (pose theta, warp embed, uv WarpGenerator, "
+                               f"2x 3-D grid_sample, decoder, uint8 pack), 1 source identity, {B} driver frames per GPU per step",
+                   "image_size": S, "frames_per_gpu_per_step": B, "weights": "seeded random, reference key layout",
+                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 32x32x2 MFMA implicit-GEMM conv, all instantiations)",
+                     "achieved": round(conv_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc,
+                     "launches_per_step": conv_meter.launches // max(1, a.steps),
+                     "avg_launch_ms": round(conv_ms / max(1, conv_meter.launches), 4),
+                     "share_of_step": round(conv_ms / (elapsed * 1e3), 3)},
+        "roofline_sampler": {"bound": "hbm", "kernel": "gs3d_cl_v2 / gs3d_cl2ncdhw_v2 (3-D grid_sample, channels-last)",
+                             "achieved": round(samp_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": round(samp_gbps / PEAK_HBM_GBPS, 4),
+                             "avg_launch_ms": round(samp_ms / max(1, len(samp_meter.events)), 4)},
+        "source_pass_ms": None if source_ms is None else round(source_ms, 2),
+        "broadcast_ms": round(broadcast_ms, 3),
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        inputs = dict(canonical=cache["canonical"].cpu(), idt=idt_cpu, pose=pose.cpu(), theta=ops.pose_theta(*srt).cpu())
+        rec["cpu_baseline"] = cpu_baseline(cfg, sd, inputs)
+    else:
+        rec["cpu_baseline"] = None
+    print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -300,6 +300,24 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
   return start + idx;
 }
 
+// Block order of one launch.  ORDER 0: dispatch order.  1: XCD-contiguous (above).  2: XCD-contiguous AND, inside an
+// XCD's share, z-slice-major over the samples of that share (needs N % 8 == 0): when N driver frames sample ONE shared
+// canonical volume with near-identity warps, the same few z-slices of the volume then serve all of the XCD's samples
+// back to back out of its L2 instead of being re-streamed once per sample.
+template <int ORDER>
+__device__ __forceinline__ void block_to_work(int b, int total, int bps, int nslices, int& n, int& blk) {
+  if (ORDER == 0) { n = b / bps; blk = b - n * bps; return; }
+  if (ORDER == 1) { const int L = xcd_remap(b, total); n = L / bps; blk = L - n * bps; return; }
+  const int xcd = b & 7, idx = b >> 3;
+  const int spx = (total / bps) >> 3;          // samples per XCD
+  const int bpz = bps / nslices;               // blocks per z-slice of one sample
+  const int z = idx / (spx * bpz);
+  const int rem = idx - z * (spx * bpz);
+  const int j = rem / bpz;
+  n = xcd * spx + j;
+  blk = z * bpz + (rem - j * bpz);
+}
+
 template <int PAD, int MODE, int VPB>
 __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const float* __restrict__ grid,
                                            const float* __restrict__ theta, const float* __restrict__ lin_x,
@@ -357,7 +375,7 @@ __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, c
 }
 
 // NDHWC -> NDHWC, 1-D grid of N * ceil(nvox/VPB) blocks
-template <int PAD, int MODE, int VPB, bool REMAP>
+template <int PAD, int MODE, int VPB, int ORDER>
 __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -365,9 +383,9 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
   __shared__ TapRec recs[VPB];
   const int LPV = C >> 2;
   const int nvox = Do * Ho * Wo;
-  const int L = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int n = L / bps;
-  const int vox0 = (L - n * bps) * VPB;
+  int n, blk;
+  block_to_work<ORDER>(blockIdx.x, gridDim.x, bps, Do, n, blk);
+  const int vox0 = blk * VPB;
   stage_taps<PAD, MODE, VPB>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
   __syncthreads();
   const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
@@ -383,7 +401,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
 }
 
 // NDHWC -> NCDHW, 1-D grid; dynamic LDS = VPB tap records + C * (VPB + 1) floats (transpose tile)
-template <int PAD, int MODE, int VPB, bool REMAP>
+template <int PAD, int MODE, int VPB, int ORDER>
 __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -394,9 +412,9 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   constexpr int LD = VPB + 1;
   const int LPV = C >> 2;
   const int nvox = Do * Ho * Wo;
-  const int L = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int n = L / bps;
-  const int vox0 = (L - n * bps) * VPB;
+  int n, blk;
+  block_to_work<ORDER>(blockIdx.x, gridDim.x, bps, Do, n, blk);
+  const int vox0 = blk * VPB;
   stage_taps<PAD, MODE, VPB>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
   __syncthreads();
   const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
@@ -423,7 +441,7 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   }
 }
 
-template <int PAD, int MODE, int VPB, bool REMAP>
+template <int PAD, int MODE, int VPB, int ORDER>
 int launch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                  const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                  long vol_bstride, bool out_cl, hipStream_t s) {
@@ -431,34 +449,38 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
   const int bps = emo_cdiv(nvox, VPB);
   const long total = (long)bps * N;
   if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  if (ORDER == 2 && ((N & 7) || (bps % Do) || (nvox % VPB)))     // z-slice-major order needs whole slices and N % 8 == 0
+    return launch_cl_v2<PAD, MODE, VPB, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
+                                           vol_bstride, out_cl, s);
   if (out_cl) {
-    hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, VPB, REMAP>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
+    hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, VPB, ORDER>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
                        theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
   } else {
     const size_t lds = VPB * sizeof(TapRec) + (size_t)C * (VPB + 1) * sizeof(float);
     if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, VPB, REMAP>), dim3((unsigned)total), dim3(256), lds, s, vol,
+    hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, VPB, ORDER>), dim3((unsigned)total), dim3(256), lds, s, vol,
                        grid, theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
   }
   return emo_launch_status();
 }
 
 // variant: 0 / 2 = XCD-remapped, 64 voxels per block (default); 3 = no remap; 4 / 5 = 128 voxels (remap / not);
-//          6 / 7 = 256 voxels (NDHWC output only).  Kept selectable for in-process A/B measurements.
+//          6 / 7 = 256 voxels (NDHWC output only); 8 = XCD-remapped + z-slice-major over the XCD's samples.  Kept selectable for in-process A/B measurements.
 template <int PAD, int MODE>
 int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                    const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                    long vol_bstride, bool out_cl, int variant, hipStream_t s) {
-#define EMO_CLV2(VPB_, REMAP_)                                                                                   \
-  return launch_cl_v2<PAD, MODE, VPB_, REMAP_>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, \
+#define EMO_CLV2(VPB_, ORDER_)                                                                                   \
+  return launch_cl_v2<PAD, MODE, VPB_, ORDER_>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, \
                                                Wo, vol_bstride, out_cl, s)
   switch (variant) {
-    case 0: case 2: EMO_CLV2(64, true);
-    case 3: EMO_CLV2(64, false);
-    case 4: EMO_CLV2(128, true);
-    case 5: EMO_CLV2(128, false);
-    case 6: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, true);
-    case 7: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, false);
+    case 0: case 2: EMO_CLV2(64, 1);
+    case 3: EMO_CLV2(64, 0);
+    case 4: EMO_CLV2(128, 1);
+    case 5: EMO_CLV2(128, 0);
+    case 6: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, 1);
+    case 7: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, 0);
+    case 8: EMO_CLV2(64, 2);
     default: return EMO_ERR_BAD_ARG;
   }
 #undef EMO_CLV2

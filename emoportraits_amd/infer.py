@@ -1,0 +1,335 @@
+"""Drop-in `InferenceWrapper` for the MI355X hot path -- SURVEY.md section 8(b), seams b1 (user API) and b2 (model attributes).
+
+Mirrors notebooks/infer.py of the reference: same constructor and `forward` signature (infer.py:63-65, :355-357),
+same files (`<project_dir>/<folder>/<experiment_name>/args.txt`, `.../checkpoints/<model_file_name>`), same cached
+attributes after a source call (`idt_embed`, `source_latent_volume`, `target_latent_volume`, `pred_source_theta`, ...)
+and the same return value `(List[PIL.Image], Tensor[B,3,S,S])` / `None`.
+
+What is NOT here, by scope ("next"): the third-party nets the reference calls around the hot path --
+face detector / cropper (mediapipe), face parsing (BiSeNet), matting (MODNet), IdtEmbed (ResNet-50), ExpressionEmbed and
+HeadPoseRegressor (ResNet-18s).  They plug in through `embedders=` (any callables, e.g. the reference's own torch
+modules); without them `forward` needs `crop=False` plus the embeddings those nets would have produced, through the
+reference's own hooks `custome_target_pose_embed` / `custome_target_theta_embed` (infer.py:565-566,603-604) and their
+source-side counterparts added here (`custome_source_pose_embed`, `custome_source_theta_embed`, `custome_idt_embed`).
+Missing pieces raise -- nothing falls back silently.
+
+Extension over the reference (which is batch-1, F5): driver inputs may carry a batch dimension, and
+`animate()` streams N driver frames in device-sized batches, sharded across ranks (emoportraits_amd/parallel.py).
+"""
+import os
+import pathlib
+from argparse import Namespace
+
+import torch
+
+from . import config as cfg_mod
+from . import nets, ops, parallel, schema
+
+
+class HipModel:
+    """The `self.model` attribute seam (b2): reference attribute names and call signatures over the HIP executors."""
+
+    def __init__(self, hot_path, args):
+        self.hp = hot_path
+        self.args = args
+        c = hot_path.cfg
+        d, s = c["latent_volume_depth"], c["latent_volume_size"]
+        gs, gz = torch.linspace(-1, 1, s), torch.linspace(-1, 1, d)
+        w, v, u = torch.meshgrid(gz, gs, gs, indexing="ij")
+        # models/stage_1/volumetric_avatar/va.py:101-105
+        self.identity_grid_3d = torch.stack([u, v, w, torch.ones_like(u)], dim=3).view(1, -1, 4).to(hot_path.device)
+        self._ident3 = torch.stack([u, v, w], 0)[None].contiguous().to(hot_path.device)   # [1,3,d,s,s]
+        self.embed_size = c["gen_embed_size"]
+        self.resize_warp_func = lambda x: x        # warp_output_size == gen_latent_texture_size is enforced by config
+
+    # va.py:264-265
+    def grid_sample(self, inputs, grid):
+        return ops.grid_sample3d(inputs.float().contiguous(), grid.float().contiguous(),
+                                 padding_mode=self.hp.pad)
+
+    def local_encoder_nw(self, img):
+        return self.hp.local_encoder(img.float().contiguous())
+
+    def volume_source_nw(self, vol):
+        return self.hp.volume_source(vol.contiguous())
+
+    def volume_process_nw(self, vol, embed_dict=None):
+        return self.hp.volume_process(vol.contiguous())
+
+    def _warp_from_delta(self, delta):
+        # warp_generator_resnet.py:178: (identity_grid + deltas).permute(0, 2, 3, 4, 1) -- a permuted view, as there
+        return ops.add(delta, self._ident3.reshape(-1)).permute(0, 2, 3, 4, 1)
+
+    def xy_generator_nw(self, embed_dict):
+        delta = self.hp.xy_generator(embed_dict["orig"].contiguous())
+        return [self._warp_from_delta(delta), delta]
+
+    def uv_generator_nw(self, embed_dict):
+        delta = self.hp.uv_generator(embed_dict["orig"].contiguous())
+        return [self._warp_from_delta(delta), delta]
+
+    def decoder_nw(self, data_dict, embed_dict, feat_2d, input_flip_feat=False, stage_two=False, **_):
+        img, feat, img_f = self.hp.decoder(feat_2d.contiguous())
+        if stage_two:
+            return img, None, feat, img_f
+        return img, None, None, None
+
+    def predict_embed(self, data_dict):
+        """va.py:813-885 -> (source, target, mixing, embed_dict); the mixing branch is a training construct (None)."""
+        idt = data_dict["idt_embed"]
+        out = []
+        for key in ("source_pose_embed", "target_pose_embed"):
+            e = self.hp.embed(data_dict[key].float().contiguous(), idt.float().contiguous())
+            out.append({"orig": e, "orig_d": e, "ada_v": data_dict[key]})
+        return out[0], out[1], None, {}
+
+
+class InferenceWrapper:
+    def __init__(self, experiment_name, which_epoch='latest', model_file_name='', use_gpu=True, num_gpus=1,
+                 fixed_bounding_box=False, project_dir='./', folder='mp_logs', model_='va',
+                 torch_home='', debug=False, print_model=False, print_params=True, args_overwrite={}, state_dict=None,
+                 pose_momentum=0.5, rank=0, args_path=None, embedders=None):
+        if not use_gpu:
+            raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
+        if model_ != 'va':
+            raise ValueError("only the stage-1 'va' model is on the MI355X hot path")
+        self.use_gpu, self.debug, self.num_gpus = use_gpu, debug, num_gpus
+        args_path = pathlib.Path(project_dir) / folder / experiment_name / 'args.txt' if args_path is None else args_path
+        found = cfg_mod.parse_args_txt(args_path)                                  # infer.py:74-76
+        found['project_dir'] = project_dir
+        for k, v in (args_overwrite or {}).items():                                # infer.py:79-81
+            found[k] = v
+        self.args = Namespace(**found)
+        self.cfg = cfg_mod.hot_path_config(found, released=False) if 'norm_layer_type' in found else \
+            cfg_mod.hot_path_config(found)
+        for k, v in self.cfg.items():
+            setattr(self.args, k, v)
+        if torch_home:
+            os.environ['TORCH_HOME'] = torch_home
+        # one process per GPU (infer.py:94-105 uses the same env:// rendezvous)
+        if num_gpus > 8:
+            raise RuntimeError("at most 8 GPUs per node")                          # infer.py:104-105 (bare raise there)
+        if num_gpus > 1:
+            self.rank, self.world = parallel.init_distributed()
+        else:
+            self.rank, self.world = 0, 1
+        self.device = torch.device("cuda", parallel.local_device_index())
+        torch.cuda.set_device(self.device)
+
+        self.model_checkpoint = pathlib.Path(project_dir) / folder / experiment_name / 'checkpoints' / model_file_name
+        self.model_dict = torch.load(self.model_checkpoint, map_location='cpu') if state_dict is None else state_dict
+        schema.check_state_dict(self.model_dict, self.cfg)        # strict: the reference's strict=False hides mismatches
+        self.hot_path = nets.HotPath(self.model_dict, self.cfg, self.device)
+        self.model = HipModel(self.hot_path, self.args)
+        if rank == 0 and print_params:
+            n = sum(v.numel() for k, v in self.model_dict.items() if k.startswith(schema.HOT_PATH_PREFIXES))
+            print(f'Number of hot-path parameters: {n}')
+        self.embedders = dict(embedders or {})
+
+        self.fixed_bounding_box = fixed_bounding_box
+        self.momentum = 0.01
+        self.center = None
+        self.size = None
+        self.pose_momentum = pose_momentum
+        self.theta = None
+        self.norm_momentum = 0.1
+        self.delta_yaw = None
+        self.delta_pitch = None
+        self.resize_warp = False
+        self.use_seg = bool(found.get('use_seg', False))
+        self.target_latent_volume = None
+        self._canonical_cl = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def _need(self, name, what):
+        fn = self.embedders.get(name)
+        if fn is None:
+            raise RuntimeError(
+                f"{what} needs the third-party '{name}' network, which is outside the MI355X hot path: pass it via "
+                f"InferenceWrapper(embedders={{'{name}': callable}}) or supply its output through the custome_* arguments")
+        return fn
+
+    def convert_to_tensor(self, image):
+        """infer.py:211-223: PIL / ndarray / tensor -> float tensor [B,3,H,W] in [0,1]"""
+        import numpy as np
+        if isinstance(image, torch.Tensor):
+            t = image.float()
+            return t[None] if t.dim() == 3 else t
+        if isinstance(image, (list, tuple)):
+            return torch.cat([self.convert_to_tensor(i) for i in image])
+        arr = np.asarray(image)
+        t = torch.from_numpy(arr.copy())
+        if t.dtype == torch.uint8:
+            t = t.float() / 255.0
+        t = t.float()
+        if t.dim() == 2:
+            t = t[..., None].expand(-1, -1, 3)
+        return t.permute(2, 0, 1)[None]
+
+    def _prepare_image(self, image):
+        S = self.cfg["image_size"]
+        t = self.convert_to_tensor(image)[:, :3]
+        if t.shape[-2:] != (S, S):
+            t = torch.nn.functional.interpolate(t, size=(S, S), mode='bicubic')    # infer.py:399-401 (host glue)
+        return t.to(self.device).contiguous()
+
+    def _theta_from(self, embed):
+        """(scale, rotation, translation) as the reference's custome_target_theta_embed (-> get_transform_matrix,
+        infer.py:565-566), or an already formed [B,4,4] theta tensor (extension)"""
+        if isinstance(embed, torch.Tensor):
+            return embed.to(self.device).float().contiguous(), None
+        srt = tuple(t.to(self.device).float().contiguous() for t in embed)
+        return ops.pose_theta(*srt), srt
+
+    def to_image(self, img_u8_hwc):
+        from PIL import Image
+        return Image.fromarray(img_u8_hwc)
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward(self, source_image=None, driver_image=None, source_mask=None, source_mask_add=0, driver_mask=None,
+                crop=True, reset_tracking=False, smooth_pose=False, hard_normalize=False, soft_normalize=False,
+                delta_yaw=None, delta_pitch=None, cloth=False, thetas_pass='', theta_n=0, target_theta=True,
+                mix=False, mix_old=True, c_source_latent_volume=None, c_target_latent_volume=None,
+                custome_target_pose_embed=None, custome_target_theta_embed=None, no_grad_infer=True,
+                modnet_mask=False, custome_source_pose_embed=None, custome_source_theta_embed=None,
+                custome_idt_embed=None):
+        self.no_grad_infer = no_grad_infer
+        self.target_theta = target_theta
+        with torch.no_grad():
+            if reset_tracking:
+                self.center = self.size = self.theta = self.delta_yaw = self.delta_pitch = None
+            self.mix, self.mix_old = mix, mix_old
+            if mix:
+                raise RuntimeError("mix=True (scipy polar mixing of source/driver pose, infer.py:686-736) is host glue "
+                                   "outside the hot path: compute the mixed theta and pass custome_target_theta_embed")
+            if delta_yaw is not None:
+                self.delta_yaw = delta_yaw
+            if delta_pitch is not None:
+                self.delta_pitch = delta_pitch
+            c, d, s = self.cfg["latent_volume_channels"], self.cfg["latent_volume_depth"], self.cfg["latent_volume_size"]
+
+            if source_image is not None:
+                if crop:
+                    source_img_crop = self._need('cropper', 'crop=True')(source_image).to(self.device)
+                else:
+                    source_img_crop = self._prepare_image(source_image)
+                self.source_image = source_image
+                self.source_image_crop = source_img_crop
+                if source_mask is not None:
+                    face_mask_source = source_mask.to(self.device).float()
+                elif 'face_parsing' in self.embedders:
+                    face_mask_source = (self.embedders['face_parsing'](source_img_crop) > 0.6).float()  # infer.py:408-411
+                else:
+                    raise RuntimeError("a source call needs source_mask= (or a 'face_parsing' embedder): the reference "
+                                       "masks the source with BiSeNet face parsing (infer.py:410-417)")
+                source_img_mask = face_mask_source
+                if modnet_mask:
+                    source_img_mask = self._need('matting', 'modnet_mask=True')(source_img_crop)
+                if source_mask_add:
+                    source_img_mask = source_img_mask.clamp(max=1, min=0)
+                source_img_crop = (source_img_crop * face_mask_source).float()
+                self.source_img_crop_m = source_img_crop
+                self.source_img_mask = source_img_mask
+                masked = (source_img_crop * source_img_mask).contiguous()
+                if custome_idt_embed is not None:
+                    self.idt_embed = custome_idt_embed.to(self.device).float().contiguous()
+                else:
+                    self.idt_embed = self._need('idt_embedder', 'a source call')(masked)               # infer.py:432
+                if custome_source_theta_embed is not None:
+                    pred_source_theta = self._theta_from(custome_source_theta_embed)[0]
+                else:
+                    pred_source_theta = self._need('head_pose_regressor', 'a source call')(source_img_crop)  # :437
+                self.pred_source_theta = pred_source_theta
+                if custome_source_pose_embed is not None:
+                    source_pose_embed = custome_source_pose_embed.to(self.device).float().contiguous()
+                else:
+                    source_pose_embed = self._need('expression_embedder', 'a source call')(source_img_crop, pred_source_theta)
+                self.pred_source_pose_embed = source_pose_embed
+                self.source_img = source_img_crop
+
+                hp = self.hot_path
+                source_latents = hp.local_encoder(masked)                                              # infer.py:433
+                emb = hp.embed(source_pose_embed, self.idt_embed)                                      # infer.py:459
+                delta_xy = hp.xy_generator(emb)                                                        # infer.py:462
+                vol = source_latents.view(1, c, d, s, s)
+                if self.cfg["source_volume_num_blocks"] > 0:
+                    vol = hp.volume_source(vol)                                                        # infer.py:490-491
+                self.source_latent_volume = vol if c_source_latent_volume is None else \
+                    c_source_latent_volume.to(self.device).float().contiguous()
+                inv = torch.linalg.inv(pred_source_theta.float().cpu()).to(self.device)                # infer.py:443
+                self.source_rotation_warp = inv
+                self.source_xy_warp_resize = delta_xy
+                rot = ops.grid_sample3d(self.source_latent_volume, theta=inv, padding_mode=hp.pad)     # infer.py:499-500
+                tv = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=hp.pad)
+                self.target_latent_volume_1 = tv if c_target_latent_volume is None else \
+                    c_target_latent_volume.to(self.device).float().contiguous()
+                self.target_latent_volume = hp.volume_process(self.target_latent_volume_1)             # infer.py:507
+                self._canonical_cl = hp.prepare_canonical(self.target_latent_volume)
+
+            if driver_image is None and custome_target_pose_embed is None:
+                return None                                                                            # infer.py:644-646
+            if self.target_latent_volume is None:
+                raise RuntimeError("call forward with a source_image first (no cached canonical volume)")
+
+            driver_img_crop = None
+            if driver_image is not None:
+                driver_img_crop = self._need('cropper', 'crop=True')(driver_image).to(self.device) if crop \
+                    else self._prepare_image(driver_image)
+            if custome_target_theta_embed is not None:                                                 # infer.py:565-566
+                pred_target_theta, self.pred_target_srt = self._theta_from(custome_target_theta_embed)
+            else:
+                pred_target_theta, *srt = self._need('head_pose_regressor', 'a driver call')(driver_img_crop, True)
+                self.pred_target_srt = tuple(srt)
+            if smooth_pose:                                                                            # infer.py:571-581
+                if self.theta is None:
+                    self.theta = pred_target_theta[0].clone()
+                sm = []
+                for i in range(pred_target_theta.shape[0]):
+                    self.theta = pred_target_theta[i] * self.pose_momentum + self.theta * (1 - self.pose_momentum)
+                    sm.append(self.theta.clone())
+                pred_target_theta = torch.stack(sm)
+            self.pred_target_theta = pred_target_theta
+            theta_used = pred_target_theta if target_theta else self.pred_source_theta.expand_as(pred_target_theta)
+            if custome_target_pose_embed is not None:                                                  # infer.py:603-604
+                target_pose_embed = custome_target_pose_embed.to(self.device).float().contiguous()
+            else:
+                target_pose_embed = self._need('expression_embedder', 'a driver call')(driver_img_crop, pred_target_theta)
+            self.target_pose_embed = target_pose_embed
+            B = target_pose_embed.shape[0]
+            if theta_used.shape[0] != B:
+                theta_used = theta_used.expand(B, -1, -1)
+            img = self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, target_pose_embed,
+                                            theta_used.float().contiguous())                          # infer.py:612-637
+            u8 = ops.pack_rgb8(img).cpu().numpy()                                                      # infer.py:641-643
+            return [self.to_image(u8[i]) for i in range(B)], img
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------------------------------------------
+    def animate(self, target_pose_embeds, target_srt, batch_size=16, as_uint8=True):
+        """1 source -> N driver frames (the BASELINE metric).  Frames are sharded contiguously across ranks
+        (SURVEY.md section 8e); each rank walks its shard in batches of `batch_size`.  Yields (first_frame_index, frames)
+        with frames a uint8 [B,H,W,3] (or fp32 [B,3,H,W]) DEVICE tensor -- no host sync inside the loop."""
+        if self._canonical_cl is None:
+            raise RuntimeError("call forward with a source_image first")
+        N = target_pose_embeds.shape[0]
+        lo, hi = parallel.shard_range(N, self.rank, self.world)
+        for b0 in range(lo, hi, batch_size):
+            b1 = min(b0 + batch_size, hi)
+            pose = target_pose_embeds[b0:b1].to(self.device).float().contiguous()
+            srt = [t[b0:b1].to(self.device).float().contiguous() for t in target_srt]
+            theta = ops.pose_theta(*srt)
+            img = self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, pose, theta)
+            yield b0, (ops.pack_rgb8(img) if as_uint8 else img)
+
+    def share_source(self, src_rank=0):
+        """RCCL broadcast of the per-identity cache computed on `src_rank`: canonical volume
+        (25 MB) + idt_embed (32 KB) + source theta."""
+        c, d, s = self.cfg["latent_volume_channels"], self.cfg["latent_volume_depth"], self.cfg["latent_volume_size"]
+        cache = parallel.broadcast_source_cache(
+            dict(canonical=self.target_latent_volume, idt_embed=getattr(self, 'idt_embed', None),
+                 theta_src=getattr(self, 'pred_source_theta', None)),
+            shapes=dict(canonical=(1, c, d, s, s), idt_embed=(1, self.cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4)),
+            src=src_rank, device=self.device, world=self.world, rank=self.rank)
+        self.target_latent_volume, self.idt_embed, self.pred_source_theta = cache["canonical"], cache["idt_embed"], cache["theta_src"]
+        self._canonical_cl = self.hot_path.prepare_canonical(self.target_latent_volume)

@@ -28,7 +28,10 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
            warp_generator_resnet.py:178) without materialising the grid.
     """
     lib = hip.load()
-    hip.require_cuda_f32(vol, grid, theta, delta)
+    hip.require_cuda_f32(vol, grid, delta)
+    if theta is not None:
+        theta = theta.float().contiguous()      # e.g. torch.linalg.inv returns a column-major result
+        hip.require_cuda_f32(theta)
     cl_in = in_layout == "ndhwc"
     cl_out = out_layout == "ndhwc"
     if cl_in:

@@ -1,0 +1,141 @@
+"""GPU tests of the drop-in boundary: InferenceWrapper with the reference's constructor / forward
+signature, fed from an args.txt + checkpoint on disk, checked against the golden outputs of the real reference."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return torch.load(os.path.join(golden_dir, "tiny_hotpath.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="module")
+def project(tmp_path_factory, tiny):
+    """<project>/<folder>/<exp>/args.txt (`key: value` lines as train.py:80-83 dumps them) + checkpoints/<file>"""
+    from emoportraits_amd import config
+    root = tmp_path_factory.mktemp("proj")
+    exp = root / "logs" / "exp"
+    (exp / "checkpoints").mkdir(parents=True)
+    cfg = config.hot_path_config(overrides=tiny["cfg"])
+    with open(exp / "args.txt", "wt") as f:
+        for k, v in cfg.items():
+            f.write(f"{k}: {v}\n")
+        f.write("experiment_name: exp\nuse_seg: True\n")
+    torch.save(tiny["state_dict"], exp / "checkpoints" / "model.pth")
+    return root
+
+
+def _wrapper(project, **kw):
+    from notebooks.infer import InferenceWrapper
+    return InferenceWrapper(experiment_name="exp", model_file_name="model.pth", project_dir=str(project), folder="logs",
+                            print_params=False, **kw)
+
+
+def test_source_then_driver_calls_match_reference_golden(project, tiny):
+    w = _wrapper(project)
+    S = tiny["cfg"]["image_size"]
+    # source call: returns None (driver_image is None), caches the canonical volume like the reference
+    r = w.forward(source_image=tiny["img"], crop=False, source_mask=torch.ones(1, 1, S, S),
+                  custome_idt_embed=tiny["idt_embed"], custome_source_pose_embed=tiny["source_pose_embed"],
+                  custome_source_theta_embed=tiny["theta_src"])
+    assert r is None
+    ref_c = tiny["source"]["canonical"]
+    assert w.target_latent_volume.shape == ref_c.shape
+    assert (w.target_latent_volume.cpu() - ref_c).abs().max().item() <= 1e-3 * ref_c.abs().max().item()
+    for attr in ("idt_embed", "source_latent_volume", "target_latent_volume", "pred_source_theta",
+                 "source_rotation_warp", "source_xy_warp_resize", "pred_source_pose_embed"):
+        assert getattr(w, attr) is not None
+    # driver-only call with the "emotion-driver" hooks (infer.py:565-566,603-604), one frame as the reference does
+    w.target_latent_volume = ref_c.to(w.device)                 # continue from the reference's volume
+    w._canonical_cl = w.hot_path.prepare_canonical(w.target_latent_volume)
+    for i in range(2):
+        imgs, t = w.forward(driver_image=None, crop=False, custome_target_pose_embed=tiny["target_pose_embed"][i:i + 1],
+                            custome_target_theta_embed=tiny["theta_drv"][i:i + 1])
+        assert len(imgs) == 1 and imgs[0].size == (S, S) and imgs[0].mode == "RGB"
+        ref = tiny["driver"][i]["img"]
+        assert t.shape == ref.shape
+        assert (t.cpu() - ref).abs().max().item() <= 1e-3
+        import numpy as np
+        want = ref[0].clamp(0, 1).mul(255).byte().permute(1, 2, 0).numpy()
+        assert np.abs(np.asarray(imgs[0]).astype(int) - want.astype(int)).max() <= 1
+        assert w.pred_target_theta.shape == (1, 4, 4) and w.target_pose_embed.shape[0] == 1
+    # batched extension: both frames in one call
+    imgs, t = w.forward(crop=False, custome_target_pose_embed=tiny["target_pose_embed"],
+                        custome_target_theta_embed=tiny["theta_drv"])
+    assert len(imgs) == 2 and t.shape[0] == 2
+
+
+def test_animate_streams_all_frames_in_order(project, tiny):
+    w = _wrapper(project)
+    S = tiny["cfg"]["image_size"]
+    w.forward(source_image=tiny["img"], crop=False, source_mask=torch.ones(1, 1, S, S),
+              custome_idt_embed=tiny["idt_embed"], custome_source_pose_embed=tiny["source_pose_embed"],
+              custome_source_theta_embed=tiny["theta_src"])
+    g = torch.Generator().manual_seed(0)
+    N = 7
+    pose = torch.randn(N, tiny["cfg"]["lpe_output_channels_expression"], generator=g)
+    srt = (1 + 0.05 * torch.randn(N, 3, generator=g), 0.3 * torch.randn(N, 3, generator=g), 0.05 * torch.randn(N, 3, generator=g))
+    seen = []
+    frames = {}
+    for b0, u8 in w.animate(pose, srt, batch_size=3):
+        assert u8.dtype == torch.uint8 and u8.shape[1:] == (S, S, 3)
+        seen.append((b0, u8.shape[0]))
+        for j in range(u8.shape[0]):
+            frames[b0 + j] = u8[j].cpu()
+    assert seen == [(0, 3), (3, 3), (6, 1)]
+    # frame 4 alone equals frame 4 of the stream
+    imgs, _ = w.forward(crop=False, custome_target_pose_embed=pose[4:5], custome_target_theta_embed=tuple(t[4:5] for t in srt))
+    import numpy as np
+    assert np.abs(np.asarray(imgs[0]).astype(int) - frames[4].numpy().astype(int)).max() <= 1
+
+
+def test_strict_checkpoint_loading_and_loud_failures(project, tiny):
+    bad = dict(tiny["state_dict"])
+    bad.pop("decoder_nw.res_decoder.1.block.0.weight_u")
+    with pytest.raises(KeyError, match="missing"):
+        _wrapper(project, state_dict=bad)
+    bad = dict(tiny["state_dict"])
+    bad["decoder_nw.res_decoder.0.weight_orig"] = torch.zeros(3, 3, 1, 1)
+    with pytest.raises(KeyError, match="shape mismatch"):
+        _wrapper(project, state_dict=bad)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _wrapper(project, use_gpu=False)
+    w = _wrapper(project)
+    with pytest.raises(RuntimeError, match="source_image first"):
+        w.forward(crop=False, custome_target_pose_embed=tiny["target_pose_embed"], custome_target_theta_embed=tiny["theta_drv"])
+    with pytest.raises(RuntimeError, match="cropper"):
+        w.forward(source_image=tiny["img"], crop=True)
+    with pytest.raises(RuntimeError, match="idt_embedder"):
+        w.forward(source_image=tiny["img"], crop=False, source_mask=torch.ones(1, 1, 64, 64))
+
+
+def test_model_attribute_seam(project, tiny):
+    """b2/b3: the reference reaches into self.model.<net>; the operator seam grid_sample(inputs, grid) is NCDHW"""
+    import torch.nn.functional as F
+    w = _wrapper(project)
+    m = w.model
+    c, d, s = (tiny["cfg"][k] for k in ("latent_volume_channels", "latent_volume_depth", "latent_volume_size"))
+    g = torch.Generator().manual_seed(2)
+    vol = torch.randn(1, c, d, s, s, generator=g)
+    grid = torch.rand(1, d, s, s, 3, generator=g) * 2.2 - 1.1
+    got = m.grid_sample(vol.to(w.device), grid.to(w.device))
+    assert torch.equal(got.cpu(), F.grid_sample(vol, grid, padding_mode="zeros", align_corners=False))
+    assert m.identity_grid_3d.shape == (1, d * s * s, 4)
+    dd = {"idt_embed": tiny["idt_embed"].to(w.device), "source_pose_embed": tiny["source_pose_embed"].to(w.device),
+          "target_pose_embed": tiny["target_pose_embed"][:1].to(w.device)}
+    src_e, tgt_e, _, embed_dict = m.predict_embed(dd)
+    assert embed_dict == {} and tgt_e["orig"].shape == tiny["driver"][0]["warp_embed"].shape
+    warp, delta = m.uv_generator_nw(tgt_e)
+    assert warp.shape == (1, d, s, s, 3) and delta.shape == (1, 3, d, s, s)
+    assert (warp.cpu() - tiny["driver"][0]["uv_warp"]).abs().max().item() <= 2e-4
+    feat = torch.randn(1, c * d, s, s, generator=g).to(w.device)
+    img, seg, deep_f, img_f = m.decoder_nw({}, {}, feat, False, stage_two=True)
+    assert seg is None and img.shape[1] == 3 and deep_f is not None and img_f is not None
