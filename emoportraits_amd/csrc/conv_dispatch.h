@@ -18,9 +18,11 @@ typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 #define CONV_FOR_SHAPE(KH, KW, KC, TM, TP, WGM, WGP, shape, ups)                                              \
   ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 1, 128, TM, TP, WGM, WGP, true>          \
                                   : &conv_igemm_launch<KH, KW, KC, 1, 1, 128, TM, TP, WGM, WGP, false>)        \
+   : (shape) == SHAPE_W64 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 2, 64, TM, TP, WGM, WGP, true>          \
+                                   : &conv_igemm_launch<KH, KW, KC, 1, 2, 64, TM, TP, WGM, WGP, false>)        \
+   : (shape) == SHAPE_W32 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 4, 32, TM, TP, WGM, WGP, true>          \
+                                   : &conv_igemm_launch<KH, KW, KC, 1, 4, 32, TM, TP, WGM, WGP, false>)        \
    : (ups)               ? (conv_launch_fn) nullptr                                                            \
-   : (shape) == SHAPE_W64 ? &conv_igemm_launch<KH, KW, KC, 1, 2, 64, TM, TP, WGM, WGP, false>                 \
-   : (shape) == SHAPE_W32 ? &conv_igemm_launch<KH, KW, KC, 1, 4, 32, TM, TP, WGM, WGP, false>                 \
    : (shape) == SHAPE_W16 ? &conv_igemm_launch<KH, KW, KC, 1, 8, 16, TM, TP, WGM, WGP, false>                 \
    : (shape) == SHAPE_W8  ? &conv_igemm_launch<KH, KW, KC, 2, 8, 8, TM, TP, WGM, WGP, false>                  \
                           : (conv_launch_fn) nullptr)
