@@ -57,6 +57,20 @@ def _compile(src):
     return obj, True
 
 
+def build_variant(name, defines):
+    """A/B build of the whole library with extra -D flags into lib/libemoportraits_hip_<name>.so (measurement only;
+    selected at run time with EMO_HIP_LIB=<path>)."""
+    global FLAGS, OBJDIR, LIB
+    saved = (FLAGS, OBJDIR, LIB)
+    try:
+        FLAGS = FLAGS + ["-D" + d for d in defines]
+        OBJDIR = os.path.join(LIBDIR, "obj_" + name)
+        LIB = os.path.join(LIBDIR, f"libemoportraits_hip_{name}.so")
+        return build(force=False, verbose=True)
+    finally:
+        FLAGS, OBJDIR, LIB = saved
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sources()
@@ -80,4 +94,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    else:
+        build(force="--force" in sys.argv)

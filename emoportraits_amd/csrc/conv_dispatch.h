@@ -11,7 +11,9 @@ enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, N_CFGS = 3 };
 typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 
 
+#ifndef EMO_CONV_KC_3X3
 #define EMO_CONV_KC_3X3 4
+#endif
 #define EMO_CONV_KC_1X1 16   /* 32 measured slower (64 KiB+ LDS, 163 VGPR: 67 vs 73 TF on 1536->512 @64^2) */
 #define EMO_CONV_KC_1X7 4
 

@@ -218,12 +218,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     // prefetch the next stage while this one computes; on the last stage the (clamped) prefetch re-reads the
     // last stage and its LDS write lands in the idle buffer -- harmless, and it keeps the loop branch-free
     const int stn = (st + 1) < nstages ? (st + 1) : st;
-    EMO_ISSUE_LOADS(stn);
+#ifndef EMO_CONV_ABLATE
+#define EMO_CONV_ABLATE 0   /* timing experiments only: 1 = no global loads / LDS stores in the loop, 2 = also no barrier,
+                               3 = MFMA stream only (operands read once) -- results are WRONG for any value != 0 */
+#endif
+    if (EMO_CONV_ABLATE == 0) { EMO_ISSUE_LOADS(stn); }
 
     const float* As = cur;
     const float* Ps = cur + ASZ;
+#ifndef EMO_CONV_STORE_AT
+#define EMO_CONV_STORE_AT 1   /* 0: write the next stage into LDS after all MFMAs of this stage; 1: after half of them */
+#endif
+    constexpr int STORE_PAIR = EMO_CONV_STORE_AT ? (KC / 4) : -1;   // the idle LDS buffer is free for the whole stage
 #pragma unroll
     for (int pair = 0; pair < KC / 2; ++pair) {
+      if (pair == STORE_PAIR && STORE_PAIR > 0 && EMO_CONV_ABLATE == 0) {
+        // mid-stage: the prefetched tile goes to the other buffer while the second half of the MFMAs still runs,
+        // so only the barrier (not load-wait + LDS stores + barrier) separates two stages' MFMA streams
+        EMO_STORE_STAGE(stn, nxt);
+      }
 #pragma unroll
       for (int r = 0; r < KH; ++r) {
 #pragma unroll
@@ -231,9 +244,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           const int tap = r * KW + s;
           float av_[TM], bv_[TP];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) av_[i] = As[a_base + ((pair * TAPS + tap) * 2) * BM + i * 32];
+          for (int i = 0; i < TM; ++i)
+            av_[i] = As[a_base + (EMO_CONV_ABLATE == 3 ? 0 : ((pair * TAPS + tap) * 2) * BM) + i * 32];
 #pragma unroll
-          for (int j = 0; j < TP; ++j) bv_[j] = Ps[b_base[j] + (pair * 2) * CHS + r * PW + s];
+          for (int j = 0; j < TP; ++j)
+            bv_[j] = Ps[b_base[j] + (EMO_CONV_ABLATE == 3 ? 0 : (pair * 2) * CHS + r * PW + s)];
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -242,8 +257,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         }
       }
     }
-    EMO_STORE_STAGE(stn, nxt);
-    __syncthreads();
+    if (STORE_PAIR <= 0 && EMO_CONV_ABLATE == 0) {
+      EMO_STORE_STAGE(stn, nxt);
+    }
+    if (EMO_CONV_ABLATE < 2) __syncthreads();
   }
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----

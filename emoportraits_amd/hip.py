@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libemoportraits_hip.so")
+# EMO_HIP_LIB selects an alternative build of the same library (A/B measurements of kernel variants only)
+LIB_PATH = os.environ.get("EMO_HIP_LIB") or os.path.join(_HERE, "lib", "libemoportraits_hip.so")
 
 PAD_MODES = {"zeros": 0, "border": 1, "reflection": 2}
 LAYOUT_NCDHW, LAYOUT_NDHWC = 0, 1

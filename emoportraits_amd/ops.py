@@ -175,7 +175,7 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
     elif tuple(out.shape) != shape:
         raise ValueError("bad out shape")
     if res is not None:
-        want = (N, layer.cout, D, H, W) if res_ups else (N, layer.cout, D, Hl, Wl)
+        want = (N, layer.cout, D, Hl // 2, Wl // 2) if res_ups else (N, layer.cout, D, Hl, Wl)
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
             raise ValueError("bad residual shape")
     cfg = layer.cfg_for(N * D * Hl * Wl // 128)
