@@ -57,11 +57,13 @@ struct ConvCfg {
   static constexpr int PATCH = KC * CHS;
   static constexpr int ASZ = KLOC * BM;             // floats of one stage's weight tile
   static constexpr int BUF = ASZ + ((PATCH + 3) & ~3);
-  static constexpr int NPE = (PATCH + 255) / 256;   // patch elements per thread
+  static constexpr int CPW = KC / 4;                // channels staged per wave per stage (4 waves)
+  static constexpr int EPC = (CHS + 63) / 64;       // patch elements per lane per channel
+  static constexpr int NPE = CPW * EPC;             // patch elements per thread per stage
   static constexpr int NA4 = (ASZ / 4 + 255) / 256; // float4 weight loads per thread
   static_assert(WGM * WGP == 4, "4 waves per block");
   static_assert(TZ * TR * TW == BP, "position tile must equal BP");
-  static_assert(KC % 2 == 0, "channels are consumed in pairs");
+  static_assert(KC % 4 == 0, "one input channel per wave and stage group");
   static_assert(ASZ % 4 == 0, "weight tile must be float4-copyable");
   static_assert(TM * TP <= 4, "accumulator budget");
 };
@@ -80,11 +82,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int PATCH = Cfg::PATCH, ASZ = Cfg::ASZ, BUF = Cfg::BUF, NPE = Cfg::NPE, NA4 = Cfg::NA4;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_scale = smem + 2 * BUF;          // [Cin] (only when a.scale)
-  float* s_shift = s_scale + a.Cin;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  // wave id as a scalar (SGPR): everything derived from it (staged channel, base pointers, GN scale/shift) is then
+  // wave-uniform and handled by the scalar unit instead of costing VALU issue slots next to the MFMA stream
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
   const int wm = wave / WGP, wp = wave % WGP;
   const int m0 = wm * TM * 32, p0 = wp * TP * 32;
@@ -103,86 +106,117 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const bool has_affine = a.scale != nullptr;
   const bool relu_in = a.relu_in != 0;
   const int padD = a.KD >> 1;
+  const float* scale_n = has_affine ? a.scale + (long)n * a.Cin : nullptr;
+  const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : nullptr;
 
-  if (has_affine) {
-    for (int c = tid; c < a.Cin; c += 256) {
-      s_scale[c] = a.scale[(long)n * a.Cin + c];
-      s_shift[c] = a.shift[(long)n * a.Cin + c];
-    }
-  }
-
-  // ---- per-thread description of the patch elements this thread stages (constant over stages) ----
-  int p_goff[NPE];     // ci*DHW + ys*W + xs   (z term added per stage)
-  int p_ci[NPE];       // channel within the chunk
-  int p_pz[NPE];       // z within the tile
-  bool p_ok[NPE];      // (y, x) inside the logical image and element index inside the patch
+  // ---- patch staging map: wave w stages input channels {w, w+4, ...} of the chunk; lane l element l + 64*i of the
+  //      channel's [TZ][PR][PW] patch.  Per element only a plane offset and a validity bit are kept (constant over
+  //      stages); the channel / depth part of the address is a scalar base per stage. ----
+  constexpr int CPW = Cfg::CPW, EPC = Cfg::EPC;
+  unsigned p_off[EPC]; // BYTE offset (ys*W + xs)*4 inside an input plane (0 when the element is outside the image);
+                       // unsigned 32-bit so that loads take the scalar-base + vector-offset addressing form
+  int p_pz[EPC];       // z within the tile (non-zero only for TZ > 1)
+  bool p_ok[EPC];      // element exists and its (y, x) lies inside the logical image
 #pragma unroll
-  for (int i = 0; i < NPE; ++i) {
-    const int e = tid + i * 256;
-    const int ci = e / CHS;
-    const int rem = e - ci * CHS;
-    const int pz = rem / (PR * PW);
-    const int rem2 = rem - pz * (PR * PW);
+  for (int i = 0; i < EPC; ++i) {
+    const int e = lane + i * 64;
+    const int pz = e / (PR * PW);
+    const int rem2 = e - pz * (PR * PW);
     const int pr = rem2 / PW;
     const int pc = rem2 - pr * PW;
     const int yl = y0 + pr - (KH >> 1);
     const int xl = x0 + pc - (KW >> 1);
-    p_ok[i] = (e < PATCH) && ((unsigned)yl < (unsigned)a.Hl) && ((unsigned)xl < (unsigned)a.Wl);
+    const bool ok = (e < CHS) && ((unsigned)yl < (unsigned)a.Hl) && ((unsigned)xl < (unsigned)a.Wl);
     const int ys = UPS ? (yl >> 1) : yl;
     const int xs = UPS ? (xl >> 1) : xl;
-    p_goff[i] = (int)(ci * DHW) + ys * a.W + xs;
-    p_ci[i] = ci;
+    p_ok[i] = ok;
+    p_off[i] = ok ? (unsigned)(ys * a.W + xs) * 4u : 0u;
     p_pz[i] = pz;
   }
 
   const int nstages = a.n_cchunks * a.KD;
   const float4* wsrc = reinterpret_cast<const float4*>(a.wpk) + ((long)cotile * nstages) * (ASZ / 4);
 
-  float pv[NPE];
-  bool pvok[NPE];
+  float pv[NPE];        // staged patch values (raw)
+  bool pvz[NPE];        // per-element depth validity (only varies per element when TZ > 1)
+  bool sv[CPW];         // wave-uniform: channel exists (and, for TZ == 1, the depth slice is inside the volume)
+  float sc[CPW], sh[CPW];
   float4 av[NA4];
+#ifndef EMO_CONV_GLDS_A
+#define EMO_CONV_GLDS_A 0   /* 0: weight tile through VGPRs + ds_write_b128; 1: by LDS-DMA (global_load_lds).  Measured on
+                               MI355X: 0 is 1 % faster end to end and 5-8 % faster on the 64-row block config */
+#endif
+  constexpr int NGL = (ASZ * 4 + 4095) / 4096;   // 1-KiB LDS-DMA pieces per wave
 
 // Both staging halves are macros (not lambdas / conditionals) so that pv[] / av[] are unconditionally defined
 // straight-line values and stay in VGPRs (a conditional or lambda-captured definition sent them to scratch).
-#define EMO_ISSUE_LOADS(stage_)                                                                       \
+#define EMO_ISSUE_LOADS(stage_, dst_)                                                                 \
   {                                                                                                   \
     const int cc_ = (stage_) / a.KD;                                                                  \
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
     const int ci0_ = cc_ * KC;                                                                        \
-    const float* xc_ = xn + (long)ci0_ * DHW;                                                         \
-    _Pragma("unroll") for (int i = 0; i < NPE; ++i) {                                                 \
-      const int zi = z0 + p_pz[i] + t_ - padD;                                                        \
-      const bool ok = p_ok[i] && ((unsigned)zi < (unsigned)a.D) && (ci0_ + p_ci[i] < a.Cin);          \
-      pvok[i] = ok;                                                                                   \
-      pv[i] = ok ? xc_[p_goff[i] + zi * HW] : 0.0f;                                                   \
+    _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
+      const int c_ = ci0_ + g * 4 + wave;                                                             \
+      const bool cv_ = c_ < a.Cin;                                                                    \
+      const int cs_ = cv_ ? c_ : 0;                                                                   \
+      const int zu_ = z0 + t_ - padD;           /* depth of tile slice 0 */                           \
+      const bool zv_ = (unsigned)zu_ < (unsigned)a.D;                                                 \
+      const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;            \
+      sv[g] = cv_ && (TZ > 1 || zv_);                                                                 \
+      if (has_affine) { sc[g] = scale_n[cs_]; sh[g] = shift_n[cs_]; }                                 \
+      _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
+        if (TZ == 1) {                                                                                \
+          pvz[g * EPC + i] = true;                                                                    \
+          pv[g * EPC + i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + p_off[i]); \
+        } else {                                                                                      \
+          const int zi = zu_ + p_pz[i];                                                               \
+          const bool zok = (unsigned)zi < (unsigned)a.D;                                              \
+          pvz[g * EPC + i] = zok;                                                                     \
+          pv[g * EPC + i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + (p_off[i] + (unsigned)((zok ? zi : 0) * HW) * 4u)); \
+        }                                                                                             \
+      }                                                                                               \
     }                                                                                                 \
     const float4* ws_ = wsrc + (long)(stage_) * (ASZ / 4);                                            \
-    _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                 \
-      const int idx = tid + i * 256;                                                                  \
-      av[i] = ws_[idx < ASZ / 4 ? idx : ASZ / 4 - 1];                                                 \
+    if (EMO_CONV_GLDS_A) {                                                                            \
+      /* weight tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), no VGPR round trip. */ \
+      /* The LDS image is lane-linear = exactly the packed weight order.                               */ \
+      _Pragma("unroll") for (int i = 0; i < NGL; ++i) {                                               \
+        const int j = wave + 4 * i;                                                                   \
+        const int boff = j * 1024 + lane * 16;                                                        \
+        if (boff < ASZ * 4)                                                                           \
+          __builtin_amdgcn_global_load_lds(                                                           \
+              (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(ws_) + boff), \
+              (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(dst_) + j * 1024), 16, 0, 0); \
+      }                                                                                               \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                               \
+        const int idx = tid + i * 256;                                                                \
+        av[i] = ws_[idx < ASZ / 4 ? idx : ASZ / 4 - 1];                                               \
+      }                                                                                               \
     }                                                                                                 \
   }
 
 #define EMO_STORE_STAGE(stage_, buf_)                                                                 \
   {                                                                                                   \
-    const int ci0_ = ((stage_) / a.KD) * KC;                                                          \
-    float4* As4_ = reinterpret_cast<float4*>(buf_);                                                   \
-    _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                 \
-      const int idx = tid + i * 256;                                                                  \
-      if (idx < ASZ / 4) As4_[idx] = av[i];                                                           \
+    if (!EMO_CONV_GLDS_A) {                                                                           \
+      float4* As4_ = reinterpret_cast<float4*>(buf_);                                                 \
+      _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                               \
+        const int idx = tid + i * 256;                                                                \
+        if (idx < ASZ / 4) As4_[idx] = av[i];                                                         \
+      }                                                                                               \
     }                                                                                                 \
     float* Ps_ = (buf_) + ASZ;                                                                        \
-    _Pragma("unroll") for (int i = 0; i < NPE; ++i) {                                                 \
-      const int e = tid + i * 256;                                                                    \
-      if (e < PATCH) {                                                                                \
-        float v = pv[i];                                                                              \
-        if (has_affine) {                                                                             \
-          const int c = ci0_ + p_ci[i];                                                               \
-          const int cs = c < a.Cin ? c : 0;                                                           \
-          v = __fmaf_rn(v, s_scale[cs], s_shift[cs]);                                                 \
+    _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
+      float* Pc_ = Ps_ + (g * 4 + wave) * CHS;                                                        \
+      _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
+        const int e = lane + i * 64;                                                                  \
+        if (e < CHS) {                                                                                \
+          float v = pv[g * EPC + i];                                                                  \
+          if (has_affine) v = __fmaf_rn(v, sc[g], sh[g]);                                             \
+          if (relu_in) v = fmaxf(v, 0.0f);                                                            \
+          /* zero padding applies to the transformed tensor */                                        \
+          Pc_[e] = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                 \
         }                                                                                             \
-        if (relu_in) v = fmaxf(v, 0.0f);                                                              \
-        Ps_[e] = pvok[i] ? v : 0.0f; /* zero padding applies to the transformed tensor */            \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -207,8 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     b_base[j] = half * CHS + pz * (PR * PW) + row * PW + col;
   }
 
-  __syncthreads();                 // s_scale / s_shift visible
-  EMO_ISSUE_LOADS(0);
+  EMO_ISSUE_LOADS(0, smem);
   EMO_STORE_STAGE(0, smem);
   __syncthreads();
 
@@ -222,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #define EMO_CONV_ABLATE 0   /* timing experiments only: 1 = no global loads / LDS stores in the loop, 2 = also no barrier,
                                3 = MFMA stream only (operands read once) -- results are WRONG for any value != 0 */
 #endif
-    if (EMO_CONV_ABLATE == 0) { EMO_ISSUE_LOADS(stn); }
+    if (EMO_CONV_ABLATE == 0) { EMO_ISSUE_LOADS(stn, nxt); }
 
     const float* As = cur;
     const float* Ps = cur + ASZ;
@@ -313,7 +346,7 @@ int conv_igemm_launch(ConvArgs a, hipStream_t s) {
   const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
   if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
-  const size_t lds = (size_t)(2 * Cfg::BUF + (a.scale ? 2 * a.Cin : 0)) * sizeof(float);
+  const size_t lds = (size_t)(2 * Cfg::BUF) * sizeof(float);
   if (lds > 160 * 1024) return EMO_ERR_UNSUPPORTED;
   auto kern = conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   if (lds > 64 * 1024) {
