@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=16, help="driver frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-source-pass", action="store_true",
+                    help="profiling aid: use a synthetic canonical volume instead of running the source pass, so that "
+                         "a rocprofv3 trace of this command contains driver-pass launches only")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
 
@@ -150,7 +153,7 @@ def main():
 
     cfg = config.hot_path_config(overrides={"image_size": a.image_size})
     sd = random_init.random_state_dict(cfg, seed=a.seed)
-    hp = nets.HotPath(sd, cfg, dev, with_source=(rank == 0))
+    hp = nets.HotPath(sd, cfg, dev, with_source=(rank == 0 and not a.no_source_pass))
     c, d, s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
     S, B = a.image_size, a.batch
 
@@ -159,7 +162,10 @@ def main():
     idt_cpu = torch.randn(1, cfg["gen_max_channels"], 4, 4, generator=g)
     cache = {"canonical": None, "idt_embed": None, "theta_src": None}
     source_ms = None
-    if rank == 0:
+    if rank == 0 and a.no_source_pass:
+        cache = {"canonical": torch.randn(1, c, d, s, s, generator=g).to(dev), "idt_embed": idt_cpu.to(dev),
+                 "theta_src": torch.eye(4)[None].to(dev)}
+    elif rank == 0:
         img = torch.rand(1, 3, S, S, generator=g).to(dev)
         pose_s = torch.randn(1, cfg["lpe_output_channels_expression"], generator=g).to(dev)
         srt_s = [t.to(dev) for t in (1 + 0.05 * torch.randn(1, 3, generator=g), 0.3 * torch.randn(1, 3, generator=g),
@@ -214,8 +220,9 @@ def main():
     conv_tflops = conv_meter.flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     samp_gbps = samp_meter.bytes / (samp_ms * 1e-3) / 1e9 if samp_ms > 0 else 0.0
     pmc = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_conv_traffic.json")
-    if os.path.exists(pmc_path):
+    pmc_path = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_traffic.json")))[-1:]
+    pmc_path = pmc_path[0] if pmc_path else ""
+    if pmc_path and os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:

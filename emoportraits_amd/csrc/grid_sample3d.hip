@@ -311,11 +311,23 @@ __device__ __forceinline__ void block_to_work(int b, int total, int bps, int nsl
   const int xcd = b & 7, idx = b >> 3;
   const int spx = (total / bps) >> 3;          // samples per XCD
   const int bpz = bps / nslices;               // blocks per z-slice of one sample
-  const int z = idx / (spx * bpz);
-  const int rem = idx - z * (spx * bpz);
-  const int j = rem / bpz;
-  n = xcd * spx + j;
-  blk = z * bpz + (rem - j * bpz);
+  if (ORDER == 2) {
+    const int z = idx / (spx * bpz);
+    const int rem = idx - z * (spx * bpz);
+    const int j = rem / bpz;
+    n = xcd * spx + j;
+    blk = z * bpz + (rem - j * bpz);
+  } else {
+    // ORDER 3: (z-slice, group of 8 blocks, sample, block in group): the group's corner rows (a few hundred KB of the
+    // shared volume) stay in L2 while all of the XCD's samples pass over them
+    constexpr int G = 8;
+    const int per_group = spx * G;
+    const int grp = idx / per_group;            // global group index = z * (bpz / G) + row group
+    const int rem = idx - grp * per_group;
+    const int j = rem / G;
+    n = xcd * spx + j;
+    blk = grp * G + (rem - j * G);
+  }
 }
 
 template <int PAD, int MODE, int VPB>
@@ -449,7 +461,7 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
   const int bps = emo_cdiv(nvox, VPB);
   const long total = (long)bps * N;
   if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  if (ORDER == 2 && ((N & 7) || (bps % Do) || (nvox % VPB)))     // z-slice-major order needs whole slices and N % 8 == 0
+  if (ORDER >= 2 && ((N & 7) || (bps % Do) || (nvox % VPB) || ((bps / Do) % 8)))   // needs whole slices / groups, N % 8 == 0
     return launch_cl_v2<PAD, MODE, VPB, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
                                            vol_bstride, out_cl, s);
   if (out_cl) {
@@ -481,6 +493,7 @@ int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, cons
     case 6: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, 1);
     case 7: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, 0);
     case 8: EMO_CLV2(64, 2);
+    case 9: EMO_CLV2(64, 3);
     default: return EMO_ERR_BAD_ARG;
   }
 #undef EMO_CLV2

@@ -16,6 +16,11 @@ import torch.distributed as dist
 
 
 def local_device_index():
+    """GPU of this process: LOCAL_RANK (one process per GPU).  EMO_FORCE_DEVICE overrides it -- a test hook that lets
+    a world_size-2 run share the single GPU of a test box (with EMO_DIST_BACKEND=gloo; RCCL refuses two ranks per GPU)."""
+    forced = os.environ.get("EMO_FORCE_DEVICE")
+    if forced is not None:
+        return int(forced)
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
@@ -26,7 +31,7 @@ def init_distributed(backend=None):
         return 0, 1
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
+            backend = os.environ.get("EMO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

@@ -1,0 +1,114 @@
+"""CPU tests of the host-side logic around the kernels: config contract, checkpoint schema, SN/WS folding, weight packing."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import restate as O  # noqa: E402
+
+from emoportraits_amd import config, pack, random_init, schema  # noqa: E402
+
+
+def test_released_config_matches_the_oracle_and_is_validated():
+    cfg = config.hot_path_config()
+    assert {k: cfg[k] for k in O.RELEASED_CFG} == O.RELEASED_CFG
+    with pytest.raises(ValueError, match="norm_layer_type"):
+        config.hot_path_config(overrides={"norm_layer_type": "bn"})
+    with pytest.raises(ValueError, match="use_back"):
+        config.hot_path_config(overrides={"use_back": True})
+    with pytest.raises(ValueError, match="resize_warp"):
+        config.hot_path_config(overrides={"warp_output_size": 128})
+
+
+def test_args_txt_both_formats(tmp_path):
+    # `key: value` dump (train.py:80-83 / utils/args.py:34-65 type sniffing)
+    p = tmp_path / "args.txt"
+    p.write_text("image_size: 256\nnorm_layer_type: gn\nuse_ws: True\nuse_sn: True\nenc_channel_mult: 4.0\n"
+                 "experiment_name: foo: bar\nuse_back: False\n")
+    found = config.parse_args_txt(p)
+    assert found["image_size"] == 256 and found["use_ws"] is True and found["enc_channel_mult"] == 4.0
+    assert found["experiment_name"] == "foo: bar" and found["use_back"] is False
+    # launch-command form (experiments/args.txt of the reference)
+    q = tmp_path / "cmd.txt"
+    q.write_text("python3 -m torch.distributed.launch --nproc_per_node=8 ../train.py --image_size 512 --norm_layer_type gn "
+                 "--use_ws True --dec_channel_mult 2 --im_dec_ch_div_factor 1.5 --use_back False")
+    found = config.parse_args_txt(q)
+    assert found["image_size"] == 512 and found["use_ws"] is True and found["im_dec_ch_div_factor"] == 1.5
+    cfg = config.hot_path_config(found)
+    assert cfg["image_size"] == 512 and cfg["dec_channel_mult"] == 2.0
+
+
+def test_schema_matches_golden_reference_state_dict(golden_dir):
+    tiny = torch.load(os.path.join(golden_dir, "tiny_hotpath.pt"), weights_only=False)
+    cfg = config.hot_path_config(overrides=tiny["cfg"])
+    want = schema.hot_path_schema(cfg)
+    got = {k: tuple(v.shape) for k, v in tiny["state_dict"].items()}
+    assert want == got
+    sd = dict(tiny["state_dict"])
+    sd["decoder_nw.extra.weight"] = torch.zeros(1)
+    with pytest.raises(KeyError, match="unexpected"):
+        schema.check_state_dict(sd, cfg)
+    # a 512-px checkpoint does not load into a 256-px model (layer names embed the resolution)
+    cfg256 = config.hot_path_config(overrides={"image_size": 256})
+    cfg512 = config.hot_path_config(overrides={"image_size": 512})
+    k512 = set(schema.hot_path_schema(cfg512))
+    assert "local_encoder_nw.from_rgb_512px.weight_orig" in k512
+    with pytest.raises(KeyError):
+        schema.check_state_dict({k: torch.zeros(s) for k, s in schema.hot_path_schema(cfg512).items()}, cfg256)
+
+
+def test_random_state_dict_is_schema_complete_and_trained_like():
+    cfg = config.hot_path_config(overrides={"image_size": 256})
+    sd = random_init.random_state_dict(cfg, seed=1, with_source=False)
+    assert schema.check_state_dict(sd, cfg, with_source=False)
+    # u, v at the dominant singular pair => folded weight has spectral norm ~1
+    w = pack.fold_sn(sd["decoder_nw.res_decoder.1.block.0.weight_orig"], sd["decoder_nw.res_decoder.1.block.0.weight_u"],
+                     sd["decoder_nw.res_decoder.1.block.0.weight_v"])
+    s = torch.linalg.svdvals(w.reshape(w.shape[0], -1))[0].item()
+    assert 0.9 < s < 1.2
+
+
+def test_folding_equals_the_oracle_restatement(golden_dir):
+    tiny = torch.load(os.path.join(golden_dir, "tiny_hotpath.pt"), weights_only=False)
+    sd = tiny["state_dict"]
+    p = "decoder_nw.res_decoder.1.block.0"
+    assert torch.equal(pack.folded_conv(sd, p, "sn")[0], O.sn_weight(sd, p))
+    p = "decoder_nw.res_decoder.1.block_feats.2"
+    assert torch.equal(pack.folded_conv(sd, p, "ws")[0], O.ws_weight(sd[p + ".weight"]))
+
+
+@pytest.mark.parametrize("cfg_id", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(5, 6, 3, 3), (40, 9, 3, 3, 3), (33, 20, 1, 1), (130, 3, 7, 1, 7)])
+def test_pack_weight_layout(cfg_id, shape):
+    """every weight element lands at [co_tile][chunk][kd][pair][tap][half][BM] and padding is zero"""
+    if shape[-1] == 7 and cfg_id == 2:
+        pytest.skip("1x7 taps have no 32-row config")
+    w = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    flat = pack.pack_weight(w, cfg_id)
+    w5 = w if w.dim() == 5 else w.unsqueeze(2)
+    cout, cin, kd, kh, kw = w5.shape
+    bm, kc = pack.conv_pack_info(kh, kw, cfg_id)
+    ncc = -(-cin // kc)
+    taps = kh * kw
+    assert flat.numel() == (-(-cout // bm)) * bm * ncc * kc * kd * taps
+    assert abs(flat.abs().sum().item() - w.abs().sum().item()) < 1e-3 * w.abs().sum().item()
+    g = torch.Generator().manual_seed(1)
+    for _ in range(50):
+        co, ci = int(torch.randint(cout, (1,), generator=g)), int(torch.randint(cin, (1,), generator=g))
+        t, tap = int(torch.randint(kd, (1,), generator=g)), int(torch.randint(taps, (1,), generator=g))
+        cot, i = divmod(co, bm)
+        cc, cl = divmod(ci, kc)
+        pair, half = divmod(cl, 2)
+        idx = (((((cot * ncc + cc) * kd + t) * (kc // 2) + pair) * taps + tap) * 2 + half) * bm + i
+        assert flat[idx].item() == w5[co, ci, t, tap // kw, tap % kw].item()
+
+
+def test_launch_config_heuristic():
+    assert pack.choose_cfg(512) == pack.CFG_A and pack.choose_cfg(320) == pack.CFG_B and pack.choose_cfg(3) == pack.CFG_C
+    # few position tiles: prefer more (smaller) blocks; many: least padding wins
+    assert pack.choose_cfg_for_launch(256, 16) == pack.CFG_C
+    assert pack.choose_cfg_for_launch(320, 4096) == pack.CFG_B
+    assert pack.choose_cfg_for_launch(128, 32768) == pack.CFG_A

@@ -55,7 +55,7 @@ def main():
         for cpb in (4, 8, 12, 16, 24, 32, 48, 96):
             cases.append((f"uv/ncdhw/cpb{cpb}", lambda cpb=cpb: ops.grid_sample3d(vol, warp, variant=cpb, out=out_nc), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("uv/cl", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), vol_bytes / N + grid_bytes + vol_bytes))
-        for var in (3, 8):
+        for var in (3, 8, 9):
             cases.append((f"uv/cl_var{var}", lambda var=var: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=var), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("uv/cl_v1", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=1), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("uv/cl2ncdhw", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ncdhw", out=out_nc), vol_bytes / N + grid_bytes + vol_bytes))
@@ -68,7 +68,7 @@ def main():
         inN_cl = torch.randn(N, D, S, S, C, device=DEV)
         inN_nc = torch.randn(N, C, D, S, S, device=DEV)
         cases.append(("rot_theta_unshared/ncdhw/cpb8", lambda: ops.grid_sample3d(inN_nc, theta=theta, variant=8, out=out_nc), 2 * vol_bytes))
-        for var in (3, 8):
+        for var in (3, 9):
             cases.append((f"rot_theta_unshared/cl2ncdhw_var{var}", lambda var=var: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc, variant=var), 2 * vol_bytes))
         cases.append(("rot_theta_unshared/cl2ncdhw_v1", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc, variant=1), 2 * vol_bytes))
         cases.append(("rot_theta_unshared/cl2ncdhw", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc), 2 * vol_bytes))

@@ -1,0 +1,36 @@
+"""Copies the summaries of the last GPU run from gpurun_out/ (scratch) into profiles/ (tracked) and derives
+profiles/<tag>_pmc_conv_traffic.json = per-launch HBM traffic + MFMA utilisation of the dominant kernel."""
+import csv
+import json
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+g, p = "gpurun_out/", "profiles/"
+shutil.copy(g + f"{tag}_kernel_stats.csv", p + f"{tag}_bench_kernel_stats.csv")
+f, w, m = (json.load(open(g + f"{tag}_pmc_{n}.json")) for n in ("fetch", "write", "mfma"))
+for n, d in (("fetch", f), ("write", w), ("mfma", m)):
+    json.dump(d, open(p + f"{tag}_pmc_{n}.json", "w"), indent=1, sort_keys=True)
+conv = [k for k in f if k.startswith("conv_igemm_kernel")]
+n = sum(f[k]["FETCH_SIZE"]["launches"] for k in conv)
+tf = sum(f[k]["FETCH_SIZE"]["sum"] for k in conv)
+tw = sum(w[k]["WRITE_SIZE"]["sum"] for k in conv)
+mf = sum(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] for k in conv)
+gui = sum(m[k]["GRBM_GUI_ACTIVE"]["sum"] for k in conv)
+rows = list(csv.DictReader(open(p + f"{tag}_bench_kernel_stats.csv")))
+ct = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("conv_igemm"))
+cc = sum(int(r["Calls"]) for r in rows if r["Name"].startswith("conv_igemm"))
+out = {
+    "kernel": "conv_igemm_kernel (all instantiations)",
+    "pmc_run": "rocprofv3 --pmc <one counter set> (separate passes for FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE) "
+               "-- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-source-pass (batch 16, as the bench)",
+    "launches": n, "fetch_size_kib_per_launch": tf / n, "write_size_kib_per_launch": tw / n,
+    "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream "
+                  "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated (it equals the output tensor bytes exactly on the large layers)",
+    "hbm_bytes_per_launch": (2 * tf + tw) * 1024 / n,
+    "mfma_util": mf / (gui / 8 * 1024),
+    "mfma_util_formula": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); GRBM_GUI_ACTIVE sums the 8 XCDs",
+    "kernel_trace_avg_launch_ms": ct / cc / 1e6, "kernel_trace_launches": cc,
+}
+json.dump(out, open(p + f"{tag}_pmc_conv_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
