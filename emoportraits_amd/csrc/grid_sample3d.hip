@@ -476,8 +476,9 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
   return emo_launch_status();
 }
 
-// variant: 0 / 2 = XCD-remapped, 64 voxels per block (default); 3 = no remap; 4 / 5 = 128 voxels (remap / not);
-//          6 / 7 = 256 voxels (NDHWC output only); 8 = XCD-remapped + z-slice-major over the XCD's samples.  Kept selectable for in-process A/B measurements.
+// variant: 0 = default (XCD-remapped, 64 voxels per block; shared volumes also sample-interleaved = 9); 2 = XCD-remapped;
+//          3 = no remap; 4 / 5 = 128 voxels (remap / not);
+//          6 / 7 = 256 voxels (NDHWC output only); 8 / 9 = XCD-remapped + z-slice-major / row-group-major over the XCD's samples.  Kept selectable for in-process A/B measurements.
 template <int PAD, int MODE>
 int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                    const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
@@ -486,7 +487,10 @@ int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, cons
   return launch_cl_v2<PAD, MODE, VPB_, ORDER_>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, \
                                                Wo, vol_bstride, out_cl, s)
   switch (variant) {
-    case 0: case 2: EMO_CLV2(64, 1);
+    case 0:   // default: XCD-contiguous; for a volume shared by N % 8 == 0 samples also row-group-major over the samples
+      if (vol_bstride == 0 && N >= 8) EMO_CLV2(64, 3);
+      EMO_CLV2(64, 1);
+    case 2: EMO_CLV2(64, 1);
     case 3: EMO_CLV2(64, 0);
     case 4: EMO_CLV2(128, 1);
     case 5: EMO_CLV2(128, 0);
