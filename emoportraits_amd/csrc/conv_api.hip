@@ -48,7 +48,7 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
   a.Dl = D; a.Hl = ups ? 2 * H : H; a.Wl = ups ? 2 * W : W;
   a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
-  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0;
+  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0;
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;

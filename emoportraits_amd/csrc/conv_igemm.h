@@ -43,6 +43,7 @@ struct ConvArgs {
   int res_ups;         // residual is read at (z, y>>1, x>>1) from a [N,Cout,Dl,Hl/2,Wl/2] tensor
   int n_cchunks;       // ceil(Cin / KC)
   int tiles_x, tiles_y, tiles_z;
+  int n_cotiles;       // ceil(Cout / BM)
 };
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
@@ -57,13 +58,22 @@ struct ConvCfg {
   static constexpr int PATCH = KC * CHS;
   static constexpr int ASZ = KLOC * BM;             // floats of one stage's weight tile
   static constexpr int BUF = ASZ + ((PATCH + 3) & ~3);
-  static constexpr int CPW = KC / 4;                // channels staged per wave per stage (4 waves)
+#ifndef EMO_CONV_PRODUCERS
+#define EMO_CONV_PRODUCERS 0   /* 0: all 4 waves stage AND multiply; 2: two extra loader waves do all the staging
+                                  (wave specialisation), the 4 MFMA waves only read LDS and multiply */
+#endif
+  static constexpr int NPW = EMO_CONV_PRODUCERS;    // loader ("producer") waves
+  static constexpr int SW = NPW ? NPW : 4;          // waves that stage
+  static constexpr int ST = SW * 64;                // threads that stage
+  static constexpr int THREADS = 256 + 64 * NPW;
+  static constexpr int CPW = KC / SW;               // channels staged per staging wave per stage
   static constexpr int EPC = (CHS + 63) / 64;       // patch elements per lane per channel
   static constexpr int NPE = CPW * EPC;             // patch elements per thread per stage
-  static constexpr int NA4 = (ASZ / 4 + 255) / 256; // float4 weight loads per thread
+  static constexpr int NA4 = (ASZ / 4 + SW * 64 - 1) / (SW * 64); // float4 weight loads per staging thread
   static_assert(WGM * WGP == 4, "4 waves per block");
   static_assert(TZ * TR * TW == BP, "position tile must equal BP");
   static_assert(KC % 4 == 0, "one input channel per wave and stage group");
+  static_assert(EMO_CONV_PRODUCERS == 0 || EMO_CONV_PRODUCERS == 2, "0 or 2 loader waves");
   static_assert(ASZ % 4 == 0, "weight tile must be float4-copyable");
   static_assert(TM * TP <= 4, "accumulator budget");
 };
@@ -76,7 +86,10 @@ __device__ __forceinline__ float emo_act(float v, int act) {
 }
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+#ifndef EMO_CONV_MIN_WAVES
+#define EMO_CONV_MIN_WAVES 2   /* __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocation must allow */
+#endif
+__global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) void conv_igemm_kernel(const ConvArgs a) {
   using Cfg = ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS;
   constexpr int PATCH = Cfg::PATCH, ASZ = Cfg::ASZ, BUF = Cfg::BUF, NPE = Cfg::NPE, NA4 = Cfg::NA4;
@@ -89,12 +102,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // wave-uniform and handled by the scalar unit instead of costing VALU issue slots next to the MFMA stream
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
-  const int wm = wave / WGP, wp = wave % WGP;
+  constexpr int NPW = Cfg::NPW, SW = Cfg::SW, ST = Cfg::ST;
+  const bool is_producer = NPW > 0 && wave >= 4;          // wave-uniform role
+  const bool is_consumer = wave < 4;
+  const bool stages_data = NPW == 0 || is_producer;
+  const int sw = NPW ? (wave >= 4 ? wave - 4 : 0) : wave; // index among the staging waves
+  const int stid = sw * 64 + lane;                        // index among the staging threads
+  const int cwave = wave & 3;
+  const int wm = cwave / WGP, wp = cwave % WGP;
   const int m0 = wm * TM * 32, p0 = wp * TP * 32;
 
-  const int n = blockIdx.z;
-  const int cotile = blockIdx.y;
-  int bx = blockIdx.x;
+#ifndef EMO_CONV_XCD_ORDER
+#define EMO_CONV_XCD_ORDER 1   /* 1: 1-D grid, XCD-contiguous, output-channel tile fastest (see below); 0: (ptile, cotile, n) grid */
+#endif
+  int n, cotile, bx;
+  if (EMO_CONV_XCD_ORDER) {
+    // Block b runs on XCD b % 8 (private 4 MiB L2 each).  Re-map so that every XCD walks one contiguous eighth of the
+    // (sample, position tile, output-channel tile) work with the channel tile fastest: all channel tiles of a position
+    // tile then run back to back on ONE XCD and share the input patch out of its L2 (it was fetched from HBM /
+    // Infinity Cache once per channel tile before: 2-5x read amplification), and x-adjacent position tiles share
+    // their halo columns the same way.  Bijective for any grid size.
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    cotile = L % a.n_cotiles;
+    const int rest = L / a.n_cotiles;
+    const int nptiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    n = rest / nptiles;
+    bx = rest - n * nptiles;
+  } else {
+    n = blockIdx.z;
+    cotile = blockIdx.y;
+    bx = blockIdx.x;
+  }
   const int tx = bx % a.tiles_x; bx /= a.tiles_x;
   const int ty = bx % a.tiles_y; bx /= a.tiles_y;
   const int tz = bx;
@@ -146,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #define EMO_CONV_GLDS_A 0   /* 0: weight tile through VGPRs + ds_write_b128; 1: by LDS-DMA (global_load_lds).  Measured on
                                MI355X: 0 is 1 % faster end to end and 5-8 % faster on the 64-row block config */
 #endif
-  constexpr int NGL = (ASZ * 4 + 4095) / 4096;   // 1-KiB LDS-DMA pieces per wave
+  constexpr int NGL = (ASZ * 4 + 1024 * SW - 1) / (1024 * SW);   // 1-KiB LDS-DMA pieces per staging wave
 
 // Both staging halves are macros (not lambdas / conditionals) so that pv[] / av[] are unconditionally defined
 // straight-line values and stay in VGPRs (a conditional or lambda-captured definition sent them to scratch).
@@ -156,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
     const int ci0_ = cc_ * KC;                                                                        \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
-      const int c_ = ci0_ + g * 4 + wave;                                                             \
+      const int c_ = ci0_ + g * SW + sw;                                                              \
       const bool cv_ = c_ < a.Cin;                                                                    \
       const int cs_ = cv_ ? c_ : 0;                                                                   \
       const int zu_ = z0 + t_ - padD;           /* depth of tile slice 0 */                           \
@@ -181,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       /* weight tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), no VGPR round trip. */ \
       /* The LDS image is lane-linear = exactly the packed weight order.                               */ \
       _Pragma("unroll") for (int i = 0; i < NGL; ++i) {                                               \
-        const int j = wave + 4 * i;                                                                   \
+        const int j = sw + SW * i;                                                                    \
         const int boff = j * 1024 + lane * 16;                                                        \
         if (boff < ASZ * 4)                                                                           \
           __builtin_amdgcn_global_load_lds(                                                           \
@@ -190,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       }                                                                                               \
     } else {                                                                                          \
       _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                               \
-        const int idx = tid + i * 256;                                                                \
+        const int idx = stid + i * ST;                                                                \
         av[i] = ws_[idx < ASZ / 4 ? idx : ASZ / 4 - 1];                                               \
       }                                                                                               \
     }                                                                                                 \
@@ -201,13 +242,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (!EMO_CONV_GLDS_A) {                                                                           \
       float4* As4_ = reinterpret_cast<float4*>(buf_);                                                 \
       _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                               \
-        const int idx = tid + i * 256;                                                                \
+        const int idx = stid + i * ST;                                                                \
         if (idx < ASZ / 4) As4_[idx] = av[i];                                                         \
       }                                                                                               \
     }                                                                                                 \
     float* Ps_ = (buf_) + ASZ;                                                                        \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
-      float* Pc_ = Ps_ + (g * 4 + wave) * CHS;                                                        \
+      float* Pc_ = Ps_ + (g * SW + sw) * CHS;                                                         \
       _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
         const int e = lane + i * 64;                                                                  \
         if (e < CHS) {                                                                                \
@@ -219,6 +260,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
+  }
+
+#ifndef EMO_CONV_ABLATE
+#define EMO_CONV_ABLATE 0   /* timing experiments only: 1 = no global loads / LDS stores in the loop, 2 = also no barrier,
+                               3 = MFMA stream only (operands read once) -- results are WRONG for any value != 0 */
+#endif
+#ifndef EMO_CONV_STORE_AT
+#define EMO_CONV_STORE_AT 1   /* 0: write the next stage into LDS after all MFMAs of this stage; 1: after half of them */
+#endif
+  constexpr int STORE_PAIR = EMO_CONV_STORE_AT ? (KC / 4) : -1;   // the idle LDS buffer is free for the whole stage
+
+  if (stages_data) {
+    EMO_ISSUE_LOADS(0, smem);
+    EMO_STORE_STAGE(0, smem);
+  }
+  __syncthreads();
+
+  if (is_producer) {
+    // ---- loader waves (wave specialisation): the whole stage time to fetch, transform and park the next stage.
+    //      Same number of barriers as the MFMA waves; no accumulators live on this path. ----
+    for (int st = 0; st < nstages; ++st) {
+      float* nxt = smem + ((st + 1) & 1) * BUF;
+      const int stn = (st + 1) < nstages ? (st + 1) : st;
+      EMO_ISSUE_LOADS(stn, nxt);
+      EMO_STORE_STAGE(stn, nxt);
+      __syncthreads();
+    }
+    return;
   }
 
   floatx16 acc[TM][TP];
@@ -241,9 +310,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     b_base[j] = half * CHS + pz * (PR * PW) + row * PW + col;
   }
 
-  EMO_ISSUE_LOADS(0, smem);
-  EMO_STORE_STAGE(0, smem);
-  __syncthreads();
+// all MFMAs of one channel pair of the current stage: per tap 1 A read + 1 B read per 32x32 tile, TM*TP MFMAs
+#define EMO_MFMA_PAIR(pair_)                                                                          \
+  {                                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < KH; ++r) {                                                  \
+      _Pragma("unroll") for (int s = 0; s < KW; ++s) {                                                \
+        const int tap = r * KW + s;                                                                   \
+        float av_[TM], bv_[TP];                                                                       \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+          av_[i] = As[a_base + (EMO_CONV_ABLATE == 3 ? 0 : (((pair_) * TAPS + tap) * 2) * BM) + i * 32]; \
+        _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                \
+          bv_[j] = Ps[b_base[j] + (EMO_CONV_ABLATE == 3 ? 0 : ((pair_) * 2) * CHS + r * PW + s)];     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+          _Pragma("unroll") for (int j = 0; j < TP; ++j)                                              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc[i][j], 0, 0, 0);     \
+      }                                                                                               \
+    }                                                                                                 \
+  }
 
   for (int st = 0; st < nstages; ++st) {
     float* cur = smem + (st & 1) * BUF;
@@ -251,50 +334,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     // prefetch the next stage while this one computes; on the last stage the (clamped) prefetch re-reads the
     // last stage and its LDS write lands in the idle buffer -- harmless, and it keeps the loop branch-free
     const int stn = (st + 1) < nstages ? (st + 1) : st;
-#ifndef EMO_CONV_ABLATE
-#define EMO_CONV_ABLATE 0   /* timing experiments only: 1 = no global loads / LDS stores in the loop, 2 = also no barrier,
-                               3 = MFMA stream only (operands read once) -- results are WRONG for any value != 0 */
-#endif
-    if (EMO_CONV_ABLATE == 0) { EMO_ISSUE_LOADS(stn, nxt); }
-
     const float* As = cur;
     const float* Ps = cur + ASZ;
-#ifndef EMO_CONV_STORE_AT
-#define EMO_CONV_STORE_AT 1   /* 0: write the next stage into LDS after all MFMAs of this stage; 1: after half of them */
-#endif
-    constexpr int STORE_PAIR = EMO_CONV_STORE_AT ? (KC / 4) : -1;   // the idle LDS buffer is free for the whole stage
+    if (NPW == 0) {
+      // every wave stages and multiplies: loads first, LDS write of the next stage half way through the MFMAs
+      if (EMO_CONV_ABLATE == 0) { EMO_ISSUE_LOADS(stn, nxt); }
 #pragma unroll
-    for (int pair = 0; pair < KC / 2; ++pair) {
-      if (pair == STORE_PAIR && STORE_PAIR > 0 && EMO_CONV_ABLATE == 0) {
-        // mid-stage: the prefetched tile goes to the other buffer while the second half of the MFMAs still runs,
-        // so only the barrier (not load-wait + LDS stores + barrier) separates two stages' MFMA streams
-        EMO_STORE_STAGE(stn, nxt);
+      for (int pair = 0; pair < KC / 2; ++pair) {
+        if (pair == STORE_PAIR && STORE_PAIR > 0 && EMO_CONV_ABLATE == 0) { EMO_STORE_STAGE(stn, nxt); }
+        EMO_MFMA_PAIR(pair);
       }
+      if (STORE_PAIR <= 0 && EMO_CONV_ABLATE == 0) { EMO_STORE_STAGE(stn, nxt); }
+    } else {
+      // MFMA waves of the wave-specialised variant: nothing but LDS reads and matrix instructions
 #pragma unroll
-      for (int r = 0; r < KH; ++r) {
-#pragma unroll
-        for (int s = 0; s < KW; ++s) {
-          const int tap = r * KW + s;
-          float av_[TM], bv_[TP];
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-            av_[i] = As[a_base + (EMO_CONV_ABLATE == 3 ? 0 : ((pair * TAPS + tap) * 2) * BM) + i * 32];
-#pragma unroll
-          for (int j = 0; j < TP; ++j)
-            bv_[j] = Ps[b_base[j] + (EMO_CONV_ABLATE == 3 ? 0 : (pair * 2) * CHS + r * PW + s)];
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    if (STORE_PAIR <= 0 && EMO_CONV_ABLATE == 0) {
-      EMO_STORE_STAGE(stn, nxt);
+      for (int pair = 0; pair < KC / 2; ++pair) { EMO_MFMA_PAIR(pair); }
     }
     if (EMO_CONV_ABLATE < 2) __syncthreads();
   }
+#undef EMO_MFMA_PAIR
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
   const long plane = (long)a.Hl * a.Wl;
@@ -359,7 +417,9 @@ int conv_igemm_launch(ConvArgs a, hipStream_t s) {
       raised = true;
     }
   }
-  dim3 g((unsigned)nt, cot, a.N);
-  hipLaunchKernelGGL(kern, g, dim3(256), lds, s, a);
+  a.n_cotiles = cot;
+  if (nt * cot * a.N > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  dim3 g = EMO_CONV_XCD_ORDER ? dim3((unsigned)(nt * cot * a.N)) : dim3((unsigned)nt, cot, a.N);
+  hipLaunchKernelGGL(kern, g, dim3(Cfg::THREADS), lds, s, a);
   return emo_launch_status();
 }

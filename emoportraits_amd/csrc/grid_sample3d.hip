@@ -306,27 +306,49 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 // back to back out of its L2 instead of being re-streamed once per sample.
 template <int ORDER>
 __device__ __forceinline__ void block_to_work(int b, int total, int bps, int nslices, int& n, int& blk) {
+  constexpr int G = 8;                          // blocks (= output rows at Wo = 64) per row group
   if (ORDER == 0) { n = b / bps; blk = b - n * bps; return; }
   if (ORDER == 1) { const int L = xcd_remap(b, total); n = L / bps; blk = L - n * bps; return; }
+  const int bpz = bps / nslices;               // blocks per z-slice of one sample
+  if (ORDER == 4) {
+    // XCD-contiguous over samples; inside a sample (row group, z, row): the corner rows of a row group are re-used by
+    // the next z-slice while they are still L2-resident (a whole z-slice of 96 channels is 1.5 MB x 2 corner planes)
+    const int L = xcd_remap(b, total);
+    n = L / bps;
+    const int i = L - n * bps;
+    const int rg = i / (nslices * G);
+    const int rem = i - rg * (nslices * G);
+    const int z = rem / G;
+    blk = z * bpz + rg * G + (rem - z * G);
+    return;
+  }
   const int xcd = b & 7, idx = b >> 3;
   const int spx = (total / bps) >> 3;          // samples per XCD
-  const int bpz = bps / nslices;               // blocks per z-slice of one sample
   if (ORDER == 2) {
     const int z = idx / (spx * bpz);
     const int rem = idx - z * (spx * bpz);
     const int j = rem / bpz;
     n = xcd * spx + j;
     blk = z * bpz + (rem - j * bpz);
-  } else {
-    // ORDER 3: (z-slice, group of 8 blocks, sample, block in group): the group's corner rows (a few hundred KB of the
+  } else if (ORDER == 3) {
+    // (z-slice, group of 8 blocks, sample, block in group): the group's corner rows (a few hundred KB of the
     // shared volume) stay in L2 while all of the XCD's samples pass over them
-    constexpr int G = 8;
     const int per_group = spx * G;
     const int grp = idx / per_group;            // global group index = z * (bpz / G) + row group
     const int rem = idx - grp * per_group;
     const int j = rem / G;
     n = xcd * spx + j;
     blk = grp * G + (rem - j * G);
+  } else {
+    // ORDER 5: (row group, z-slice, sample, block in group): ORDER 3 with the z sweep inside the row group
+    const int per_rg = nslices * spx * G;
+    const int rg = idx / per_rg;
+    int rem = idx - rg * per_rg;
+    const int z = rem / (spx * G);
+    rem -= z * (spx * G);
+    const int j = rem / G;
+    n = xcd * spx + j;
+    blk = z * bpz + rg * G + (rem - j * G);
   }
 }
 
@@ -461,7 +483,10 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
   const int bps = emo_cdiv(nvox, VPB);
   const long total = (long)bps * N;
   if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  if (ORDER >= 2 && ((N & 7) || (bps % Do) || (nvox % VPB) || ((bps / Do) % 8)))   // needs whole slices / groups, N % 8 == 0
+  if (ORDER == 4 && ((bps % Do) || (nvox % VPB) || ((bps / Do) % 8)))
+    return launch_cl_v2<PAD, MODE, VPB, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
+                                           vol_bstride, out_cl, s);
+  if (ORDER >= 2 && ORDER != 4 && ((N & 7) || (bps % Do) || (nvox % VPB) || ((bps / Do) % 8)))   // whole slices / groups, N % 8 == 0
     return launch_cl_v2<PAD, MODE, VPB, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
                                            vol_bstride, out_cl, s);
   if (out_cl) {
@@ -498,6 +523,8 @@ int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, cons
     case 7: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, 0);
     case 8: EMO_CLV2(64, 2);
     case 9: EMO_CLV2(64, 3);
+    case 10: EMO_CLV2(64, 4);
+    case 11: EMO_CLV2(64, 5);
     default: return EMO_ERR_BAD_ARG;
   }
 #undef EMO_CLV2

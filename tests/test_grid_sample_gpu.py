@@ -147,6 +147,9 @@ def test_size_independent_properties_at_batch_64():
     assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=8), out)
     assert torch.equal(ops.grid_sample3d(vcl, grid[:5].contiguous(), in_layout="ndhwc", out_layout="ncdhw", variant=8), out[:5])
     assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=9), out)
+    for var in (10, 11):
+        assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=var), out), var
+        assert torch.equal(ops.grid_sample3d(vcl, grid[:3].contiguous(), in_layout="ndhwc", out_layout="ncdhw", variant=var), out[:3]), var
     assert torch.equal(ops.volume_to_channels_first(ops.grid_sample3d(vcl, grid[:16].contiguous(), in_layout="ndhwc", out_layout="ndhwc", variant=9)), out[:16])
     zs, ys, xs = [((2 * torch.arange(n) + 1) / n - 1) for n in (D, S, S)]
     zz, yy, xx = torch.meshgrid(zs, ys, xs, indexing="ij")

@@ -42,11 +42,10 @@ def main():
     for N in Ns:
         warp = (ident() + 0.05 * torch.tanh(torch.randn(N, D, S, S, 3, generator=g))).to(DEV)
         yaw = (torch.rand(N, 3, generator=g) * 0.6 - 0.3)
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-        import restate as O
-        theta = O.get_transform_matrix(0.9 + 0.2 * torch.rand(N, 3, generator=g), yaw,
-                                       torch.rand(N, 3, generator=g) * 0.1 - 0.05)[:, :3].contiguous().to(DEV)
-        rot_warp = O.rotation_warp(torch.cat([theta.cpu(), torch.tensor([[[0., 0, 0, 1]]]).expand(N, 1, 4)], 1), D, S).to(DEV)
+        theta = ops.pose_theta((0.9 + 0.2 * torch.rand(N, 3, generator=g)).to(DEV), yaw.to(DEV),
+                               (torch.rand(N, 3, generator=g) * 0.1 - 0.05).to(DEV))[:, :3].contiguous()
+        lat = torch.cat([ident().view(1, -1, 3), torch.ones(1, D * S * S, 1)], -1).to(DEV)
+        rot_warp = lat.expand(N, -1, -1).bmm(theta.transpose(1, 2)).view(N, D, S, S, 3).contiguous()
         volN = vol.expand(N, -1, -1, -1, -1).contiguous() if N <= 8 else None
         out_nc = torch.empty(N, C, D, S, S, device=DEV)
         out_cl = torch.empty(N, D, S, S, C, device=DEV)
@@ -55,7 +54,7 @@ def main():
         for cpb in (4, 8, 12, 16, 24, 32, 48, 96):
             cases.append((f"uv/ncdhw/cpb{cpb}", lambda cpb=cpb: ops.grid_sample3d(vol, warp, variant=cpb, out=out_nc), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("uv/cl", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), vol_bytes / N + grid_bytes + vol_bytes))
-        for var in (3, 8, 9):
+        for var in (9, 10, 11):
             cases.append((f"uv/cl_var{var}", lambda var=var: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=var), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("uv/cl_v1", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=1), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("uv/cl2ncdhw", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ncdhw", out=out_nc), vol_bytes / N + grid_bytes + vol_bytes))
@@ -68,7 +67,7 @@ def main():
         inN_cl = torch.randn(N, D, S, S, C, device=DEV)
         inN_nc = torch.randn(N, C, D, S, S, device=DEV)
         cases.append(("rot_theta_unshared/ncdhw/cpb8", lambda: ops.grid_sample3d(inN_nc, theta=theta, variant=8, out=out_nc), 2 * vol_bytes))
-        for var in (3, 9):
+        for var in (2, 10):
             cases.append((f"rot_theta_unshared/cl2ncdhw_var{var}", lambda var=var: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc, variant=var), 2 * vol_bytes))
         cases.append(("rot_theta_unshared/cl2ncdhw_v1", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc, variant=1), 2 * vol_bytes))
         cases.append(("rot_theta_unshared/cl2ncdhw", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc), 2 * vol_bytes))
