@@ -78,6 +78,32 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     out[i] = (a[i] + b[i % period]) * alpha;
 }
 
+// stage-2 glue (notebooks/infer_s2.py:365-375)
+__global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ img, const float* __restrict__ mask,
+                                                       float* __restrict__ out, long N, int C, long HW) {
+  const long total = N * C * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i % HW;
+    const long n = i / (HW * C);
+    out[i] = img[i] * mask[n * HW + p];
+  }
+}
+
+__global__ __launch_bounds__(256) void stage2_compose_kernel(const float* __restrict__ img, const float* __restrict__ add,
+                                                             const float* __restrict__ mask,
+                                                             const float* __restrict__ face_mask,
+                                                             float* __restrict__ out, long N, int C, long HW) {
+  const long total = N * C * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i % HW;
+    const long n = i / (HW * C);
+    const float m = mask[n * HW + p] * face_mask[n * HW + p];
+    float v = img[i] + add[i] * m;
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    out[i] = v;
+  }
+}
+
 inline int grid_for(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -111,5 +137,20 @@ extern "C" int emo_add_f32(const float* a, const float* b, float* out, int64_t n
   if (!a || !b || !out || n <= 0 || period <= 0) return EMO_ERR_BAD_ARG;
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n,
                      (long)period, alpha);
+  return emo_launch_status();
+}
+
+extern "C" int emo_mul_mask_f32(const float* img, const float* mask, float* out, int N, int C, int64_t HW, void* stream) {
+  if (!img || !mask || !out || N <= 0 || C <= 0 || HW <= 0) return EMO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(mul_mask_kernel, dim3(grid_for((long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, img, mask, out,
+                     (long)N, C, (long)HW);
+  return emo_launch_status();
+}
+
+extern "C" int emo_stage2_compose_f32(const float* img, const float* add, const float* mask, const float* face_mask,
+                                      float* out, int N, int C, int64_t HW, void* stream) {
+  if (!img || !add || !mask || !face_mask || !out || N <= 0 || C <= 0 || HW <= 0) return EMO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(stage2_compose_kernel, dim3(grid_for((long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, img,
+                     add, mask, face_mask, out, (long)N, C, (long)HW);
   return emo_launch_status();
 }

@@ -27,6 +27,27 @@ def _dev(t, device):
     return t.detach().float().contiguous().to(device)
 
 
+class Norm:
+    """nn.GroupNorm(32, C) (statistics reduced on the GPU per call) or eval-mode nn.BatchNorm (a static per-channel
+    affine folded at load time: stage 2 with its default flags) -> (scale, shift) [N,C] for the conv staging."""
+
+    def __init__(self, sd, prefix, device):
+        self.gamma, self.beta = _dev(sd[prefix + ".weight"], device), _dev(sd[prefix + ".bias"], device)
+        self.bn = (prefix + ".running_mean") in sd
+        if self.bn:
+            rm, rv = sd[prefix + ".running_mean"].double(), sd[prefix + ".running_var"].double()
+            sc = sd[prefix + ".weight"].double() / torch.sqrt(rv + 1e-5)      # nn.BatchNorm2d eps
+            sh = sd[prefix + ".bias"].double() - rm * sc
+            self.scale, self.shift = _dev(sc.float()[None], device), _dev(sh.float()[None], device)
+
+    def affine(self, x, ada=None):
+        if self.bn:
+            n = x.shape[0]
+            return self.scale.expand(n, -1).contiguous(), self.shift.expand(n, -1).contiguous()
+        a = ada or (None, None)
+        return ops.groupnorm_affine(x, self.gamma, self.beta, a[0], a[1])
+
+
 class ResBlock:
     """GN -> ReLU -> conv3 -> GN -> ReLU -> conv3 (+ skip), utils.py:661-788.
 
@@ -41,21 +62,19 @@ class ResBlock:
         self.skip = None
         if (prefix + ".skip.0.weight_orig") in sd:
             self.skip = PackedConv.from_state_dict(sd, prefix + ".skip.0", "sn", device)
-        self.g1, self.b1 = _dev(sd[prefix + ".block_feats.0.weight"], device), _dev(sd[prefix + ".block_feats.0.bias"], device)
-        self.g2, self.b2 = _dev(sd[prefix + ".block_feats.3.weight"], device), _dev(sd[prefix + ".block_feats.3.bias"], device)
+        self.n1 = Norm(sd, prefix + ".block_feats.0", device)
+        self.n2 = Norm(sd, prefix + ".block_feats.3", device)
 
     def __call__(self, x, ups=False, ada1=None, ada2=None, down=None):
         """x: block input (pre-upsample when ups).  ada1/ada2: (ada_gamma, ada_beta) [N,C] views or None.
         down: avg-pool kernel applied to the block output.  The reference pools the main and the skip branch
         separately before adding them (utils.py:744-760); pooling is linear, so pool(main + skip) is the same
         function evaluated with one pooling pass instead of two."""
-        a1 = ada1 or (None, None)
-        a2 = ada2 or (None, None)
         # GroupNorm statistics are invariant under nearest x2 upsampling (every element is replicated 4x),
         # so they are reduced on the small pre-upsample tensor
-        s1, h1 = ops.groupnorm_affine(x, self.g1, self.b1, a1[0], a1[1])
+        s1, h1 = self.n1.affine(x, ada1)
         h = ops.conv_igemm(x, self.conv1, s1, h1, relu_in=True, ups=ups)
-        s2, h2 = ops.groupnorm_affine(h, self.g2, self.b2, a2[0], a2[1])
+        s2, h2 = self.n2.affine(h, ada2)
         if self.skip is not None:
             r = ops.conv_igemm(x, self.skip, ups=ups)
             out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, out=r)
@@ -118,7 +137,7 @@ class WarpGenerator:
         self.v_all = _dev(torch.stack(vs), device)                                       # [2nb, E, 2]
         self.norm_of_row = torch.tensor(rows, dtype=torch.int32, device=device)
         self.gamma_all, self.beta_all = _dev(torch.cat(gam), device), _dev(torch.cat(bet), device)
-        self.gh, self.bh = _dev(sd[prefix + ".pre_head.0.weight"], device), _dev(sd[prefix + ".pre_head.0.bias"], device)
+        self.nh = Norm(sd, prefix + ".pre_head.0", device)
         self.head = PackedConv.from_state_dict(sd, prefix + ".head.0.0", "sn", device)
 
     def __call__(self, embed):
@@ -142,7 +161,7 @@ class WarpGenerator:
             x = blk(x, ada1=(ag[:, a0:a1], ab[:, a0:a1]), ada2=(ag[:, b0:b1], ab[:, b0:b1]))
             if down:
                 x = ops.avgpool(x, (2, 1, 1))
-        s, h = ops.groupnorm_affine(x, self.gh, self.bh)
+        s, h = self.nh.affine(x)
         return ops.conv_igemm(x, self.head, s, h, relu_in=True, act="tanh")
 
 
@@ -160,7 +179,7 @@ class Decoder:
                 self.up.append((ResBlock(sd, f"{prefix}.img_decoder.dec_img_blocks.{k}", "ws", device), j == 0))
                 k += 1
         hp = prefix + ".img_decoder.dec_img_head"
-        self.gh, self.bh = _dev(sd[hp + ".0.weight"], device), _dev(sd[hp + ".0.bias"], device)
+        self.nh = Norm(sd, hp + ".0", device)
         self.head = PackedConv.from_state_dict(sd, hp + ".2", "ws", device)
 
     def __call__(self, feat_2d):
@@ -171,7 +190,7 @@ class Decoder:
         feat = x
         for blk, ups in self.up:
             x = blk(x, ups=ups)
-        s, h = ops.groupnorm_affine(x, self.gh, self.bh)
+        s, h = self.nh.affine(x)
         img = ops.conv_igemm(x, self.head, s, h, relu_in=True, act="sigmoid")
         return img, feat, x
 
@@ -198,7 +217,7 @@ class Unet3D:
         self.up = [ResBlock(sd, f"{prefix}.blocks_3d_up.{i}", "sn", device) for i in range(self.nb)]
         self.skipb = [ResBlock(sd, f"{prefix}.skip_blocks_3d_up.{i}", "sn", device) for i in range(self.nb)]
         self.input_tensor = _dev(sd[prefix + ".input_tensor"], device)
-        self.gh, self.bh = _dev(sd[prefix + ".head.0.weight"], device), _dev(sd[prefix + ".head.0.bias"], device)
+        self.nh = Norm(sd, prefix + ".head.0", device)
         self.head = PackedConv.from_state_dict(sd, prefix + ".head.2", "sn", device)
 
     def __call__(self, vol):
@@ -235,7 +254,7 @@ class Unet3D:
             x = self.up[i - 1](ops.add(x, skip))
             if down:
                 x = ops.avgpool(x, (2, 1, 1))
-        s, h = ops.groupnorm_affine(x, self.gh, self.bh)
+        s, h = self.nh.affine(x)
         return ops.conv_igemm(x, self.head, s, h, relu_in=True)
 
 

@@ -282,3 +282,29 @@ def pack_rgb8(img):
     out = torch.empty((N, H, W, 3), device=img.device, dtype=torch.uint8)
     hip.check(lib.emo_pack_rgb8(hip.ptr(img), hip.ptr(out), N, H, W, hip.current_stream()), "emo_pack_rgb8")
     return out
+
+
+def mul_mask(img, mask):
+    """img [N,C,H,W] * mask [N,1,H,W]  (notebooks/infer_s2.py:370)"""
+    lib = hip.load()
+    hip.require_cuda_f32(img, mask)
+    N, C, H, W = img.shape
+    if mask.numel() != N * H * W:
+        raise ValueError("mask must be [N,1,H,W]")
+    out = torch.empty_like(img)
+    hip.check(lib.emo_mul_mask_f32(hip.ptr(img), hip.ptr(mask), hip.ptr(out), N, C, H * W, hip.current_stream()),
+              "emo_mul_mask_f32")
+    return out
+
+
+def stage2_compose(img, add_img, mask, face_mask):
+    """clamp(img + add * (mask * face_mask), 0, 1)  (notebooks/infer_s2.py:365,373-375)"""
+    lib = hip.load()
+    hip.require_cuda_f32(img, add_img, mask, face_mask)
+    N, C, H, W = img.shape
+    if mask.numel() != N * H * W or face_mask.numel() != N * H * W or add_img.shape != img.shape:
+        raise ValueError("bad shapes")
+    out = torch.empty_like(img)
+    hip.check(lib.emo_stage2_compose_f32(hip.ptr(img), hip.ptr(add_img), hip.ptr(mask), hip.ptr(face_mask), hip.ptr(out),
+                                         N, C, H * W, hip.current_stream()), "emo_stage2_compose_f32")
+    return out

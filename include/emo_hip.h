@@ -141,6 +141,13 @@ int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC, int D, in
 int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int kd, int kh, int kw, void* stream);
 int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, float alpha, void* stream);
 
+/* stage-2 glue (notebooks/infer_s2.py:365-375):
+ *   emo_mul_mask_f32:        out[n,c,p] = img[n,c,p] * mask[n,0,p]            (local_encoder input, :370)
+ *   emo_stage2_compose_f32:  out = clamp(img + add * (mask * face_mask), 0, 1)   (:365,373-375); masks are [N,1,H,W] */
+int emo_mul_mask_f32(const float* img, const float* mask, float* out, int N, int C, int64_t HW, void* stream);
+int emo_stage2_compose_f32(const float* img, const float* add, const float* mask, const float* face_mask, float* out,
+                           int N, int C, int64_t HW, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a3/a4/a5 -- small wave-reduced kernels
  *   emo_small_gemm_f32: C[b][m][0..NN) = sum_k A[m][k] * B[b][k][0..NN), NN in {1,2,4,16}: pose_unsqueeze_nw Linear

@@ -133,9 +133,37 @@ def tiny_hotpath():
           sum(v.numel() for v in sd.values()) / 1e6, "M params")
 
 
+TINY_S2 = dict(output_size_s2=64, gen_latent_texture_size2=16, gen_latent_texture_channels2=8, gen_latent_texture_depth=4,
+               gen_num_channels=32, gen_max_channels=64, enc_channel_mult_stage2=1.0, dec_channel_mult_stage2=1.0,
+               dec_num_blocks_stage2=2, dec_max_channels2=64)
+
+
+def tiny_stage2():
+    """reduced-width stage-2 model with its default flags (BatchNorm, no WS), trained-like spectral-norm vectors and
+    non-trivial BN statistics; outputs of the reference's LocalEncoderOld + Decoder_stage2Old"""
+    import restate as O
+    args = R.stage2_args(TINY_S2)
+    h = R.build_stage2_holder(args, seed=4)
+    R.make_trained_like(h)
+    R.randomize_affines(h, seed=6, scale=0.1)
+    R.randomize_bn_stats(h, seed=8)
+    sd = {k: v.detach().clone() for k, v in h.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    S = TINY_S2["output_size_s2"]
+    img = torch.rand(2, 3, S, S, generator=g)
+    mask = (torch.rand(2, 1, S, S, generator=g) > 0.15).float()
+    face = (torch.rand(2, 1, S, S, generator=g) > 0.3).float()
+    ref = R.reference_stage2(h, img, mask, face)
+    blob = dict(cfg=O.stage2_cfg_from_args(args), state_dict=sd, img=img, mask=mask, face_mask=face, **ref)
+    path = os.path.join(OUT, "tiny_stage2.pt")
+    torch.save(blob, path)
+    print("tiny_stage2.pt", os.path.getsize(path) / 1e6, "MB;", len(sd), "tensors")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     sampler_kat()
     pose_theta()
     tiny_hotpath()
+    tiny_stage2()

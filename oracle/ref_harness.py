@@ -222,3 +222,128 @@ def reference_driver_pass(h, canonical, idt_embed, target_pose_embed, theta_drv,
         img, _, deep_f, img_f = h.decoder_nw(dd, embed_dict, feat, False, stage_two=True)  # infer.py:637
     return dict(target_rotation_warp=target_rotation_warp, uv_warp=uv_warp, delta_uv=delta_uv,
                 aligned=aligned, img=img, deep_f=deep_f, img_f=img_f, warp_embed=tgt_embed["orig"])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# stage 2: notebooks/infer_s2.py + models/stage_2/base/volumetric_avatar_two.py
+# ----------------------------------------------------------------------------------------------------------------
+def stage2_args(overrides=None):
+    """argparse defaults of models/stage_2/base/volumetric_avatar_two.py:26-270 (the released stage-2 args.txt lives in
+    logs_s2.zip, which is not in the reference tree) + overrides"""
+    install()
+    # volumetric_avatar_two.py:20 imports datasets.Retinaface, a file that is absent from the reference tree
+    import datasets as _ref_datasets  # the reference's own datasets/ package (REF_ROOT is first on sys.path)
+    stub = MagicMock(name="datasets.Retinaface")
+    sys.modules.setdefault("datasets.Retinaface", stub)
+    if not hasattr(_ref_datasets, "Retinaface"):
+        _ref_datasets.Retinaface = stub
+    from models.stage_2.base import volumetric_avatar_two as m2
+    p = argparse.ArgumentParser(conflict_handler="resolve")
+    p.add_argument("--num_gpus", default=1, type=int)
+    p.add_argument("--project_dir", default=REF_ROOT, type=str)
+    p = m2.Model.add_argparse_args(p)
+    args, _ = p.parse_known_args([])
+    args.num_gpus = 1
+    for k, v in (overrides or {}).items():
+        setattr(args, k, v)
+    return args
+
+
+def build_stage2_holder(args, seed=0):
+    """local_encoder + decoder of the stage-2 Model (volumetric_avatar_two.py:338-445), initialised and wrapped with
+    spectral norm / weight standardisation exactly as Model.__init__ does (:461, :548-575)."""
+    install()
+    import contextlib
+    import io
+    import torch
+    from torch import nn
+    from networks import volumetric_avatar
+    from utils import weight_init, spectral_norm, args as args_utils
+
+    torch.manual_seed(seed)
+
+    class Holder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.args = args
+            self.local_encoder = volumetric_avatar.LocalEncoderOld(
+                use_amp_autocast=False, gen_upsampling_type=args.gen_upsampling_type,
+                gen_downsampling_type=args.gen_downsampling_type, gen_input_image_size=args.output_size_s2,
+                gen_latent_texture_size=args.gen_latent_texture_size2,
+                gen_latent_texture_depth=args.gen_latent_texture_depth, warp_norm_grad=args.warp_norm_grad,
+                gen_num_channels=args.gen_num_channels, enc_channel_mult=args.enc_channel_mult_stage2,
+                norm_layer_type=args.norm_layer_type, num_gpus=args.num_gpus, gen_max_channels=args.gen_max_channels,
+                enc_block_type=args.enc_block_type, gen_activation_type=args.gen_activation_type,
+                gen_latent_texture_channels=args.gen_latent_texture_channels2, in_channels=3)
+            self.decoder = volumetric_avatar.Decoder_stage2Old(
+                eps=args.eps, image_size=args.output_size_s2, use_amp_autocast=False,
+                gen_embed_size=args.gen_embed_size, gen_adaptive_kernel=args.gen_adaptive_kernel,
+                gen_adaptive_conv_type=args.gen_adaptive_conv_type,
+                gen_latent_texture_size=args.gen_latent_texture_size2,
+                in_channels=args.gen_latent_texture_channels2 * args.gen_latent_texture_depth,
+                gen_num_channels=args.gen_num_channels, dec_max_channels=args.dec_max_channels2, gen_use_adanorm=False,
+                gen_activation_type=args.gen_activation_type, gen_use_adaconv=args.gen_use_adaconv,
+                dec_channel_mult=args.dec_channel_mult_stage2, dec_num_blocks=args.dec_num_blocks_stage2,
+                dec_up_block_type=args.dec_up_block_type, dec_pred_seg=args.dec_pred_seg,
+                dec_seg_channel_mult=args.dec_seg_channel_mult, dec_pred_conf=args.dec_pred_conf,
+                dec_conf_ms_names=args.dec_conf_ms_names, dec_conf_names=args.dec_conf_names,
+                dec_conf_ms_scales=args.dec_conf_ms_scales, dec_conf_channel_mult=args.dec_conf_channel_mult,
+                gen_downsampling_type=args.gen_downsampling_type, num_gpus=args.num_gpus,
+                norm_layer_type=args.norm_layer_type)
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        h = Holder()
+        h.apply(weight_init.weight_init(args.init_type, args.init_gain))                       # :461
+        if args.use_sn:                                                                          # :548-561
+            spn_layers = args_utils.parse_str_to_list(args.spn_layers, sep=",")
+            for name in args_utils.parse_str_to_list(args.spn_networks, sep=","):
+                if hasattr(h, name):
+                    getattr(h, name).apply(lambda mod: spectral_norm.apply_spectral_norm(mod, apply_to=spn_layers))
+        if args.use_ws:                                                                          # :564-575
+            for name in args_utils.parse_str_to_list(args.ws_networks, sep=","):
+                if hasattr(h, name):
+                    setattr(h, name, volumetric_avatar.utils.replace_conv_to_ws_conv(getattr(h, name), conv2d=True, conv3d=True))
+    h.eval()
+    return h
+
+
+def randomize_bn_stats(holder, seed=7):
+    """eval-mode BatchNorm of a fresh module is the identity (mean 0, var 1): give the running statistics values"""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, b in holder.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.3 * torch.randn(b.shape, generator=g))
+            elif name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    return holder
+
+
+def reference_stage2(h, img, mask, face_mask):
+    """notebooks/infer_s2.py:351-376 with the third-party masks given (img already at output_size_s2)"""
+    import torch
+    with torch.no_grad():
+        vol = h.local_encoder(img * mask)                                                        # infer_s2.py:370
+        add, _, _, _ = h.decoder(None, None, vol, False, pred_feat=None)                         # :371
+        add_m = add * (mask * face_mask)                                                         # :365,373
+        out = (img + add_m).clamp(max=1, min=0)                                                  # :374-375
+    return dict(latents=vol, add=add, out=out)
+
+
+def make_trained_like(holder, iters=8):
+    """bring every spectral-norm (u, v) pair to the dominant singular pair of its weight (the invariant training
+    maintains, utils/spectral_norm.py:56-58): with the random unit vectors SpectralNorm.apply leaves behind, W/sigma
+    has an arbitrary gain and a BatchNorm network overflows to inf/NaN"""
+    import torch
+    sd = holder.state_dict()
+    with torch.no_grad():
+        for k in list(sd):
+            if k.endswith(".weight_orig"):
+                p = k[: -len(".weight_orig")]
+                w = sd[k].reshape(sd[k].shape[0], -1)
+                u, v = sd[p + ".weight_u"], sd[p + ".weight_v"]
+                for _ in range(iters):
+                    v.copy_(torch.nn.functional.normalize(torch.mv(w.t(), u), dim=0))
+                    u.copy_(torch.nn.functional.normalize(torch.mv(w, v), dim=0))
+    return holder

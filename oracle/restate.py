@@ -93,7 +93,12 @@ def conv(x, sd, prefix, kind, padding=0):
 # norms
 # ----------------------------------------------------------------------------------------------
 def group_norm(x, sd, prefix, groups=32, eps=1e-5):
-    """norm_layers['gn'|'gn_3d'] = nn.GroupNorm(32, C) (networks/volumetric_avatar/utils.py:953-957)."""
+    """norm_layers['gn'|'gn_3d'] = nn.GroupNorm(32, C) (networks/volumetric_avatar/utils.py:953-957);
+    norm_layers['bn'] = nn.BatchNorm2d (utils.py:948) in eval mode when the checkpoint carries running statistics
+    (stage 2 with its default flags, models/stage_2/base/volumetric_avatar_two.py:33)."""
+    if (prefix + ".running_mean") in sd:
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                            sd[prefix + ".bias"], False, 0.0, eps)
     return F.group_norm(x, groups, sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
 
 
@@ -378,17 +383,22 @@ def decoder(sd, prefix, feat_2d, cfg):
 # ----------------------------------------------------------------------------------------------
 # a6: LocalEncoder (networks/volumetric_avatar/local_encoder.py:48-125)
 # ----------------------------------------------------------------------------------------------
-def local_encoder(sd, prefix, img, cfg):
+def local_encoder(sd, prefix, img, cfg, image_size=None, latent_size=None, ws=True):
+    """also networks/volumetric_avatar/local_encoder_old.py:25-117 (stage 2: identical structure, other sizes).
+    ws: whether the WS replacement hit the convs that follow a GroupNorm (use_ws and norm 'gn')."""
     s = img.shape[2]
-    nblk = int(math.log(cfg["image_size"] // cfg["latent_volume_size"], 2))
+    image_size = cfg["image_size"] if image_size is None else image_size
+    latent_size = cfg["latent_volume_size"] if latent_size is None else latent_size
+    kind = "ws" if ws else "sn"
+    nblk = int(math.log(image_size // latent_size, 2))
     w, b = conv_params(sd, f"{prefix}.from_rgb_{s}px", "sn")
     x = F.conv2d(img, w, b, padding=3)                                            # local_encoder.py:64-73
     pool = lambda t: F.avg_pool2d(t, 2)                                           # AvgPool2d(stride) utils.py:962
     for i in range(nblk):
-        x = res_block(x, sd, f"{prefix}.enc_{i}_block={s}px", "ws", downsample=pool)
+        x = res_block(x, sd, f"{prefix}.enc_{i}_block={s}px", kind, downsample=pool)
         s //= 2
     x = F.relu(group_norm(x, sd, prefix + ".finale_layers.0"))
-    w, b = conv_params(sd, prefix + ".finale_layers.2", "ws")
+    w, b = conv_params(sd, prefix + ".finale_layers.2", kind)
     return F.conv2d(x, w, b)                                                      # local_encoder.py:97-111
 
 
@@ -480,3 +490,58 @@ def driver_pass(sd, cfg, canonical, idt_embed, target_pose_embed, theta_drv):
     img, deep_f, img_f = decoder(sd, "decoder_nw", feat, cfg)                     # infer.py:637
     return dict(target_rotation_warp=rot, uv_warp=uv_warp, delta_uv=delta, aligned=aligned,
                 img=img, deep_f=deep_f, img_f=img_f, warp_embed=emb)
+
+
+# ----------------------------------------------------------------------------------------------
+# stage 2: notebooks/infer_s2.py:351-376 on models/stage_2/base/volumetric_avatar_two.py:338-445
+# ----------------------------------------------------------------------------------------------
+STAGE2_DEFAULT_CFG = dict(   # argparse defaults of volumetric_avatar_two.py:26-270 (released stage-2 args are not in the repo)
+    output_size_s2=512, gen_latent_texture_size2=64, gen_latent_texture_channels2=64, gen_latent_texture_depth=16,
+    gen_num_channels=32, gen_max_channels=512, enc_channel_mult_stage2=4.0, dec_channel_mult_stage2=4.0,
+    dec_num_blocks_stage2=8, dec_max_channels2=512, norm_layer_type="bn", use_ws=False,
+)
+
+
+def stage2_cfg_from_args(args):
+    return {k: getattr(args, k) for k in STAGE2_DEFAULT_CFG}
+
+
+def stage2_decoder_channels(cfg2):
+    nup = int(math.log(cfg2["output_size_s2"] // cfg2["gen_latent_texture_size2"], 2))
+    trunk = min(int(cfg2["gen_num_channels"] * cfg2["dec_channel_mult_stage2"] * 2 ** nup), cfg2["dec_max_channels2"])
+    ups, c = [], trunk
+    for _ in range(nup - 1):
+        c = max(c // 2, cfg2["gen_num_channels"])                                  # decoder_s2_old.py:378
+        ups.append(c)
+    return trunk, ups
+
+
+def decoder_stage2(sd, prefix, feat_2d, cfg2):
+    """Decoder_stage2 + ImageDecoder_stage2 (networks/volumetric_avatar/decoder_s2_old.py:18-218, :346-472):
+    1x1 -> dec_num_blocks ResBlocks -> (num_up-1) nearest-x2 ResBlocks -> x2 ResBlock to 128 + three ResBlocks
+    128/64/32 -> norm + ReLU + 1x1 + tanh.  Returns the additive residual image."""
+    kind = "ws" if (cfg2["use_ws"] and cfg2["norm_layer_type"] == "gn") else "sn"
+    _, ups = stage2_decoder_channels(cfg2)
+    x = F.conv2d(feat_2d, sn_weight(sd, prefix + ".res_decoder.0"))
+    for i in range(cfg2["dec_num_blocks_stage2"]):
+        x = res_block(x, sd, f"{prefix}.res_decoder.{i + 1}", kind)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    for i in range(len(ups)):
+        x = res_block(x, sd, f"{prefix}.img_decoder.dec_img_blocks.{i}", kind, upsample=up)
+    x = res_block(x, sd, f"{prefix}.img_decoder.dec_img_feat_blocks.0", kind, upsample=up)
+    for i in (1, 2, 3):
+        x = res_block(x, sd, f"{prefix}.img_decoder.dec_img_feat_blocks.{i}", kind)
+    h = F.relu(group_norm(x.float(), sd, prefix + ".img_decoder.dec_img_head.0"))
+    w, b = conv_params(sd, prefix + ".img_decoder.dec_img_head.2", kind)
+    return torch.tanh(F.conv2d(h, w, b))
+
+
+def stage2_forward(sd, cfg2, img, mask, face_mask):
+    """infer_s2.py:351-376 with the third-party masks (MODNet matte `mask`, BiSeNet `face_mask`) given and `img`
+    already at output_size_s2: add = decoder(encoder(img*mask)) * (mask*face_mask); out = clamp(img + add, 0, 1)"""
+    ws = cfg2["use_ws"] and cfg2["norm_layer_type"] == "gn"
+    lat = local_encoder(sd, "local_encoder", img * mask, cfg2, image_size=cfg2["output_size_s2"],
+                        latent_size=cfg2["gen_latent_texture_size2"], ws=ws)
+    add = decoder_stage2(sd, "decoder", lat, cfg2)
+    out = (img + add * (mask * face_mask)).clamp(max=1, min=0)
+    return dict(latents=lat, add=add, out=out)

@@ -94,6 +94,24 @@ def main():
         print(f"  {pm:10s} max_abs={d:.3e}")
         results.append(dict(name="sampler." + pm, max_abs=float(d)))
 
+    print("stage 2 (infer_s2.py:351-376), default flags (BatchNorm) and GroupNorm+WS variant")
+    for ov in (dict(output_size_s2=S), dict(output_size_s2=S, norm_layer_type="gn", use_ws=True)):
+        a2 = R.stage2_args(ov)
+        h2 = R.build_stage2_holder(a2, seed=1)
+        R.make_trained_like(h2)
+        R.randomize_affines(h2, seed=5, scale=0.1)
+        R.randomize_bn_stats(h2)
+        sd2 = {k: v.detach().clone() for k, v in h2.state_dict().items()}
+        gg2 = torch.Generator().manual_seed(3)
+        im = torch.rand(1, 3, S, S, generator=gg2)
+        mk = (torch.rand(1, 1, S, S, generator=gg2) > 0.2).float()
+        fm = (torch.rand(1, 1, S, S, generator=gg2) > 0.3).float()
+        ref2 = R.reference_stage2(h2, im, mk, fm)
+        with torch.no_grad():
+            our2 = O.stage2_forward(sd2, O.stage2_cfg_from_args(a2), im, mk, fm)
+        for k in ("latents", "add", "out"):
+            results.append(stats(f"s2[{a2.norm_layer_type}].{k}", our2[k], ref2[k]))
+
     summary = dict(image_size=S, torch=torch.__version__, threads=torch.get_num_threads(),
                    reference_source_s=t_ref, reference_driver_s=t_ref_d, results=results)
     if out:

@@ -122,3 +122,12 @@ def test_ada_group_norm_double_affine_quirk(tiny):
     base = F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
     want = base * (sd[p + ".weight"][None] + dg)[:, :, None, None, None] + (sd[p + ".bias"][None] + db)[:, :, None, None, None]
     assert torch.allclose(y, want)
+
+
+def test_stage2_restatement_matches_reference_golden(golden_dir):
+    """LocalEncoderOld + Decoder_stage2Old with the stage-2 default flags (BatchNorm)"""
+    t = torch.load(os.path.join(golden_dir, "tiny_stage2.pt"), weights_only=False)
+    with torch.no_grad():
+        got = O.stage2_forward(t["state_dict"], t["cfg"], t["img"], t["mask"], t["face_mask"])
+    for k in ("latents", "add", "out"):
+        assert torch.equal(got[k], t[k]), k
