@@ -8,6 +8,17 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 g, p = "gpurun_out/", "profiles/"
 shutil.copy(g + f"{tag}_kernel_stats.csv", p + f"{tag}_bench_kernel_stats.csv")
+import os
+for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench256.json", f"{tag}_bench_n1_r256.json"),
+                 (f"{tag}_bench_2ranks_1gpu.json", f"{tag}_bench_2ranks_on_1gpu_gloo.json"),
+                 (f"{tag}_stage2.jsonl", f"{tag}_stage2_bench.jsonl"), (f"{tag}_sampler.jsonl", f"{tag}_sampler_microbench.jsonl"),
+                 (f"{tag}_conv.jsonl", f"{tag}_conv_microbench.jsonl"), (f"{tag}_driver512.jsonl", f"{tag}_driver_breakdown_r512.jsonl"),
+                 (f"{tag}_smoke.log", f"{tag}_smoke.txt")):
+    if os.path.exists(g + src):
+        shutil.copy(g + src, p + dst)
+if os.path.exists(g + f"{tag}_pytest.log"):
+    lines = [l for l in open(g + f"{tag}_pytest.log", errors="replace") if "PARITY" in l or "passed" in l or "failed" in l]
+    open(p + f"{tag}_parity.txt", "w").writelines(lines)
 f, w, m = (json.load(open(g + f"{tag}_pmc_{n}.json")) for n in ("fetch", "write", "mfma"))
 for n, d in (("fetch", f), ("write", w), ("mfma", m)):
     json.dump(d, open(p + f"{tag}_pmc_{n}.json", "w"), indent=1, sort_keys=True)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Full round-end validation on the GPU box (what the driver runs, plus the evidence kept under profiles/):
+#   all GPU parity tests, smoke(), the bench line (N=1; R512 and R256), a 2-rank run on one GPU (gloo, test hook),
+#   stage-2 throughput, sampler / conv microbenchmarks, rocprofv3 kernel stats + PMC passes.
+# usage: gpurun -- 'bash tools/gpu_validate.sh r1'   then   python tools/collect_profiles.py r1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r1}
+mkdir -p $R/gpurun_out; cd $R
+timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${TAG}_pytest_full.log
+grep -a "PARITY\|passed\|failed\|Error\|FAILED" gpurun_out/${TAG}_pytest_full.log > gpurun_out/${TAG}_pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_smoke.log
+timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --image-size 256 --batch 32 --no-cpu-baseline > gpurun_out/${TAG}_bench256.json 2>> gpurun_out/${TAG}_bench.err
+EMO_DIST_BACKEND=gloo EMO_FORCE_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+   bench.py --gpus 2 --steps 2 --warmup 1 --batch 4 > gpurun_out/${TAG}_bench_2ranks_1gpu.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 python tools/bench_stage2.py 8 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_stage2.jsonl
+timeout 300 python tools/bench_sampler.py 64 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_sampler.jsonl
+timeout 300 python tools/bench_conv.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_conv.jsonl
+timeout 300 python tools/bench_driver.py 512 1 4 16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_driver512.jsonl
+bash tools/profile_bench.sh ${TAG}
+tail -3 gpurun_out/${TAG}_pytest.log; tail -1 gpurun_out/${TAG}_smoke.log; cut -c1-200 gpurun_out/${TAG}_bench.json
