@@ -78,6 +78,58 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     out[i] = (a[i] + b[i % period]) * alpha;
 }
 
+// F.interpolate(x, size=(Ho, Wo), mode='bilinear' | 'bicubic', align_corners=False) on 4-D tensors (ATen
+// UpSampleBilinear2d / UpSampleBicubic2d: area_pixel_compute_source_index + cubic convolution, A = -0.75).
+// Wrapper glue of the reference: bicubic resize of source / driver crops to image_size (notebooks/infer.py:399-401,
+// :548-552), bilinear resize to output_size_s2 (notebooks/infer_s2.py:360-362).
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
+
+__global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__ x, float* __restrict__ out, long NC,
+                                                       int H, int W, int Ho, int Wo, int bicubic) {
+  const long total = NC * Ho * Wo;
+  const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;   // scale = in/out when only `size` is given
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xo = (int)(i % Wo);
+    const long r = i / Wo;
+    const int yo = (int)(r % Ho);
+    const long nc = r / Ho;
+    const float* p = x + nc * (long)H * W;
+    float sy = sh * ((float)yo + 0.5f) - 0.5f, sx = sw * ((float)xo + 0.5f) - 0.5f;
+    if (!bicubic) {
+      sy = sy < 0.0f ? 0.0f : sy;
+      sx = sx < 0.0f ? 0.0f : sx;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+      const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+      out[i] = ly0 * (lx0 * p[(long)y0 * W + x0] + lx1 * p[(long)y0 * W + x1]) +
+               ly1 * (lx0 * p[(long)y1 * W + x0] + lx1 * p[(long)y1 * W + x1]);
+    } else {
+      const float fy = floorf(sy), fx = floorf(sx);
+      const int iy = (int)fy, ix = (int)fx;
+      const float ty = sy - fy, tx = sx - fx;
+      const float A = -0.75f;
+      const float wy[4] = {cubic2(ty + 1.0f, A), cubic1(ty, A), cubic1(1.0f - ty, A), cubic2(2.0f - ty, A)};
+      const float wx[4] = {cubic2(tx + 1.0f, A), cubic1(tx, A), cubic1(1.0f - tx, A), cubic2(2.0f - tx, A)};
+      float acc = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        int yy = iy - 1 + a;
+        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+        float row = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          int xx = ix - 1 + b;
+          xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+          row += p[(long)yy * W + xx] * wx[b];
+        }
+        acc += row * wy[a];
+      }
+      out[i] = acc;
+    }
+  }
+}
+
 // stage-2 glue (notebooks/infer_s2.py:365-375)
 __global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ img, const float* __restrict__ mask,
                                                        float* __restrict__ out, long N, int C, long HW) {
@@ -152,5 +204,13 @@ extern "C" int emo_stage2_compose_f32(const float* img, const float* add, const 
   if (!img || !add || !mask || !face_mask || !out || N <= 0 || C <= 0 || HW <= 0) return EMO_ERR_BAD_ARG;
   hipLaunchKernelGGL(stage2_compose_kernel, dim3(grid_for((long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, img,
                      add, mask, face_mask, out, (long)N, C, (long)HW);
+  return emo_launch_status();
+}
+
+extern "C" int emo_resize2d_f32(const float* x, float* out, int64_t NC, int H, int W, int Ho, int Wo, int bicubic,
+                                void* stream) {
+  if (!x || !out || NC <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return EMO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(resize2d_kernel, dim3(grid_for(NC * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, out, (long)NC,
+                     H, W, Ho, Wo, bicubic);
   return emo_launch_status();
 }

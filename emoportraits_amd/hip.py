@@ -31,6 +31,7 @@ SIGNATURES = {
     "emo_upsample_trilinear_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_add_f32": [_c_void, _c_void, _c_void, _c_i64, _c_i64, _c_float, _c_void],
+    "emo_resize2d_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 5 + [_c_void],
     "emo_mul_mask_f32": [_c_void, _c_void, _c_void, _c_int, _c_int, _c_i64, _c_void],
     "emo_stage2_compose_f32": [_c_void] * 5 + [_c_int, _c_int, _c_i64, _c_void],
     "emo_small_gemm_f32": [_c_void] * 3 + [_c_int] * 4 + [_c_i64, _c_i64, _c_void],

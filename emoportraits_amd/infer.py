@@ -168,10 +168,10 @@ class InferenceWrapper:
 
     def _prepare_image(self, image):
         S = self.cfg["image_size"]
-        t = self.convert_to_tensor(image)[:, :3]
+        t = self.convert_to_tensor(image)[:, :3].to(self.device).contiguous()
         if t.shape[-2:] != (S, S):
-            t = torch.nn.functional.interpolate(t, size=(S, S), mode='bicubic')    # infer.py:399-401 (host glue)
-        return t.to(self.device).contiguous()
+            t = ops.resize2d(t, (S, S), "bicubic")                                  # infer.py:399-401
+        return t
 
     def _theta_from(self, embed):
         """(scale, rotation, translation) as the reference's custome_target_theta_embed (-> get_transform_matrix,

@@ -104,18 +104,12 @@ def volume_to_channels_first(vol):
 # ----------------------------------------------------------------------------------------------------------------
 # GroupNorm -> per-(sample, channel) affine
 # ----------------------------------------------------------------------------------------------------------------
-_gn_ws = {}
-
-
 def _gn_workspace(N, G, device):
+    """per-call scratch for the split partial sums (stream-ordered through torch's caching allocator, so concurrent
+    streams never share it)"""
     lib = hip.load()
     need = lib.emo_groupnorm_workspace_bytes(N, G)
-    key = device.index
-    buf = _gn_ws.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
-        _gn_ws[key] = buf
-    return buf, need
+    return torch.empty(need, dtype=torch.uint8, device=device), need
 
 
 def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, groups=32, eps=1e-5, want_stats=False):
@@ -307,4 +301,16 @@ def stage2_compose(img, add_img, mask, face_mask):
     out = torch.empty_like(img)
     hip.check(lib.emo_stage2_compose_f32(hip.ptr(img), hip.ptr(add_img), hip.ptr(mask), hip.ptr(face_mask), hip.ptr(out),
                                          N, C, H * W, hip.current_stream()), "emo_stage2_compose_f32")
+    return out
+
+
+def resize2d(x, size, mode="bilinear"):
+    """F.interpolate(x, size=size, mode=mode, align_corners=False) for 4-D x; mode 'bilinear' or 'bicubic'"""
+    lib = hip.load()
+    hip.require_cuda_f32(x)
+    N, C, H, W = x.shape
+    Ho, Wo = size
+    out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    hip.check(lib.emo_resize2d_f32(hip.ptr(x), hip.ptr(out), N * C, H, W, Ho, Wo, {"bilinear": 0, "bicubic": 1}[mode],
+                                   hip.current_stream()), "emo_resize2d_f32")
     return out

@@ -259,8 +259,7 @@ class InferenceWrapper:
         S2 = self.cfg["output_size_s2"]
         img = img.to(self.device).float().contiguous()
         if img.shape[-1] != S2 or img.shape[-2] != S2:
-            raise RuntimeError(f"stage-2 input must already be {S2}x{S2} (the reference resizes with bilinear "
-                               "F.interpolate, infer_s2.py:360-362: host/torch glue outside the hot path)")
+            img = ops.resize2d(img, (S2, S2), "bilinear")                          # infer_s2.py:360-362
         if mask is None:
             if 'matting' not in self.embedders:
                 raise RuntimeError("stage 2 needs the MODNet matte: pass mask= or embedders={'matting': fn}")

@@ -141,6 +141,10 @@ int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC, int D, in
 int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int kd, int kh, int kw, void* stream);
 int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, float alpha, void* stream);
 
+/* f4 -- F.interpolate(x, size=(Ho, Wo), mode='bilinear' (bicubic = 0) | 'bicubic' (1), align_corners=False) on
+ * [NC, H, W] planes: the wrappers' crop resize (notebooks/infer.py:399-401,548-552; notebooks/infer_s2.py:360-362). */
+int emo_resize2d_f32(const float* x, float* out, int64_t NC, int H, int W, int Ho, int Wo, int bicubic, void* stream);
+
 /* stage-2 glue (notebooks/infer_s2.py:365-375):
  *   emo_mul_mask_f32:        out[n,c,p] = img[n,c,p] * mask[n,0,p]            (local_encoder input, :370)
  *   emo_stage2_compose_f32:  out = clamp(img + add * (mask * face_mask), 0, 1)   (:365,373-375); masks are [N,1,H,W] */

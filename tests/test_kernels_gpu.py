@@ -264,3 +264,14 @@ def test_pose_theta_and_pack(golden_dir):
     img = torch.rand(2, 3, 16, 24, generator=torch.Generator().manual_seed(9)) * 1.4 - 0.2
     ref = img.clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1)
     assert torch.equal(ops.pack_rgb8(img.to(DEV)).cpu(), ref)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+@pytest.mark.parametrize("sizes", [((37, 53), (64, 64)), ((128, 96), (48, 80)), ((64, 64), (64, 64)), ((256, 256), (512, 512))])
+def test_resize2d_matches_interpolate(mode, sizes):
+    (H, W), (Ho, Wo) = sizes
+    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(H + Wo))
+    ref = F.interpolate(x, size=(Ho, Wo), mode=mode, align_corners=False)
+    got = ops.resize2d(x.to(DEV), (Ho, Wo), mode)
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max().item() <= 2e-6
