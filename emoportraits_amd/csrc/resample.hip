@@ -4,7 +4,8 @@
 //                               scale factors 1 or 2 per axis: WarpGenerator.forward
 //                               (networks/volumetric_avatar/warp_generator_resnet.py:163-166) and Unet3D.forward
 //                               (unet_3d.py:223,269-272).
-//   emo_avgpool_f32             nn.AvgPool3d / AvgPool2d with kernel == stride in {1,2} per axis
+//   emo_avgpool_f32             nn.AvgPool3d / AvgPool2d with kernel == stride in 1..16 per axis (also the integer-window
+//                               AdaptiveAvgPool2d of the embedders: identity_embedder.py:33, expression_embedder.py:394,408)
 //                               (downsampling_layers['avgpool'(_3d)], utils.py:962-967; warp_generator_resnet.py:118,
 //                               unet_3d.py:84-86,192-193, local_encoder.py via ResBlock stride 2).
 //   emo_add_f32                 out = (a + b[i % period]) * alpha  (Unet3D skip sum unet_3d.py:281; embed mix va.py:857).
@@ -176,7 +177,7 @@ extern "C" int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC
 extern "C" int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int kd, int kh, int kw,
                                void* stream) {
   if (!x || !out || NC <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
-  if (kd < 1 || kh < 1 || kw < 1 || kd > 2 || kh > 2 || kw > 2) return EMO_ERR_UNSUPPORTED;
+  if (kd < 1 || kh < 1 || kw < 1 || kd > 16 || kh > 16 || kw > 16) return EMO_ERR_UNSUPPORTED;
   if (D % kd || H % kh || W % kw) return EMO_ERR_UNSUPPORTED;
   const long total = NC * (D / kd) * (H / kh) * (W / kw);
   hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, (long)NC, D, H,

@@ -107,6 +107,56 @@ __global__ __launch_bounds__(256) void pack_rgb8_kernel(const float* __restrict_
   }
 }
 
+// inverse of B 4x4 matrices (head-pose affines: notebooks/infer.py:443, expression_embedder.py:185-188 call
+// `theta.float().inverse()`): Gauss-Jordan with partial pivoting in double, one thread per matrix.
+__global__ __launch_bounds__(64) void mat4_inverse_kernel(const float* __restrict__ in, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  double m[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[i][j] = (double)in[b * 16 + i * 4 + j];
+      m[i][4 + j] = i == j ? 1.0 : 0.0;
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    double best = fabs(m[c][c]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r > c && fabs(m[r][c]) > best) {
+        best = fabs(m[r][c]);
+        piv = r;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r == piv && piv != c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double t = m[c][j];
+          m[c][j] = m[r][j];
+          m[r][j] = t;
+        }
+      }
+    const double inv = 1.0 / m[c][c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[c][j] *= inv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r != c) {
+        const double f = m[r][c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[b * 16 + i * 4 + j] = (float)m[i][4 + j];
+}
+
 }  // namespace
 
 extern "C" int emo_small_gemm_f32(const float* A, const float* B, float* C, int M, int K, int NN, int batch,
@@ -151,5 +201,11 @@ extern "C" int emo_pack_rgb8(const float* img, uint8_t* out, int N, int H, int W
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(pack_rgb8_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, out, (long)N,
                      (long)H * W);
+  return emo_launch_status();
+}
+
+extern "C" int emo_mat4_inverse_f32(const float* in, float* out, int B, void* stream) {
+  if (!in || !out || B <= 0) return EMO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(mat4_inverse_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, B);
   return emo_launch_status();
 }

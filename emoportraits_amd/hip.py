@@ -32,6 +32,11 @@ SIGNATURES = {
     "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_add_f32": [_c_void, _c_void, _c_void, _c_i64, _c_i64, _c_float, _c_void],
     "emo_resize2d_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 5 + [_c_void],
+    "emo_conv2d_generic_f32": [_c_void] * 6 + [_c_int] * 10 + [_c_void],
+    "emo_maxpool2d_f32": [_c_void] * 4 + [_c_i64] + [_c_int] * 6 + [_c_void],
+    "emo_affine_add_relu_f32": [_c_void] * 7 + [_c_i64, _c_i64, _c_int, _c_void],
+    "emo_grid_sample2d_f32": [_c_void] * 6 + [_c_int] * 6 + [_c_void],
+    "emo_mat4_inverse_f32": [_c_void, _c_void, _c_int, _c_void],
     "emo_mul_mask_f32": [_c_void, _c_void, _c_void, _c_int, _c_int, _c_i64, _c_void],
     "emo_stage2_compose_f32": [_c_void] * 5 + [_c_int, _c_int, _c_i64, _c_void],
     "emo_small_gemm_f32": [_c_void] * 3 + [_c_int] * 4 + [_c_i64, _c_i64, _c_void],

@@ -5,13 +5,17 @@ same files (`<project_dir>/<folder>/<experiment_name>/args.txt`, `.../checkpoint
 attributes after a source call (`idt_embed`, `source_latent_volume`, `target_latent_volume`, `pred_source_theta`, ...)
 and the same return value `(List[PIL.Image], Tensor[B,3,S,S])` / `None`.
 
-What is NOT here, by scope ("next"): the third-party nets the reference calls around the hot path --
-face detector / cropper (mediapipe), face parsing (BiSeNet), matting (MODNet), IdtEmbed (ResNet-50), ExpressionEmbed and
-HeadPoseRegressor (ResNet-18s).  They plug in through `embedders=` (any callables, e.g. the reference's own torch
-modules); without them `forward` needs `crop=False` plus the embeddings those nets would have produced, through the
-reference's own hooks `custome_target_pose_embed` / `custome_target_theta_embed` (infer.py:565-566,603-604) and their
-source-side counterparts added here (`custome_source_pose_embed`, `custome_source_theta_embed`, `custome_idt_embed`).
-Missing pieces raise -- nothing falls back silently.
+The embedders that feed the hot path -- IdtEmbed (ResNet-50), ExpressionEmbed and HeadPoseRegressor (ResNet-18s), SURVEY.md
+section 8f-1 -- run on the HIP kernels too (emoportraits_amd/embedders.py): they are built from the `idt_embedder_nw.*` /
+`expression_embedder_nw.*` keys of the checkpoint and from `head_pose_regressor_path` (args.txt or constructor argument,
+va_arguments.py:26) whenever those are present.
+
+What is NOT here, by scope: the third-party nets outside the checkpoint -- face detector / cropper (mediapipe), face
+parsing (BiSeNet), matting (MODNet).  They plug in through `embedders=` (any callables; an entry there also overrides a
+native embedder); without them `forward` needs `crop=False` and `source_mask=`.  Embeddings can also be supplied directly
+through the reference's own hooks `custome_target_pose_embed` / `custome_target_theta_embed` (infer.py:565-566,603-604)
+and their source-side counterparts added here (`custome_source_pose_embed`, `custome_source_theta_embed`,
+`custome_idt_embed`).  Missing pieces raise -- nothing falls back silently.
 
 Extension over the reference (which is batch-1, F5): driver inputs may carry a batch dimension, and
 `animate()` streams N driver frames in device-sized batches, sharded across ranks (emoportraits_amd/parallel.py).
@@ -23,6 +27,7 @@ from argparse import Namespace
 import torch
 
 from . import config as cfg_mod
+from . import embedders as emb_mod
 from . import nets, ops, parallel, schema
 
 
@@ -88,7 +93,7 @@ class InferenceWrapper:
     def __init__(self, experiment_name, which_epoch='latest', model_file_name='', use_gpu=True, num_gpus=1,
                  fixed_bounding_box=False, project_dir='./', folder='mp_logs', model_='va',
                  torch_home='', debug=False, print_model=False, print_params=True, args_overwrite={}, state_dict=None,
-                 pose_momentum=0.5, rank=0, args_path=None, embedders=None):
+                 pose_momentum=0.5, rank=0, args_path=None, embedders=None, head_pose_regressor_path=None):
         if not use_gpu:
             raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
         if model_ != 'va':
@@ -124,7 +129,7 @@ class InferenceWrapper:
         if rank == 0 and print_params:
             n = sum(v.numel() for k, v in self.model_dict.items() if k.startswith(schema.HOT_PATH_PREFIXES))
             print(f'Number of hot-path parameters: {n}')
-        self.embedders = dict(embedders or {})
+        self.embedders = {**self._native_embedders(found, head_pose_regressor_path), **dict(embedders or {})}
 
         self.fixed_bounding_box = fixed_bounding_box
         self.momentum = 0.01
@@ -141,12 +146,30 @@ class InferenceWrapper:
         self._canonical_cl = None
 
     # ------------------------------------------------------------------------------------------------------
+    def _native_embedders(self, found, head_pose_regressor_path):
+        """IdtEmbed / ExpressionEmbed from the checkpoint (va.py:161,165), HeadPoseRegressor from its own file (va.py:258)"""
+        out = {}
+        sd = self.model_dict
+        has = lambda p: any(k.startswith(p) for k in sd)
+        if has("idt_embedder_nw.") or has("expression_embedder_nw."):
+            ecfg = emb_mod.embedder_config(found, released='norm_layer_type' not in found)
+            self.embedder_cfg = ecfg
+            if has("idt_embedder_nw."):
+                out['idt_embedder'] = emb_mod.IdtEmbed(sd, ecfg, self.device)
+            if has("expression_embedder_nw."):
+                out['expression_embedder'] = emb_mod.ExpressionEmbed(sd, ecfg, self.device)
+        path = head_pose_regressor_path or found.get('head_pose_regressor_path')
+        if head_pose_regressor_path is not None or (path and os.path.isfile(str(path))):
+            out['head_pose_regressor'] = emb_mod.HeadPoseRegressor(torch.load(path, map_location='cpu'), self.device)
+        return out
+
     def _need(self, name, what):
         fn = self.embedders.get(name)
         if fn is None:
             raise RuntimeError(
-                f"{what} needs the third-party '{name}' network, which is outside the MI355X hot path: pass it via "
-                f"InferenceWrapper(embedders={{'{name}': callable}}) or supply its output through the custome_* arguments")
+                f"{what} needs the '{name}' network: its weights were not found (checkpoint keys / "
+                f"head_pose_regressor_path) and it was not passed via InferenceWrapper(embedders={{'{name}': callable}}); "
+                f"alternatively supply its output through the custome_* arguments")
         return fn
 
     def convert_to_tensor(self, image):

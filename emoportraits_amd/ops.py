@@ -314,3 +314,76 @@ def resize2d(x, size, mode="bilinear"):
     hip.check(lib.emo_resize2d_f32(hip.ptr(x), hip.ptr(out), N * C, H, W, Ho, Wo, {"bilinear": 0, "bicubic": 1}[mode],
                                    hip.current_stream()), "emo_resize2d_f32")
     return out
+
+
+# ---- embedder ResNets -----------------------------------------------------------------------
+def conv2d_generic(x, wt, cout, kh, kw, stride, pad, bias=None, scale=None, shift=None, relu_in=False):
+    """F.conv2d(relu?(x*scale+shift), w, bias, stride, pad); wt = pack.pack_generic(w) [Cin*kh*kw, CoutP]"""
+    lib = hip.load()
+    hip.require_cuda_f32(x)
+    N, Cin, H, W = x.shape
+    if wt.shape[0] != Cin * kh * kw:
+        raise ValueError(f"packed weight has K={wt.shape[0]}, input needs {Cin * kh * kw}")
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    hip.check(lib.emo_conv2d_generic_f32(hip.ptr(x), hip.ptr(wt), hip.ptr(bias), hip.ptr(scale), hip.ptr(shift),
+                                         hip.ptr(out), N, Cin, H, W, cout, kh, kw, stride, pad, int(relu_in),
+                                         hip.current_stream()), "emo_conv2d_generic_f32")
+    return out
+
+
+def maxpool2d(x, k, stride, pad, scale=None, shift=None, relu=False):
+    lib = hip.load()
+    hip.require_cuda_f32(x)
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    hip.check(lib.emo_maxpool2d_f32(hip.ptr(x), hip.ptr(scale), hip.ptr(shift), hip.ptr(out), N * C, H, W, k, stride,
+                                    pad, int(relu), hip.current_stream()), "emo_maxpool2d_f32")
+    return out
+
+
+def affine_add_relu(a, sa=None, ta=None, b=None, sb=None, tb=None, relu=True):
+    """relu?((a*sa+ta) + (b*sb+tb)) with per-(n,c) affines"""
+    lib = hip.load()
+    hip.require_cuda_f32(a)
+    N, C = a.shape[:2]
+    S = a.numel() // (N * C)
+    if b is not None and b.shape != a.shape:
+        raise ValueError("affine_add_relu: shape mismatch")
+    out = torch.empty_like(a)
+    hip.check(lib.emo_affine_add_relu_f32(hip.ptr(a), hip.ptr(sa), hip.ptr(ta), hip.ptr(b), hip.ptr(sb), hip.ptr(tb),
+                                          hip.ptr(out), N * C, S, int(relu), hip.current_stream()),
+              "emo_affine_add_relu_f32")
+    return out
+
+
+def grid_sample2d(img, grid=None, theta=None, size=None, want_grid=False):
+    """F.grid_sample(img, grid) (bilinear, zeros, align_corners=False); or theta [N,2,3] on the square
+    linspace(-1,1,size) lattice of ExpressionEmbed"""
+    lib = hip.load()
+    hip.require_cuda_f32(img)
+    N, C, H, W = img.shape
+    lin = None
+    if grid is not None:
+        Ho, Wo = grid.shape[1:3]
+    else:
+        Ho = Wo = int(size)
+        lin = _lattice(Ho, img.device.index)
+        theta = theta.float().contiguous()
+    out = torch.empty((N, C, Ho, Wo), device=img.device, dtype=torch.float32)
+    gout = torch.empty((N, Ho, Wo, 2), device=img.device, dtype=torch.float32) if want_grid else None
+    hip.check(lib.emo_grid_sample2d_f32(hip.ptr(img), hip.ptr(grid), hip.ptr(theta), hip.ptr(lin), hip.ptr(out),
+                                        hip.ptr(gout), N, C, H, W, Ho, Wo, hip.current_stream()), "emo_grid_sample2d_f32")
+    return (out, gout) if want_grid else out
+
+
+def mat4_inverse(m):
+    """[B,4,4] -> inverse, on the device (no host LAPACK round trip)"""
+    lib = hip.load()
+    hip.require_cuda_f32(m)
+    if m.shape[1:] != (4, 4):
+        raise ValueError("mat4_inverse expects [B,4,4]")
+    out = torch.empty_like(m)
+    hip.check(lib.emo_mat4_inverse_f32(hip.ptr(m), hip.ptr(out), m.shape[0], hip.current_stream()), "emo_mat4_inverse_f32")
+    return out

@@ -45,6 +45,16 @@ def folded_conv(sd, prefix, kind):
     return w, (None if b is None else b.float())
 
 
+def pack_generic(w):
+    """[Cout,Cin,KH,KW] -> [Cin*KH*KW, CoutP] (CoutP = Cout rounded up to 64, zero padded): the operand layout of
+    emo_conv2d_generic_f32 (include/emo_hip.h)"""
+    cout = w.shape[0]
+    coutp = (cout + 63) // 64 * 64
+    wt = torch.zeros((w[0].numel(), coutp), dtype=torch.float32)
+    wt[:, :cout] = w.reshape(cout, -1).t()
+    return wt.contiguous()
+
+
 def choose_cfg(cout):
     """block config minimising padded output channels; ties go to the larger tile"""
     best = None

@@ -133,7 +133,8 @@ int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias,
  * resampling / pointwise helpers (HBM-bound, one pass)
  *   emo_upsample_trilinear_f32: F.interpolate(x, scale_factor=(fd,fh,fw), mode='trilinear'), factors in {1,2}
  *       (warp_generator_resnet.py:163-166; unet_3d.py:223,269-272).  x [NC, D, H, W] -> [NC, D*fd, H*fh, W*fw]
- *   emo_avgpool_f32: nn.AvgPool2d/3d with kernel == stride in {1,2} per axis (utils.py:962-967)
+ *   emo_avgpool_f32: nn.AvgPool2d/3d with kernel == stride in 1..16 per axis (utils.py:962-967; integer-window
+ *       AdaptiveAvgPool2d of the embedders)
  *   emo_add_f32: out[i] = (a[i] + b[i % period]) * alpha   (unet_3d.py:281; va.py:857)
  */
 int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC, int D, int H, int W,
@@ -144,6 +145,30 @@ int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t p
 /* f4 -- F.interpolate(x, size=(Ho, Wo), mode='bilinear' (bicubic = 0) | 'bicubic' (1), align_corners=False) on
  * [NC, H, W] planes: the wrappers' crop resize (notebooks/infer.py:399-401,548-552; notebooks/infer_s2.py:360-362). */
 int emo_resize2d_f32(const float* x, float* out, int64_t NC, int H, int W, int Ho, int Wo, int bicubic, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f1 -- embedder ResNets (networks/volumetric_avatar/identity_embedder.py:59-69, expression_embedder.py:424-459,
+ * head_pose_regressor.py:21-32; bodies = torchvision.models.resnet*).
+ *
+ * emo_conv2d_generic_f32: F.conv2d(x', w, bias, stride, padding) with x' = relu?(x * scale[n,c] + shift[n,c]) when
+ *   scale/shift are given (the producer's norm + ReLU, applied before zero padding), any KH x KW / stride / pad.
+ *   wt is the folded weight transposed to [Cin*KH*KW][CoutP] (k = (ci*KH + ky)*KW + kx, CoutP = Cout rounded up to 64,
+ *   zero padded).  x [N,Cin,H,W], out [N,Cout,Ho,Wo].
+ * emo_maxpool2d_f32:   nn.MaxPool2d(k, stride, pad) of relu?(x * scale + shift) (scale/shift [NC] or NULL).
+ * emo_affine_add_relu_f32: out = relu?((a*sa+ta) + (b*sb+tb)), per-(n,c) affines optional, b optional: the tail of
+ *   BasicBlock / Bottleneck.forward.
+ * emo_grid_sample2d_f32: F.grid_sample(img, grid) 4-D bilinear / zeros / align_corners=False; either an explicit
+ *   grid [N,Ho,Wo,2] or theta [N,2,3] + lin [Ho] (grid = theta @ (lin[xo], lin[yo], 1): expression_embedder.py:221-231);
+ *   grid_out (optional) receives the grid that was used. */
+int emo_conv2d_generic_f32(const float* x, const float* wt, const float* bias, const float* scale, const float* shift,
+                           float* out, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                           int relu_in, void* stream);
+int emo_maxpool2d_f32(const float* x, const float* scale, const float* shift, float* out, int64_t NC, int H, int W,
+                      int k, int stride, int pad, int relu, void* stream);
+int emo_affine_add_relu_f32(const float* a, const float* sa, const float* ta, const float* b, const float* sb,
+                            const float* tb, float* out, int64_t NC, int64_t S, int relu, void* stream);
+int emo_grid_sample2d_f32(const float* img, const float* grid, const float* theta, const float* lin, float* out,
+                          float* grid_out, int N, int C, int H, int W, int Ho, int Wo, void* stream);
 
 /* stage-2 glue (notebooks/infer_s2.py:365-375):
  *   emo_mul_mask_f32:        out[n,c,p] = img[n,c,p] * mask[n,0,p]            (local_encoder input, :370)
@@ -169,6 +194,8 @@ int emo_projector_finalize_f32(const float* T, const float* V, const int* norm_o
                                const float* beta, float* ada_gamma, float* ada_beta, int B, int R, int E, void* stream);
 int emo_pose_theta_f32(const float* scale, int scale_cols, const float* rotation, const float* translation,
                        float* theta, int B, void* stream);
+/* inverse of B row-major 4x4 matrices (`theta.float().inverse()`: notebooks/infer.py:443, expression_embedder.py:185-188) */
+int emo_mat4_inverse_f32(const float* in, float* out, int B, void* stream);
 int emo_pack_rgb8(const float* img, uint8_t* out, int N, int H, int W, void* stream);
 
 #ifdef __cplusplus

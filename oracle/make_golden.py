@@ -13,6 +13,7 @@ Fixtures
                      coordinates, three padding modes.
   pose_theta.npz     utils/point_transforms.py:188-242 get_transform_matrix + the rotation warp of
                      va.py:101-105 / notebooks/infer.py:441-444,583-588 (incl. rotation clamp edge cases).
+  embedders.pt       seeds + outputs of the reference's IdtEmbed / HeadPoseRegressor / ExpressionEmbed at full width.
   tiny_hotpath.pt    reduced-width released architecture (same code paths: SN, WS, ada-GN, up/down sampling):
                      raw state_dict + synthetic inputs + per-stage outputs of the reference source and driver passes.
 """
@@ -160,6 +161,43 @@ def tiny_stage2():
     print("tiny_stage2.pt", os.path.getsize(path) / 1e6, "MB;", len(sd), "tensors")
 
 
+def embedders_golden():
+    """SURVEY.md section 8f-1.  The backbones are full-width by construction (the reference hard-codes 512 * expansion
+    channels, identity_embedder.py:37 / expression_embedder.py:381), ~150 MB of weights -- too large for git.  The fixture
+    therefore stores SEEDS + the reference's outputs: weights and inputs are regenerated on the test side with
+    emoportraits_amd.embedders.random_state_dict (a CPU torch.Generator stream), and `checksums` guards that regeneration.
+    Loading those state_dicts into the reference's own modules with strict=True also pins the checkpoint key schema."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from emoportraits_amd import embedders as E
+    args = R.released_args(512)
+    h = R.build_embedder_holder(args, seed=0)
+    cfg = E.embedder_config(vars(args), released=False)
+    seeds = dict(idt=11, expression=12, head_pose=13, inputs=14)
+    sd_i = E.random_state_dict(E.idt_schema(cfg), seeds["idt"])
+    sd_e = E.random_state_dict(E.expression_schema(cfg), seeds["expression"])
+    sd_h = E.random_state_dict(E.head_pose_schema(), seeds["head_pose"])
+    buffers = {k: v for k, v in h.state_dict().items() if k.endswith(E._BUFFERS)}
+    h.load_state_dict({**sd_i, **sd_e, **buffers}, strict=True)
+    h.head_pose_regressor.net.load_state_dict(sd_h, strict=True)
+    g = torch.Generator().manual_seed(seeds["inputs"])
+    crops = torch.rand(2, 3, 512, 512, generator=g)
+    from utils import point_transforms
+    theta = point_transforms.get_transform_matrix(1 + 0.05 * torch.randn(2, 3, generator=g),
+                                                  0.3 * torch.randn(2, 3, generator=g), 0.05 * torch.randn(2, 3, generator=g))
+    idt = R.reference_idt_embed(h, crops[:1])
+    hp = R.reference_head_pose(h, crops)
+    ex = R.reference_expression(h, crops, theta)
+    ex_own = R.reference_expression(h, crops, hp["theta"])        # the wrapper's real chain: pose net -> alignment
+    checks = {n: float(sum(v.double().sum() for v in sd.values())) for n, sd in (("idt", sd_i), ("expression", sd_e), ("head_pose", sd_h))}
+    checks["crops"] = float(crops.double().sum())
+    blob = dict(cfg=cfg, seeds=seeds, checksums=checks, theta=theta, idt_embed=idt, head_pose=hp,
+                pose_embed=ex["pose_embed"], img_align_sub=ex["img_align"][:, :, ::8, ::8].clone(),
+                align_warp_sub=ex["align_warp"][:2, ::8, ::8].clone(), pose_embed_chain=ex_own["pose_embed"])
+    path = os.path.join(OUT, "embedders.pt")
+    torch.save(blob, path)
+    print("embedders.pt", os.path.getsize(path) / 1e3, "KB", checks)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -167,3 +205,4 @@ if __name__ == "__main__":
     pose_theta()
     tiny_hotpath()
     tiny_stage2()
+    embedders_golden()

@@ -72,6 +72,13 @@ def install():
     pkg = types.ModuleType("EmoPortraits")
     pkg.__path__ = [REF_ROOT]
     sys.modules["EmoPortraits"] = pkg
+    # torchvision is absent: the embedders' `torchvision.models.resnet*` constructors resolve to the restated
+    # architecture in oracle/tv_resnet.py (see its header for what that does and does not pin)
+    import torchvision as _tv_stub
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tv_resnet
+    _tv_stub.models = tv_resnet
+    sys.modules["torchvision.models"] = tv_resnet
     _installed = True
 
 
@@ -347,3 +354,70 @@ def make_trained_like(holder, iters=8):
                     v.copy_(torch.nn.functional.normalize(torch.mv(w.t(), u), dim=0))
                     u.copy_(torch.nn.functional.normalize(torch.mv(w, v), dim=0))
     return holder
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# embedders: identity_embedder.py, expression_embedder.py, head_pose_regressor.py
+# ----------------------------------------------------------------------------------------------------------------
+def build_embedder_holder(args, seed=0):
+    """idt_embedder_nw / expression_embedder_nw of va.Model (va.py:161,165) with weight_init -> spectral norm -> weight
+    standardisation applied as Model.__init__ does (va.py:86,113-118), plus the HeadPoseRegressor object (va.py:258;
+    its external head_pose_regressor.pth is not in the tree, so the resnet18(num_classes=9) keeps a seeded random init)."""
+    install()
+    import contextlib
+    import io
+    import torch
+    from torch import nn
+    from networks import volumetric_avatar
+    from models.stage_1.volumetric_avatar.va_arguments import VolumetricAvatarConfig
+    from utils import weight_init, spectral_norm
+    import tv_resnet
+
+    torch.manual_seed(seed)
+
+    class Holder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.args = args
+            self.rank = 0
+            cfg = VolumetricAvatarConfig(args)
+            self.idt_embedder_nw = volumetric_avatar.IdtEmbed(cfg.idt_embedder_cfg)                  # va.py:161
+            self.expression_embedder_nw = volumetric_avatar.ExpressionEmbed(cfg.exp_embedder_cfg)    # va.py:165
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        h = Holder()
+        h.apply(weight_init.weight_init(args.init_type, args.init_gain))
+        if args.use_sn:
+            spectral_norm.apply_sp_to_nets(h)
+        if args.use_ws:
+            volumetric_avatar.utils.apply_ws_to_nets(h)
+        hpr = volumetric_avatar.HeadPoseRegressor.__new__(volumetric_avatar.HeadPoseRegressor)   # head_pose_regressor.py:12-19
+        hpr.net = tv_resnet.resnet18(num_classes=9)
+        hpr.net.eval()
+    h.eval()
+    h.head_pose_regressor = hpr      # a plain object, as in the reference (not an nn.Module: no SN / WS / GN swap)
+    return h
+
+
+def reference_idt_embed(h, masked_source):
+    """notebooks/infer.py:432"""
+    import torch
+    with torch.no_grad():
+        return h.idt_embedder_nw.forward_image(masked_source)
+
+
+def reference_head_pose(h, crop):
+    """notebooks/infer.py:437 / :562"""
+    theta, scale, rotation, translation = h.head_pose_regressor.forward(crop, True)
+    return dict(theta=theta, scale=scale, rotation=rotation, translation=translation)
+
+
+def reference_expression(h, crop, theta):
+    """notebooks/infer.py:596-606 (driver side; the source side, :445-455, is the same call on the source crop).  The mask
+    entries are unused with use_seg=False."""
+    import torch
+    dd = {"source_img": crop, "source_mask": None, "source_theta": theta,
+          "target_img": crop, "target_mask": None, "target_theta": theta}
+    with torch.no_grad():
+        dd = h.expression_embedder_nw(dd, True, False)
+    return dict(pose_embed=dd["target_pose_embed"], img_align=dd["target_img_align"], align_warp=dd["align_warp"])

@@ -545,3 +545,114 @@ def stage2_forward(sd, cfg2, img, mask, face_mask):
     add = decoder_stage2(sd, "decoder", lat, cfg2)
     out = (img + add * (mask * face_mask)).clamp(max=1, min=0)
     return dict(latents=lat, add=add, out=out)
+
+
+# ----------------------------------------------------------------------------------------------
+# f1: embedders.  ResNet body: torchvision 0.9.1 `models.resnet*` -- a third-party
+# dependency absent here, restated from the published architecture (see oracle/tv_resnet.py for the parity status);
+# everything around it follows the reference files cited per function.
+# ----------------------------------------------------------------------------------------------
+RESNET_LAYERS = {"resnet18": ("basic", (2, 2, 2, 2)), "resnet34": ("basic", (3, 4, 6, 3)),
+                 "resnet50": ("bottleneck", (3, 4, 6, 3))}
+IMAGENET_MEAN = (0.485, 0.456, 0.406)     # identity_embedder.py:56-57, expression_embedder.py:421-422
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _resnet_conv(x, sd, prefix, stride, padding):
+    """conv of a (possibly wrapped) torchvision ResNet: spectral norm leaves `weight_orig/_u/_v`
+    (utils/spectral_norm.py:96-168), the WS replacement leaves `weight` + a new `bias` (utils.py:1080-1083), an
+    untouched torchvision conv has `weight` only (head_pose_regressor.py:14)."""
+    if (prefix + ".weight_orig") in sd:
+        w, b = sn_weight(sd, prefix), None
+    elif (prefix + ".bias") in sd:
+        w, b = ws_weight(sd[prefix + ".weight"]), sd[prefix + ".bias"]
+    else:
+        w, b = sd[prefix + ".weight"], None
+    return F.conv2d(x, w, b, stride=stride, padding=padding)
+
+
+def resnet_trunk(sd, prefix, x, arch):
+    """conv1 .. layer4 of torchvision's ResNet.forward (what IdtEmbed._forward_impl identity_embedder.py:59-69 and
+    ResNetWrapper._forward_impl expression_embedder.py:424-439 call); norms are GroupNorm(32) after replace_bn_to_gn
+    (utils.py:1020-1038) or eval BatchNorm, told apart by the running statistics in the state_dict."""
+    kind, counts = RESNET_LAYERS[arch]
+    norm = lambda t, p: group_norm(t, sd, p)
+    x = F.relu(norm(_resnet_conv(x, sd, prefix + ".conv1", 2, 3), prefix + ".bn1"))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li, nblocks in enumerate(counts):
+        for bi in range(nblocks):
+            p = f"{prefix}.layer{li + 1}.{bi}"
+            stride = 2 if (li > 0 and bi == 0) else 1
+            identity = x
+            if kind == "basic":
+                out = F.relu(norm(_resnet_conv(x, sd, p + ".conv1", stride, 1), p + ".bn1"))
+                out = norm(_resnet_conv(out, sd, p + ".conv2", 1, 1), p + ".bn2")
+            else:
+                out = F.relu(norm(_resnet_conv(x, sd, p + ".conv1", 1, 0), p + ".bn1"))
+                out = F.relu(norm(_resnet_conv(out, sd, p + ".conv2", stride, 1), p + ".bn2"))
+                out = norm(_resnet_conv(out, sd, p + ".conv3", 1, 0), p + ".bn3")
+            if any(k.startswith(p + ".downsample.0.") for k in sd):
+                identity = norm(_resnet_conv(x, sd, p + ".downsample.0", stride, 0), p + ".downsample.1")
+            x = F.relu(out + identity)
+    return x
+
+
+def _imagenet_normalise(x):
+    mean = torch.tensor(IMAGENET_MEAN)[None, :, None, None]
+    std = torch.tensor(IMAGENET_STD)[None, :, None, None]
+    return (x - mean) / std
+
+
+def idt_embed(sd, prefix, masked_source, arch="resnet50", idt_image_size=256, idt_output_size=4):
+    """IdtEmbed.forward_image (identity_embedder.py:76-87): bilinear resize, ImageNet normalisation, trunk, the 1x1
+    `fc` conv BEFORE the adaptive average pool (:66-67)."""
+    x = F.interpolate(masked_source, size=(idt_image_size, idt_image_size), mode="bilinear")
+    x = resnet_trunk(sd, prefix + ".net", _imagenet_normalise(x), arch)
+    x = _resnet_conv(x, sd, prefix + ".net.fc", 1, 0)
+    return F.adaptive_avg_pool2d(x, idt_output_size)
+
+
+def head_pose(sd, crop):
+    """HeadPoseRegressor.forward (head_pose_regressor.py:21-32): bilinear resize to 128, torchvision resnet18 with a 9-way
+    fc, split into scale / rotation / translation, get_transform_matrix."""
+    if crop.shape[2] != 128 or crop.shape[3] != 128:
+        crop = F.interpolate(crop, size=(128, 128), mode="bilinear")
+    x = resnet_trunk({"net." + k: v for k, v in sd.items()}, "net", crop, "resnet18")
+    x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+    out = F.linear(x, sd["fc.weight"], sd["fc.bias"])
+    scale, rotation, translation = out.split([3, 3, 3], dim=1)
+    return dict(theta=get_transform_matrix(scale, rotation, translation), scale=scale, rotation=rotation,
+                translation=translation)
+
+
+def expression_align_theta(theta):
+    """expression_embedder.py:178-200 (use_smart_scale=False): 4x4 inverse, keep rows/cols (0,1,3) -> 2-D affine, then the
+    2x zoom-in `@ diag(0.5, 0.5, 1)`, first two rows."""
+    eye = torch.zeros(theta.shape[0], 1, 4)
+    eye[:, :, 3] = 1
+    t4 = torch.cat([theta[:, :3, :], eye], dim=1)
+    inv2d = t4.float().inverse()[:, :, [0, 1, 3]][:, [0, 1, 3]]
+    scale = torch.zeros_like(inv2d)
+    scale[:, [0, 1], [0, 1]] = 0.5
+    scale[:, 2, 2] = 1
+    return torch.bmm(inv2d, scale)[:, :2]
+
+
+def expression_embed(sd, prefix, crop, theta, arch="resnet18", exp_image_size=256, lpe_output_size=4):
+    """ExpressionEmbed.forward in the inference form notebooks/infer.py:452,601 calls it (estimate_kp_by_net=True,
+    use_seg=False, eval): align the crop with the inverse head pose (expression_embedder.py:176-222), then
+    ResNetWrapper.forward (:441-459) = ImageNet normalisation, trunk, 1x1 `fc` conv, (eval dropout), adaptive average
+    pool, flatten, spectral-norm Linear.  The reference runs it on cat(source, target) = the same crop twice; GroupNorm is
+    per sample, so one copy is computed."""
+    gs = exp_image_size // 2
+    lin = torch.linspace(-1, 1, gs)
+    v, u = torch.meshgrid(lin, lin, indexing="ij")
+    ident = torch.stack([u, v, torch.ones_like(u)], dim=2).view(1, -1, 3)
+    a = expression_align_theta(theta)
+    warp = ident.repeat_interleave(crop.shape[0], dim=0).bmm(a.transpose(1, 2)).view(crop.shape[0], gs, gs, 2)
+    aligned = F.grid_sample(crop.float(), warp.float(), align_corners=False)
+    p = prefix + ".net_face"
+    x = resnet_trunk(sd, p + ".net", _imagenet_normalise(aligned), arch)
+    x = _resnet_conv(x, sd, p + ".net.fc", 1, 0)
+    x = torch.flatten(F.adaptive_avg_pool2d(x, lpe_output_size), 1)
+    return dict(pose_embed=F.linear(x, sn_weight(sd, p + ".pose_head")), img_align=aligned, align_warp=warp)

@@ -112,6 +112,26 @@ def main():
         for k in ("latents", "add", "out"):
             results.append(stats(f"s2[{a2.norm_layer_type}].{k}", our2[k], ref2[k]))
 
+    print("embedders (section 8f-1): reference IdtEmbed / HeadPoseRegressor / ExpressionEmbed on the restated torchvision ResNets")
+    he = R.build_embedder_holder(args, seed=2)
+    R.make_trained_like(he)
+    R.randomize_affines(he, seed=9, scale=0.1)
+    R.randomize_bn_stats(he.head_pose_regressor.net)
+    sde = {k: v.detach().clone() for k, v in he.state_dict().items()}
+    sdh = {k: v.detach().clone() for k, v in he.head_pose_regressor.net.state_dict().items()}
+    ge = torch.Generator().manual_seed(3)
+    crops = torch.rand(2, 3, S, S, generator=ge)
+    with torch.no_grad():
+        results.append(stats("emb.idt_embed", O.idt_embed(sde, "idt_embedder_nw", crops[:1]), R.reference_idt_embed(he, crops[:1])))
+        rp, op = R.reference_head_pose(he, crops), O.head_pose(sdh, crops)
+        for k in rp:
+            results.append(stats("emb.head_pose." + k, op[k], rp[k]))
+        rex = R.reference_expression(he, crops, rp["theta"])
+        oex = O.expression_embed(sde, "expression_embedder_nw", crops, rp["theta"])
+        results.append(stats("emb.img_align", oex["img_align"], rex["img_align"]))
+        results.append(stats("emb.align_warp", oex["align_warp"], rex["align_warp"][:2]))
+        results.append(stats("emb.pose_embed", oex["pose_embed"], rex["pose_embed"]))   # reference batch is cat(src, tgt)
+
     summary = dict(image_size=S, torch=torch.__version__, threads=torch.get_num_threads(),
                    reference_source_s=t_ref, reference_driver_s=t_ref_d, results=results)
     if out:

@@ -112,3 +112,39 @@ def test_launch_config_heuristic():
     assert pack.choose_cfg_for_launch(256, 16) == pack.CFG_C
     assert pack.choose_cfg_for_launch(320, 4096) == pack.CFG_B
     assert pack.choose_cfg_for_launch(128, 32768) == pack.CFG_A
+
+
+# ---- f1: embedders ---------------------------------------------------------------------------------------------------
+def test_embedder_schema_follows_the_reference_wrapping_rules():
+    from emoportraits_amd import embedders as E
+    cfg = E.embedder_config()
+    idt = E.idt_schema(cfg)
+    # Bottleneck: conv1 keeps spectral norm, conv2 / conv3 are weight-standardised (utils.py:1061-1096)
+    assert "idt_embedder_nw.net.layer1.0.conv1.weight_orig" in idt
+    assert "idt_embedder_nw.net.layer1.0.conv2.bias" in idt and "idt_embedder_nw.net.layer1.0.conv3.bias" in idt
+    assert "idt_embedder_nw.net.layer1.0.downsample.0.weight_u" in idt
+    assert idt["idt_embedder_nw.net.fc.weight_orig"] == (512, 2048, 1, 1)
+    assert not any("running_mean" in k for k in idt)          # norm_layer_type gn
+    ex = E.expression_schema(cfg)
+    assert "expression_embedder_nw.net_face.net.layer2.0.conv1.weight_orig" in ex          # BasicBlock.conv1: SN
+    assert "expression_embedder_nw.net_face.net.layer2.0.conv2.bias" in ex                 # BasicBlock.conv2: WS
+    assert ex["expression_embedder_nw.net_face.pose_head.weight_orig"] == (128, 128 * 16)
+    hp = E.head_pose_schema()
+    assert hp["fc.weight"] == (9, 512) and "bn1.running_var" in hp and "conv1.weight" in hp and "conv1.bias" not in hp
+    # bn variant: no WS replacement (the rule keys on GroupNorm siblings)
+    bn = E.idt_schema(E.embedder_config(overrides=dict(norm_layer_type="bn")))
+    assert "idt_embedder_nw.net.layer1.0.conv2.weight_orig" in bn and "idt_embedder_nw.net.bn1.running_mean" in bn
+    with pytest.raises(ValueError):
+        E.embedder_config(overrides=dict(lpe_final_pooling_type="transformer"))
+    sd = E.random_state_dict(hp, 0)
+    assert E.check_state_dict(sd, hp, "")
+    sd.pop("fc.bias")
+    with pytest.raises(KeyError):
+        E.check_state_dict(sd, hp, "")
+
+
+def test_pack_generic_layout():
+    w = torch.arange(5 * 3 * 2 * 2, dtype=torch.float32).reshape(5, 3, 2, 2)
+    wt = pack.pack_generic(w)
+    assert wt.shape == (12, 64)
+    assert torch.equal(wt[:, :5], w.reshape(5, 12).t()) and wt[:, 5:].abs().sum() == 0

@@ -139,3 +139,52 @@ def test_model_attribute_seam(project, tiny):
     feat = torch.randn(1, c * d, s, s, generator=g).to(w.device)
     img, seg, deep_f, img_f = m.decoder_nw({}, {}, feat, False, stage_two=True)
     assert seg is None and img.shape[1] == 3 and deep_f is not None and img_f is not None
+
+
+def test_images_in_images_out_with_native_embedders(tmp_path, tiny):
+    """with the embedder weights present (checkpoint keys + head_pose_regressor_path) the wrapper
+    takes raw crops, as the reference does with crop=False (notebooks/infer.py:395-507, :546-644).  Checked against the
+    oracle's composition of the same stages."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restate as O
+    from emoportraits_amd import config
+    from emoportraits_amd import embedders as E
+    ecfg = E.embedder_config(overrides=dict(idt_output_channels=tiny["cfg"]["gen_max_channels"],
+                                            lpe_output_channels_expression=tiny["cfg"]["lpe_output_channels_expression"]))
+    sd = {**tiny["state_dict"], **E.random_state_dict(E.idt_schema(ecfg), 1),
+          **E.random_state_dict(E.expression_schema(ecfg), 2)}
+    hp_sd = E.random_state_dict(E.head_pose_schema(), 3)
+    hp_sd["fc.weight"] *= 0.05                                 # keep the random pose net near its bias ...
+    hp_sd["fc.bias"] = torch.tensor([1.0, 1.0, 1.0, 0.1, -0.2, 0.05, 0.02, -0.03, 0.01])   # ... = a plausible head pose
+    exp = tmp_path / "logs" / "exp"
+    (exp / "checkpoints").mkdir(parents=True)
+    torch.save(sd, exp / "checkpoints" / "model.pth")
+    torch.save(hp_sd, tmp_path / "head_pose_regressor.pth")
+    with open(exp / "args.txt", "wt") as f:
+        for k, v in {**config.hot_path_config(overrides=tiny["cfg"]), **ecfg}.items():
+            f.write(f"{k}: {v}\n")
+        f.write(f"head_pose_regressor_path: {tmp_path / 'head_pose_regressor.pth'}\n")
+    w = _wrapper(tmp_path)
+    assert set(w.embedders) == {"idt_embedder", "expression_embedder", "head_pose_regressor"}
+    S = tiny["cfg"]["image_size"]
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, S), torch.linspace(0, 1, S), indexing="ij")
+    smooth = lambda a, b: torch.stack([0.5 + 0.4 * torch.sin(a * xx + b * yy), 0.5 + 0.4 * torch.cos(b * xx - a * yy),
+                                       0.3 + 0.5 * xx * yy])[None]
+    src, drv = smooth(5.0, 3.0), torch.cat([smooth(4.0, 6.0), smooth(2.0, 7.0)])
+    mask = torch.ones(1, 1, S, S)
+    assert w.forward(source_image=src, crop=False, source_mask=mask) is None
+    imgs, t = w.forward(driver_image=drv, crop=False)
+    assert len(imgs) == 2 and t.shape == (2, 3, S, S)
+    cfg = tiny["cfg"]
+    with torch.no_grad():
+        idt = O.idt_embed(sd, "idt_embedder_nw", src)
+        th_s = O.head_pose(hp_sd, src)["theta"]
+        pe_s = O.expression_embed(sd, "expression_embedder_nw", src, th_s)["pose_embed"]
+        canon = O.source_pass(sd, cfg, src, idt, pe_s, th_s)["canonical"]
+        th_t = O.head_pose(hp_sd, drv)["theta"]
+        pe_t = O.expression_embed(sd, "expression_embedder_nw", drv, th_t)["pose_embed"]
+        ref = torch.cat([O.driver_pass(sd, cfg, canon, idt, pe_t[i:i + 1], th_t[i:i + 1])["img"] for i in range(2)])
+    assert (w.idt_embed.cpu() - idt).abs().max().item() <= 2e-4 * idt.abs().max().item()
+    assert (w.pred_target_theta.cpu() - th_t).abs().max().item() <= 2e-4 * th_t.abs().max().item()
+    assert (w.target_pose_embed.cpu() - pe_t).abs().max().item() <= 1e-3 * pe_t.abs().max().item()
+    assert (t.cpu() - ref).abs().max().item() <= 1e-2

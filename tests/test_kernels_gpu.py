@@ -274,4 +274,6 @@ def test_resize2d_matches_interpolate(mode, sizes):
     ref = F.interpolate(x, size=(Ho, Wo), mode=mode, align_corners=False)
     got = ops.resize2d(x.to(DEV), (Ho, Wo), mode)
     assert got.shape == ref.shape
-    assert (got.cpu() - ref).abs().max().item() <= 2e-6
+    # source coordinates reach ~128: one ulp of the coordinate (7.6e-6, FMA contraction of the CPU build) times the
+    # unit gradient of a random-noise image
+    assert (got.cpu() - ref).abs().max().item() <= 1e-5

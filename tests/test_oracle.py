@@ -131,3 +131,43 @@ def test_stage2_restatement_matches_reference_golden(golden_dir):
         got = O.stage2_forward(t["state_dict"], t["cfg"], t["img"], t["mask"], t["face_mask"])
     for k in ("latents", "add", "out"):
         assert torch.equal(got[k], t[k]), k
+
+
+# ---- f1: embedders ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emb(golden_dir):
+    """tests/golden/embedders.pt holds seeds + the reference's outputs; weights / inputs are regenerated (oracle/make_golden.py)"""
+    from emoportraits_amd import embedders as E
+    blob = torch.load(os.path.join(golden_dir, "embedders.pt"), weights_only=False)
+    cfg, seeds = blob["cfg"], blob["seeds"]
+    sds = dict(idt=E.random_state_dict(E.idt_schema(cfg), seeds["idt"]),
+               expression=E.random_state_dict(E.expression_schema(cfg), seeds["expression"]),
+               head_pose=E.random_state_dict(E.head_pose_schema(), seeds["head_pose"]))
+    crops = torch.rand(2, 3, 512, 512, generator=torch.Generator().manual_seed(seeds["inputs"]))
+    for name, sd in sds.items():
+        got = float(sum(v.double().sum() for v in sd.values()))
+        assert abs(got - blob["checksums"][name]) <= 1e-6 * abs(blob["checksums"][name]), \
+            f"regenerated '{name}' weights differ from the ones the fixture was made with (torch RNG stream changed?)"
+    assert abs(float(crops.double().sum()) - blob["checksums"]["crops"]) <= 1e-6 * blob["checksums"]["crops"]
+    return blob, sds, crops
+
+
+def test_embedder_restatement_matches_reference_golden(emb):
+    blob, sds, crops = emb
+    cfg = blob["cfg"]
+    with torch.no_grad():
+        idt = O.idt_embed(sds["idt"], "idt_embedder_nw", crops[:1], cfg["idt_backbone"], cfg["idt_image_size"],
+                          cfg["idt_output_size"])
+        hp = O.head_pose(sds["head_pose"], crops)
+        ex = O.expression_embed(sds["expression"], "expression_embedder_nw", crops, blob["theta"], cfg["lpe_face_backbone"],
+                                cfg["exp_image_size"], cfg["lpe_output_size"])
+    # 50 conv layers deep: oneDNN picks its blocking (summation order) from the thread count, so the fixture (made with
+    # 32 threads) is matched to fp32 rounding, not bit for bit (oracle/validate_restatement.py shows 0.0 in-process)
+    close = lambda a, b: (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    assert close(idt, blob["idt_embed"])
+    for k in ("theta", "scale", "rotation", "translation"):
+        assert close(hp[k], blob["head_pose"][k]), k
+    assert torch.equal(ex["img_align"][:, :, ::8, ::8], blob["img_align_sub"])
+    assert torch.equal(ex["align_warp"][:, ::8, ::8], blob["align_warp_sub"])
+    # the reference runs the ResNet on cat(source, target) (batch 4), the restatement on batch 2: conv summation order
+    assert close(ex["pose_embed"], blob["pose_embed"])
