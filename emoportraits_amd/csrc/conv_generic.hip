@@ -9,6 +9,9 @@
 //   GEMM view   D[co][col] = sum_k  Wt[k][co] * X[k][col],   k = (ci, ky, kx),  col = (n, yo, xo)  (batch folded
 //               into the columns, so a 4x4 map with 16 frames still fills 64-wide tiles)
 //   block       256 threads = 4 waves (2x2), tile 64 co x 64 col, one 32x32 accumulator per wave
+//   split-K     the deep layers are tiny GEMMs with a long K (4x4 map, K = 4608: 8..32 tiles, 144 serial chunks), so K is
+//               split over gridDim.z into a workspace and summed in fixed order by a second kernel (deterministic; no
+//               atomics); emo_conv2d_generic_splits() is the launch heuristic the host sizes the workspace with
 //   K loop      chunks of 32: im2col gather of X (with the producer's norm-apply + ReLU folded in, as in the hot-path
 //               kernel) and a coalesced copy of Wt into LDS, next chunk's global loads in flight during the MFMAs
 //   MFMA        v_mfma_f32_32x32x2_f32: A lane (l&31, k=l>>5), B lane (k=l>>5, l&31); D col = l&31,
@@ -29,6 +32,8 @@ struct GenericConvArgs {
   const float* shift;
   float* out;
   int N, Cin, H, W, Cout, CoutP, Ho, Wo, KH, KW, stride, pad, relu_in, K;
+  int chunks_per_split;   // K chunks handled by one blockIdx.z
+  float* partial;         // [splits][N*Cout*Ho*Wo] when splits > 1 (bias is added by the reduction), else null
 };
 
 template <bool AFFINE>
@@ -80,8 +85,10 @@ __global__ __launch_bounds__(256) void conv2d_generic_kernel(const GenericConvAr
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
-  issue(0);
-  for (int k0 = 0; k0 < a.K; k0 += GKC) {
+  const int k_begin = blockIdx.z * a.chunks_per_split * GKC;
+  const int k_end = min(a.K, k_begin + a.chunks_per_split * GKC);
+  issue(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += GKC) {
     __syncthreads();   // previous chunk's MFMAs are done with the LDS tiles
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void conv2d_generic_kernel(const GenericConvAr
       Bs[krow0 + 4 * i][col] = rb[i];
     }
     __syncthreads();
-    if (k0 + GKC < a.K) issue(k0 + GKC);
+    if (k0 + GKC < k_end) issue(k0 + GKC);
     const int kl = lane >> 5, j = lane & 31;
 #pragma unroll
     for (int kk = 0; kk < GKC; kk += 2) {
@@ -103,24 +110,57 @@ __global__ __launch_bounds__(256) void conv2d_generic_kernel(const GenericConvAr
   if (oc < ncols) {
     const int on = (int)(oc / hw);
     const int op = (int)(oc - (long)on * hw);
-    float* o = a.out + (long)on * a.Cout * hw + op;
+    float* base = a.partial ? a.partial + (long)blockIdx.z * ncols * a.Cout : a.out;
+    float* o = base + (long)on * a.Cout * hw + op;
+    const bool add_bias = a.bias && !a.partial;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (co < a.Cout) o[(long)co * hw] = acc[r] + (a.bias ? a.bias[co] : 0.0f);
+      if (co < a.Cout) o[(long)co * hw] = acc[r] + (add_bias ? a.bias[co] : 0.0f);
     }
   }
 }
 
+// out[i] = sum_z partial[z][i] + bias[channel(i)], z ascending
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                            float* __restrict__ out, long total, int splits, int Cout,
+                                                            int hw) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    float s = partial[i];
+    for (int z = 1; z < splits; ++z) s += partial[(long)z * total + i];
+    out[i] = s + (bias ? bias[(i / hw) % Cout] : 0.0f);
+  }
+}
+
+// aim for >= 2 blocks per CU (256 CUs), keep >= 4 K-chunks per split
+int splits_for(long ncols, int Cout, int K) {
+  const long tiles = ((ncols + GBN - 1) / GBN) * ((Cout + GBM - 1) / GBM);
+  const int chunks = (K + GKC - 1) / GKC;
+  long want = (512 + tiles - 1) / tiles;
+  long cap = chunks / 4;
+  if (want > cap) want = cap;
+  if (want > 32) want = 32;
+  return want < 1 ? 1 : (int)want;
+}
+
 }  // namespace
+
+extern "C" int emo_conv2d_generic_splits(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+  if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return EMO_ERR_BAD_ARG;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return EMO_ERR_BAD_ARG;
+  return splits_for((long)N * Ho * Wo, Cout, Cin * KH * KW);
+}
 
 extern "C" int emo_conv2d_generic_f32(const float* x, const float* wt, const float* bias, const float* scale,
                                       const float* shift, float* out, int N, int Cin, int H, int W, int Cout, int KH,
-                                      int KW, int stride, int pad, int relu_in, void* stream) {
+                                      int KW, int stride, int pad, int relu_in, int splits, float* workspace,
+                                      void* stream) {
   if (!x || !wt || !out || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
       pad < 0)
     return EMO_ERR_BAD_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMO_ERR_BAD_ARG;
+  if (splits < 1 || (splits > 1 && !workspace)) return EMO_ERR_BAD_ARG;
   GenericConvArgs a;
   a.x = x; a.wt = wt; a.bias = bias; a.scale = scale; a.shift = shift; a.out = out;
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.CoutP = (Cout + GBM - 1) / GBM * GBM;
@@ -129,10 +169,22 @@ extern "C" int emo_conv2d_generic_f32(const float* x, const float* wt, const flo
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu_in = relu_in; a.K = Cin * KH * KW;
   if (a.Ho <= 0 || a.Wo <= 0) return EMO_ERR_BAD_ARG;
   const long ncols = (long)N * a.Ho * a.Wo;
-  dim3 grid((unsigned)((ncols + GBN - 1) / GBN), (unsigned)(a.CoutP / GBM));
+  const int chunks = (a.K + GKC - 1) / GKC;
+  if (splits > chunks) splits = chunks;
+  a.chunks_per_split = (chunks + splits - 1) / splits;
+  splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;   // no empty split
+  a.partial = splits > 1 ? workspace : nullptr;
+  dim3 grid((unsigned)((ncols + GBN - 1) / GBN), (unsigned)(a.CoutP / GBM), (unsigned)splits);
   if (scale)
     hipLaunchKernelGGL(conv2d_generic_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(conv2d_generic_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (splits > 1) {
+    const long total = ncols * Cout;
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, workspace, bias,
+                       out, total, splits, Cout, a.Ho * a.Wo);
+  }
   return emo_launch_status();
 }

@@ -294,13 +294,17 @@ class ResNetTrunk:
         return x
 
 
-def _imagenet_affine(sd, prefix, n, device):
+class _ImagenetAffine:
     """(x - mean) / std as the per-(n,c) input affine of the stem conv (applied before its zero padding, like the
-    reference's explicit normalisation)"""
-    mean = sd.get(prefix + ".mean", torch.tensor(IMAGENET_MEAN)).reshape(-1).double()
-    std = sd.get(prefix + ".std", torch.tensor(IMAGENET_STD)).reshape(-1).double()
-    sc, sh = (1.0 / std).float(), (-mean / std).float()
-    return sc[None].expand(n, -1).contiguous().to(device), sh[None].expand(n, -1).contiguous().to(device)
+    reference's explicit normalisation); constants resident on the device so that calls are graph-capturable"""
+
+    def __init__(self, sd, prefix, device):
+        mean = sd.get(prefix + ".mean", torch.tensor(IMAGENET_MEAN)).reshape(-1).double()
+        std = sd.get(prefix + ".std", torch.tensor(IMAGENET_STD)).reshape(-1).double()
+        self.sc, self.sh = (1.0 / std).float()[None].to(device), (-mean / std).float()[None].to(device)
+
+    def __call__(self, n):
+        return self.sc.expand(n, -1).contiguous(), self.sh.expand(n, -1).contiguous()
 
 
 def _adaptive_avgpool(x, size):
@@ -318,7 +322,8 @@ class IdtEmbed:
 
     def __init__(self, sd, cfg, device, prefix="idt_embedder_nw"):
         check_state_dict(sd, idt_schema(cfg, prefix), prefix + ".")
-        self.cfg, self.device, self.prefix, self.sd_consts = cfg, device, prefix, {k: sd[k] for k in sd if k.endswith((".mean", ".std"))}
+        self.cfg, self.device = cfg, device
+        self.in_affine = _ImagenetAffine(sd, prefix, device)
         self.trunk = ResNetTrunk(sd, prefix + ".net", cfg["idt_backbone"], device)
         self.fc = GenericConv(sd, prefix + ".net.fc", 1, 0, device)
 
@@ -327,8 +332,7 @@ class IdtEmbed:
         x = masked_source.to(self.device).float().contiguous()
         if x.shape[-2:] != (S, S):
             x = ops.resize2d(x, (S, S), "bilinear")
-        sc, sh = _imagenet_affine(self.sd_consts, self.prefix, x.shape[0], self.device)
-        x = self.fc(self.trunk(x, sc, sh))
+        x = self.fc(self.trunk(x, *self.in_affine(x.shape[0])))
         return _adaptive_avgpool(x, self.cfg["idt_output_size"])
 
     forward_image = __call__
@@ -367,7 +371,7 @@ class ExpressionEmbed:
     def __init__(self, sd, cfg, device, prefix="expression_embedder_nw"):
         check_state_dict(sd, expression_schema(cfg, prefix), prefix + ".")
         self.cfg, self.device, self.prefix = cfg, device, prefix + ".net_face"
-        self.sd_consts = {k: sd[k] for k in sd if k.endswith((".mean", ".std"))}
+        self.in_affine = _ImagenetAffine(sd, self.prefix, device)
         self.trunk = ResNetTrunk(sd, self.prefix + ".net", cfg["lpe_face_backbone"], device)
         self.fc = GenericConv(sd, self.prefix + ".net.fc", 1, 0, device)
         p = self.prefix + ".pose_head"
@@ -376,16 +380,14 @@ class ExpressionEmbed:
         self.w_head = _dev(w, device)
         self.grid_size = cfg["exp_image_size"] // 2                                        # expression_embedder.py:87
         self.zoom = torch.diag(torch.tensor([0.5, 0.5, 1.0])).to(device)                   # :196-198
+        self.keep = torch.tensor([0, 1, 3], device=device)                                 # rows / cols of the 2-D transform
+        self.last_row = torch.tensor([[[0.0, 0.0, 0.0, 1.0]]], device=device)
 
     def align_theta(self, theta):
         """:178-200: 4x4 inverse of the head pose, rows/cols (0,1,3) -> 2-D affine, 2x zoom-in, first two rows"""
         t4 = theta.to(self.device).float()
-        if t4.shape[1] == 3:
-            eye = torch.zeros(t4.shape[0], 1, 4, device=self.device)
-            eye[:, :, 3] = 1
-            t4 = torch.cat([t4, eye], dim=1)
-        inv = ops.mat4_inverse(t4.contiguous())
-        inv2d = inv[:, :, [0, 1, 3]][:, [0, 1, 3]]
+        t4 = torch.cat([t4[:, :3], self.last_row.expand(t4.shape[0], -1, -1)], dim=1)      # :183-187 (theta_[:, :3] + e4)
+        inv2d = ops.mat4_inverse(t4.contiguous()).index_select(2, self.keep).index_select(1, self.keep)
         return torch.matmul(inv2d, self.zoom)[:, :2].contiguous()
 
     def forward(self, crop, theta, want_aligned=False):
@@ -393,8 +395,7 @@ class ExpressionEmbed:
         a = self.align_theta(theta)
         aligned, warp = ops.grid_sample2d(crop, theta=a, size=self.grid_size, want_grid=True)   # :221-231
         B = aligned.shape[0]
-        sc, sh = _imagenet_affine(self.sd_consts, self.prefix, B, self.device)
-        x = self.fc(self.trunk(aligned, sc, sh))
+        x = self.fc(self.trunk(aligned, *self.in_affine(B)))
         x = _adaptive_avgpool(x, self.cfg["lpe_output_size"]).reshape(B, -1, 1)
         pose = ops.small_gemm(self.w_head, x, 1).reshape(B, -1)
         return (pose, aligned, warp) if want_aligned else pose

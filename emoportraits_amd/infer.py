@@ -28,7 +28,7 @@ import torch
 
 from . import config as cfg_mod
 from . import embedders as emb_mod
-from . import nets, ops, parallel, schema
+from . import graphs, nets, ops, parallel, schema
 
 
 class HipModel:
@@ -93,7 +93,8 @@ class InferenceWrapper:
     def __init__(self, experiment_name, which_epoch='latest', model_file_name='', use_gpu=True, num_gpus=1,
                  fixed_bounding_box=False, project_dir='./', folder='mp_logs', model_='va',
                  torch_home='', debug=False, print_model=False, print_params=True, args_overwrite={}, state_dict=None,
-                 pose_momentum=0.5, rank=0, args_path=None, embedders=None, head_pose_regressor_path=None):
+                 pose_momentum=0.5, rank=0, args_path=None, embedders=None, head_pose_regressor_path=None,
+                 use_graphs=False):
         if not use_gpu:
             raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
         if model_ != 'va':
@@ -129,7 +130,20 @@ class InferenceWrapper:
         if rank == 0 and print_params:
             n = sum(v.numel() for k, v in self.model_dict.items() if k.startswith(schema.HOT_PATH_PREFIXES))
             print(f'Number of hot-path parameters: {n}')
-        self.embedders = {**self._native_embedders(found, head_pose_regressor_path), **dict(embedders or {})}
+        native = self._native_embedders(found, head_pose_regressor_path)
+        self.embedders = {**native, **dict(embedders or {})}
+        # hipGraph replay of the per-frame sequences (emoportraits_amd/graphs.py); only this repo's own executors are
+        # captured, user-supplied embedder callables always run eagerly
+        self.use_graphs = bool(use_graphs)
+        self._graphed = {}
+        if self.use_graphs:
+            self._graphed['driver'] = graphs.Graphed(
+                lambda pose, theta: self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, pose, theta))
+            hp_net, ex_net = native.get('head_pose_regressor'), native.get('expression_embedder')
+            if hp_net is not None and self.embedders['head_pose_regressor'] is hp_net:
+                self._graphed['head_pose_regressor'] = graphs.Graphed(lambda crop: hp_net.forward(crop, True))
+            if ex_net is not None and self.embedders['expression_embedder'] is ex_net:
+                self._graphed['expression_embedder'] = graphs.Graphed(lambda crop, theta: ex_net(crop, theta))
 
         self.fixed_bounding_box = fixed_bounding_box
         self.momentum = 0.01
@@ -162,6 +176,40 @@ class InferenceWrapper:
         if head_pose_regressor_path is not None or (path and os.path.isfile(str(path))):
             out['head_pose_regressor'] = emb_mod.HeadPoseRegressor(torch.load(path, map_location='cpu'), self.device)
         return out
+
+    def _set_source_cache(self, canonical=None, idt_embed=None):
+        """per-identity cache; with graphs the captured sequences hold the buffer addresses, so a new identity is copied
+        INTO the existing buffers instead of rebinding them"""
+        if idt_embed is not None:
+            if self.use_graphs and getattr(self, 'idt_embed', None) is not None and self.idt_embed.shape == idt_embed.shape:
+                self.idt_embed.copy_(idt_embed)
+            else:
+                self.idt_embed = idt_embed.clone() if self.use_graphs else idt_embed
+        if canonical is not None:
+            self.target_latent_volume = canonical
+            cl = self.hot_path.prepare_canonical(canonical)
+            if self.use_graphs and self._canonical_cl is not None and self._canonical_cl.shape == cl.shape:
+                self._canonical_cl.copy_(cl)
+            else:
+                self._canonical_cl = cl
+
+    def _head_pose(self, crop):
+        g = self._graphed.get('head_pose_regressor')
+        if g is not None:
+            return g(crop)
+        return self._need('head_pose_regressor', 'a driver call')(crop, True)
+
+    def _expression(self, crop, theta, what):
+        g = self._graphed.get('expression_embedder')
+        if g is not None:
+            return g(crop, theta.float().contiguous())
+        return self._need('expression_embedder', what)(crop, theta)
+
+    def _drive(self, pose, theta):
+        g = self._graphed.get('driver')
+        if g is not None:
+            return g(pose, theta)
+        return self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, pose, theta)
 
     def _need(self, name, what):
         fn = self.embedders.get(name)
@@ -255,9 +303,9 @@ class InferenceWrapper:
                 self.source_img_mask = source_img_mask
                 masked = (source_img_crop * source_img_mask).contiguous()
                 if custome_idt_embed is not None:
-                    self.idt_embed = custome_idt_embed.to(self.device).float().contiguous()
+                    self._set_source_cache(idt_embed=custome_idt_embed.to(self.device).float().contiguous())
                 else:
-                    self.idt_embed = self._need('idt_embedder', 'a source call')(masked)               # infer.py:432
+                    self._set_source_cache(idt_embed=self._need('idt_embedder', 'a source call')(masked))  # infer.py:432
                 if custome_source_theta_embed is not None:
                     pred_source_theta = self._theta_from(custome_source_theta_embed)[0]
                 else:
@@ -266,7 +314,7 @@ class InferenceWrapper:
                 if custome_source_pose_embed is not None:
                     source_pose_embed = custome_source_pose_embed.to(self.device).float().contiguous()
                 else:
-                    source_pose_embed = self._need('expression_embedder', 'a source call')(source_img_crop, pred_source_theta)
+                    source_pose_embed = self._expression(source_img_crop, pred_source_theta, 'a source call')
                 self.pred_source_pose_embed = source_pose_embed
                 self.source_img = source_img_crop
 
@@ -286,8 +334,7 @@ class InferenceWrapper:
                 tv = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=hp.pad)
                 self.target_latent_volume_1 = tv if c_target_latent_volume is None else \
                     c_target_latent_volume.to(self.device).float().contiguous()
-                self.target_latent_volume = hp.volume_process(self.target_latent_volume_1)             # infer.py:507
-                self._canonical_cl = hp.prepare_canonical(self.target_latent_volume)
+                self._set_source_cache(canonical=hp.volume_process(self.target_latent_volume_1))      # infer.py:507
 
             if driver_image is None and custome_target_pose_embed is None:
                 return None                                                                            # infer.py:644-646
@@ -301,7 +348,7 @@ class InferenceWrapper:
             if custome_target_theta_embed is not None:                                                 # infer.py:565-566
                 pred_target_theta, self.pred_target_srt = self._theta_from(custome_target_theta_embed)
             else:
-                pred_target_theta, *srt = self._need('head_pose_regressor', 'a driver call')(driver_img_crop, True)
+                pred_target_theta, *srt = self._head_pose(driver_img_crop)                             # infer.py:562
                 self.pred_target_srt = tuple(srt)
             if smooth_pose:                                                                            # infer.py:571-581
                 if self.theta is None:
@@ -316,13 +363,12 @@ class InferenceWrapper:
             if custome_target_pose_embed is not None:                                                  # infer.py:603-604
                 target_pose_embed = custome_target_pose_embed.to(self.device).float().contiguous()
             else:
-                target_pose_embed = self._need('expression_embedder', 'a driver call')(driver_img_crop, pred_target_theta)
+                target_pose_embed = self._expression(driver_img_crop, pred_target_theta, 'a driver call')   # :596-601
             self.target_pose_embed = target_pose_embed
             B = target_pose_embed.shape[0]
             if theta_used.shape[0] != B:
                 theta_used = theta_used.expand(B, -1, -1)
-            img = self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, target_pose_embed,
-                                            theta_used.float().contiguous())                          # infer.py:612-637
+            img = self._drive(target_pose_embed, theta_used.float().contiguous())                      # infer.py:612-637
             u8 = ops.pack_rgb8(img).cpu().numpy()                                                      # infer.py:641-643
             return [self.to_image(u8[i]) for i in range(B)], img
 
@@ -342,7 +388,7 @@ class InferenceWrapper:
             pose = target_pose_embeds[b0:b1].to(self.device).float().contiguous()
             srt = [t[b0:b1].to(self.device).float().contiguous() for t in target_srt]
             theta = ops.pose_theta(*srt)
-            img = self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, pose, theta)
+            img = self._drive(pose, theta)
             yield b0, (ops.pack_rgb8(img) if as_uint8 else img)
 
     def share_source(self, src_rank=0):
@@ -354,5 +400,5 @@ class InferenceWrapper:
                  theta_src=getattr(self, 'pred_source_theta', None)),
             shapes=dict(canonical=(1, c, d, s, s), idt_embed=(1, self.cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4)),
             src=src_rank, device=self.device, world=self.world, rank=self.rank)
-        self.target_latent_volume, self.idt_embed, self.pred_source_theta = cache["canonical"], cache["idt_embed"], cache["theta_src"]
-        self._canonical_cl = self.hot_path.prepare_canonical(self.target_latent_volume)
+        self.pred_source_theta = cache["theta_src"]
+        self._set_source_cache(canonical=cache["canonical"], idt_embed=cache["idt_embed"])

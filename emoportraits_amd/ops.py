@@ -317,8 +317,9 @@ def resize2d(x, size, mode="bilinear"):
 
 
 # ---- embedder ResNets -----------------------------------------------------------------------
-def conv2d_generic(x, wt, cout, kh, kw, stride, pad, bias=None, scale=None, shift=None, relu_in=False):
-    """F.conv2d(relu?(x*scale+shift), w, bias, stride, pad); wt = pack.pack_generic(w) [Cin*kh*kw, CoutP]"""
+def conv2d_generic(x, wt, cout, kh, kw, stride, pad, bias=None, scale=None, shift=None, relu_in=False, splits=None):
+    """F.conv2d(relu?(x*scale+shift), w, bias, stride, pad); wt = pack.pack_generic(w) [Cin*kh*kw, CoutP].
+    splits: K split count (None = the library's launch heuristic)"""
     lib = hip.load()
     hip.require_cuda_f32(x)
     N, Cin, H, W = x.shape
@@ -326,9 +327,14 @@ def conv2d_generic(x, wt, cout, kh, kw, stride, pad, bias=None, scale=None, shif
         raise ValueError(f"packed weight has K={wt.shape[0]}, input needs {Cin * kh * kw}")
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    if splits is None:
+        splits = lib.emo_conv2d_generic_splits(N, Cin, H, W, cout, kh, kw, stride, pad)
+        if splits < 1:
+            hip.check(splits, "emo_conv2d_generic_splits")
+    ws = torch.empty((splits, out.numel()), device=x.device, dtype=torch.float32) if splits > 1 else None
     hip.check(lib.emo_conv2d_generic_f32(hip.ptr(x), hip.ptr(wt), hip.ptr(bias), hip.ptr(scale), hip.ptr(shift),
-                                         hip.ptr(out), N, Cin, H, W, cout, kh, kw, stride, pad, int(relu_in),
-                                         hip.current_stream()), "emo_conv2d_generic_f32")
+                                         hip.ptr(out), N, Cin, H, W, cout, kh, kw, stride, pad, int(relu_in), splits,
+                                         hip.ptr(ws), hip.current_stream()), "emo_conv2d_generic_f32")
     return out
 
 

@@ -153,7 +153,9 @@ int emo_resize2d_f32(const float* x, float* out, int64_t NC, int H, int W, int H
  * emo_conv2d_generic_f32: F.conv2d(x', w, bias, stride, padding) with x' = relu?(x * scale[n,c] + shift[n,c]) when
  *   scale/shift are given (the producer's norm + ReLU, applied before zero padding), any KH x KW / stride / pad.
  *   wt is the folded weight transposed to [Cin*KH*KW][CoutP] (k = (ci*KH + ky)*KW + kx, CoutP = Cout rounded up to 64,
- *   zero padded).  x [N,Cin,H,W], out [N,Cout,Ho,Wo].
+ *   zero padded).  x [N,Cin,H,W], out [N,Cout,Ho,Wo].  splits > 1 divides K over gridDim.z through
+ *   workspace [splits][N*Cout*Ho*Wo] floats, summed in fixed order (deterministic); emo_conv2d_generic_splits returns
+ *   the split count the launch heuristic wants for a shape (>= 1; the kernel accepts any value >= 1).
  * emo_maxpool2d_f32:   nn.MaxPool2d(k, stride, pad) of relu?(x * scale + shift) (scale/shift [NC] or NULL).
  * emo_affine_add_relu_f32: out = relu?((a*sa+ta) + (b*sb+tb)), per-(n,c) affines optional, b optional: the tail of
  *   BasicBlock / Bottleneck.forward.
@@ -162,7 +164,8 @@ int emo_resize2d_f32(const float* x, float* out, int64_t NC, int H, int W, int H
  *   grid_out (optional) receives the grid that was used. */
 int emo_conv2d_generic_f32(const float* x, const float* wt, const float* bias, const float* scale, const float* shift,
                            float* out, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
-                           int relu_in, void* stream);
+                           int relu_in, int splits, float* workspace, void* stream);
+int emo_conv2d_generic_splits(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad);
 int emo_maxpool2d_f32(const float* x, const float* scale, const float* shift, float* out, int64_t NC, int H, int W,
                       int k, int stride, int pad, int relu, void* stream);
 int emo_affine_add_relu_f32(const float* a, const float* sa, const float* ta, const float* b, const float* sb,

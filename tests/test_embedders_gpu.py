@@ -58,6 +58,12 @@ def test_conv2d_generic_matches_torch(case):
                              None if sh is None else sh.to(DEV).contiguous(), relu_in=affine)
     assert got.shape == ref.shape
     assert rel_err(got, ref) <= 2e-5
+    # explicit K splits (workspace + fixed-order reduction), including more splits than K chunks
+    for splits in (1, 3, 64):
+        again = ops.conv2d_generic(x.to(DEV), pack.pack_generic(w).to(DEV), Cout, k, k, stride, pad,
+                                   None if b is None else b.to(DEV), None if sc is None else sc.to(DEV).contiguous(),
+                                   None if sh is None else sh.to(DEV).contiguous(), relu_in=affine, splits=splits)
+        assert rel_err(again, ref) <= 2e-5
 
 
 def test_maxpool_with_folded_norm_and_relu():

@@ -188,3 +188,26 @@ def test_images_in_images_out_with_native_embedders(tmp_path, tiny):
     assert (w.pred_target_theta.cpu() - th_t).abs().max().item() <= 2e-4 * th_t.abs().max().item()
     assert (w.target_pose_embed.cpu() - pe_t).abs().max().item() <= 1e-3 * pe_t.abs().max().item()
     assert (t.cpu() - ref).abs().max().item() <= 1e-2
+
+
+def test_graph_replay_equals_eager_and_follows_a_new_identity(project, tiny):
+    """hipGraph replay (emoportraits_amd/graphs.py) must be the same arithmetic as the eager launches, and a second source
+    call must reach the captured sequence (the per-identity cache is updated in place)"""
+    S = tiny["cfg"]["image_size"]
+    src_kw = dict(crop=False, source_mask=torch.ones(1, 1, S, S), custome_idt_embed=tiny["idt_embed"],
+                  custome_source_pose_embed=tiny["source_pose_embed"], custome_source_theta_embed=tiny["theta_src"])
+    drv_kw = dict(crop=False, custome_target_pose_embed=tiny["target_pose_embed"], custome_target_theta_embed=tiny["theta_drv"])
+    eager, graphed = _wrapper(project), _wrapper(project, use_graphs=True)
+    outs = {}
+    for name, w in (("eager", eager), ("graphed", graphed)):
+        w.forward(source_image=tiny["img"], **src_kw)
+        a = w.forward(**drv_kw)[1].clone()
+        b = w.forward(**drv_kw)[1].clone()                       # second call = pure replay
+        w.forward(source_image=tiny["img"].flip(-1), **src_kw)   # new identity
+        c = w.forward(**drv_kw)[1].clone()
+        outs[name] = (a, b, c)
+    assert len(graphed._graphed["driver"].signatures()) == 1
+    for x, y in zip(outs["eager"], outs["graphed"]):
+        assert torch.equal(x, y)
+    assert torch.equal(outs["graphed"][0], outs["graphed"][1])
+    assert not torch.equal(outs["graphed"][0], outs["graphed"][2])

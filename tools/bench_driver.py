@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from emoportraits_amd import config, nets, ops, random_init  # noqa: E402
+from emoportraits_amd import config, graphs, nets, ops, random_init  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -52,6 +52,9 @@ def main():
         rec["decoder_ms"] = timeit(lambda: hp.decoder(feat))
         rec["total_ms"] = timeit(lambda: hp.driver_pass(ccl, idt, pose, theta))
         rec["fps"] = B / rec["total_ms"] * 1e3
+        graphed = graphs.Graphed(lambda p, t: hp.driver_pass(ccl, idt, p, t), clone_outputs=False)
+        rec["graph_total_ms"] = timeit(lambda: graphed(pose, theta))
+        rec["graph_fps"] = B / rec["graph_total_ms"] * 1e3
         rec = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rec.items()}
         print(json.dumps(rec), flush=True)
 
