@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
 
-__global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__ x, float* __restrict__ out, long NC,
-                                                       int H, int W, int Ho, int Wo, int bicubic) {
+__global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__ x, long plane_stride, long row_stride,
+                                                       float* __restrict__ out, long NC,
+                                                       int H, int W, int Ho, int Wo, int bicubic, int clamp01) {
   const long total = NC * Ho * Wo;
   const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;   // scale = in/out when only `size` is given
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__
     const long r = i / Wo;
     const int yo = (int)(r % Ho);
     const long nc = r / Ho;
-    const float* p = x + nc * (long)H * W;
+    const float* p = x + nc * plane_stride;
     float sy = sh * ((float)yo + 0.5f) - 0.5f, sx = sw * ((float)xo + 0.5f) - 0.5f;
     if (!bicubic) {
       sy = sy < 0.0f ? 0.0f : sy;
@@ -103,8 +104,9 @@ __global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__
       const int y0 = (int)sy, x0 = (int)sx;
       const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
       const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-      out[i] = ly0 * (lx0 * p[(long)y0 * W + x0] + lx1 * p[(long)y0 * W + x1]) +
-               ly1 * (lx0 * p[(long)y1 * W + x0] + lx1 * p[(long)y1 * W + x1]);
+      const float v = ly0 * (lx0 * p[y0 * row_stride + x0] + lx1 * p[y0 * row_stride + x1]) +
+                      ly1 * (lx0 * p[y1 * row_stride + x0] + lx1 * p[y1 * row_stride + x1]);
+      out[i] = clamp01 ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
     } else {
       const float fy = floorf(sy), fx = floorf(sx);
       const int iy = (int)fy, ix = (int)fx;
@@ -122,11 +124,11 @@ __global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__
         for (int b = 0; b < 4; ++b) {
           int xx = ix - 1 + b;
           xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-          row += p[(long)yy * W + xx] * wx[b];
+          row += p[yy * row_stride + xx] * wx[b];
         }
         acc += row * wy[a];
       }
-      out[i] = acc;
+      out[i] = clamp01 ? fminf(fmaxf(acc, 0.0f), 1.0f) : acc;   // bicubic overshoots: crop_image clips (infer.py:350)
     }
   }
 }
@@ -208,10 +210,10 @@ extern "C" int emo_stage2_compose_f32(const float* img, const float* add, const 
   return emo_launch_status();
 }
 
-extern "C" int emo_resize2d_f32(const float* x, float* out, int64_t NC, int H, int W, int Ho, int Wo, int bicubic,
-                                void* stream) {
-  if (!x || !out || NC <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return EMO_ERR_BAD_ARG;
-  hipLaunchKernelGGL(resize2d_kernel, dim3(grid_for(NC * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, out, (long)NC,
-                     H, W, Ho, Wo, bicubic);
+extern "C" int emo_resize2d_f32(const float* x, int64_t plane_stride, int64_t row_stride, float* out, int64_t NC, int H,
+                                int W, int Ho, int Wo, int bicubic, int clamp01, void* stream) {
+  if (!x || !out || NC <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || row_stride < W || plane_stride < 0) return EMO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(resize2d_kernel, dim3(grid_for(NC * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)plane_stride, (long)row_stride, out, (long)NC, H, W, Ho, Wo, bicubic, clamp01);
   return emo_launch_status();
 }

@@ -31,7 +31,7 @@ SIGNATURES = {
     "emo_upsample_trilinear_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_add_f32": [_c_void, _c_void, _c_void, _c_i64, _c_i64, _c_float, _c_void],
-    "emo_resize2d_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 5 + [_c_void],
+    "emo_resize2d_f32": [_c_void, _c_i64, _c_i64, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_conv2d_generic_f32": [_c_void] * 6 + [_c_int] * 11 + [_c_void, _c_void],
     "emo_conv2d_generic_splits": [_c_int] * 9,
     "emo_maxpool2d_f32": [_c_void] * 4 + [_c_i64] + [_c_int] * 6 + [_c_void],

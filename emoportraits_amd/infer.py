@@ -28,7 +28,7 @@ import torch
 
 from . import config as cfg_mod
 from . import embedders as emb_mod
-from . import graphs, nets, ops, parallel, schema
+from . import graphs, hostglue, nets, ops, parallel, schema
 
 
 class HipModel:
@@ -158,6 +158,7 @@ class InferenceWrapper:
         self.use_seg = bool(found.get('use_seg', False))
         self.target_latent_volume = None
         self._canonical_cl = None
+        self._crop_tracker = None
 
     # ------------------------------------------------------------------------------------------------------
     def _native_embedders(self, found, head_pose_regressor_path):
@@ -215,9 +216,9 @@ class InferenceWrapper:
         fn = self.embedders.get(name)
         if fn is None:
             raise RuntimeError(
-                f"{what} needs the '{name}' network: its weights were not found (checkpoint keys / "
-                f"head_pose_regressor_path) and it was not passed via InferenceWrapper(embedders={{'{name}': callable}}); "
-                f"alternatively supply its output through the custome_* arguments")
+                f"{what} needs the '{name}' network: it was not passed via InferenceWrapper(embedders={{'{name}': callable}}) "
+                f"and, for the embedders this package runs itself, its weights were not found (checkpoint keys / "
+                f"head_pose_regressor_path); the custome_* arguments can supply its output instead")
         return fn
 
     def convert_to_tensor(self, image):
@@ -244,6 +245,55 @@ class InferenceWrapper:
             t = ops.resize2d(t, (S, S), "bicubic")                                  # infer.py:399-401
         return t
 
+    def crop_image(self, image, faces, use_smoothed_crop=False, scale=1):
+        """notebooks/infer.py:301-352: square window around each face box (host arithmetic, emoportraits_amd/hostglue.py),
+        read in place from the frame and resized to image_size with the bicubic kernel, clipped to [0,1].
+        image: list of [3,H,W] tensors or a [B,3,H,W] tensor; faces: list of (x0, y0, x1, y1) or None.
+        Returns (crops [B,3,S,S] on the device, face_check, face_scale_stats) like the reference."""
+        import numpy as np
+        S = self.cfg["image_size"]
+        if use_smoothed_crop and self._crop_tracker is None:
+            self._crop_tracker = hostglue.CropTracker(self.momentum, self.fixed_bounding_box)
+        crops, face_check, face_scale_stats = [], np.ones(len(image), dtype=bool), []
+        for b, face in enumerate(faces):
+            frame = image[b]
+            win = hostglue.crop_window(face, frame.shape[2], frame.shape[1],
+                                       self._crop_tracker if use_smoothed_crop else None, scale)
+            if win is None:
+                face_check[b] = False
+                crops.append(torch.zeros((1, 3, S, S), device=self.device))
+                face_scale_stats.append(0)
+                continue
+            x_lo, y_lo, side, face_scale = win
+            frame = frame[None, :3].to(self.device).float().contiguous()
+            crops.append(ops.resize2d(frame, (S, S), "bicubic", window=(x_lo, y_lo, side, side), clamp01=True))
+            face_scale_stats.append(face_scale)
+        if self._crop_tracker is not None:
+            self.center, self.size = self._crop_tracker.center, self._crop_tracker.size
+        return torch.cat(crops), face_check, face_scale_stats
+
+    def _detect_and_crop(self, images):
+        """crop=True (notebooks/infer.py:376-393, :515-546): face detector (third party: mediapipe in the reference, here the
+        'face_detector' callable: PIL image -> relative box (xmin, ymin, width, height) or None) + crop_image.  A 'cropper'
+        callable, if given, replaces the whole step."""
+        if 'cropper' in self.embedders:
+            return self.embedders['cropper'](images).to(self.device)
+        det = self._need('face_detector', 'crop=True')
+        images = images if isinstance(images, (list, tuple)) else [images]
+        faces, tensors = [], []
+        for img in images:
+            rel = det(img)
+            t = self.convert_to_tensor(img)[0, :3]
+            faces.append(None if rel is None else hostglue.detection_to_face(*rel, t.shape[2], t.shape[1]))
+            tensors.append(t)
+        crops, self.face_check, self.face_scale_stats = self.crop_image(tensors, faces)
+        return crops
+
+    def get_mixing_theta(self, source_theta, target_theta):
+        """notebooks/infer.py:686-736 (host scipy polar decomposition there as well)"""
+        mixed = hostglue.mixing_theta(source_theta.detach().cpu().numpy(), target_theta.detach().cpu().numpy(), self.mix_old)
+        return torch.from_numpy(mixed).float().to(self.device)
+
     def _theta_from(self, embed):
         """(scale, rotation, translation) as the reference's custome_target_theta_embed (-> get_transform_matrix,
         infer.py:565-566), or an already formed [B,4,4] theta tensor (extension)"""
@@ -269,10 +319,8 @@ class InferenceWrapper:
         with torch.no_grad():
             if reset_tracking:
                 self.center = self.size = self.theta = self.delta_yaw = self.delta_pitch = None
+                self._crop_tracker = None
             self.mix, self.mix_old = mix, mix_old
-            if mix:
-                raise RuntimeError("mix=True (scipy polar mixing of source/driver pose, infer.py:686-736) is host glue "
-                                   "outside the hot path: compute the mixed theta and pass custome_target_theta_embed")
             if delta_yaw is not None:
                 self.delta_yaw = delta_yaw
             if delta_pitch is not None:
@@ -281,7 +329,7 @@ class InferenceWrapper:
 
             if source_image is not None:
                 if crop:
-                    source_img_crop = self._need('cropper', 'crop=True')(source_image).to(self.device)
+                    source_img_crop = self._detect_and_crop(source_image)
                 else:
                     source_img_crop = self._prepare_image(source_image)
                 self.source_image = source_image
@@ -343,13 +391,14 @@ class InferenceWrapper:
 
             driver_img_crop = None
             if driver_image is not None:
-                driver_img_crop = self._need('cropper', 'crop=True')(driver_image).to(self.device) if crop \
-                    else self._prepare_image(driver_image)
+                driver_img_crop = self._detect_and_crop(driver_image) if crop else self._prepare_image(driver_image)
             if custome_target_theta_embed is not None:                                                 # infer.py:565-566
                 pred_target_theta, self.pred_target_srt = self._theta_from(custome_target_theta_embed)
             else:
                 pred_target_theta, *srt = self._head_pose(driver_img_crop)                             # infer.py:562
                 self.pred_target_srt = tuple(srt)
+            if mix:                                                                                    # infer.py:568-569
+                pred_target_theta = self.get_mixing_theta(self.pred_source_theta, pred_target_theta)
             if smooth_pose:                                                                            # infer.py:571-581
                 if self.theta is None:
                     self.theta = pred_target_theta[0].clone()
@@ -359,7 +408,7 @@ class InferenceWrapper:
                     sm.append(self.theta.clone())
                 pred_target_theta = torch.stack(sm)
             self.pred_target_theta = pred_target_theta
-            theta_used = pred_target_theta if target_theta else self.pred_source_theta.expand_as(pred_target_theta)
+            theta_used = pred_target_theta if target_theta else self.pred_source_theta
             if custome_target_pose_embed is not None:                                                  # infer.py:603-604
                 target_pose_embed = custome_target_pose_embed.to(self.device).float().contiguous()
             else:

@@ -3,6 +3,7 @@
 Names and argument meaning follow the torch ops the reference calls on the hot path, so that
 the parity tests read like `ours(x) == torch_cpu(x)`.
 """
+import ctypes
 import functools
 
 import torch
@@ -304,15 +305,21 @@ def stage2_compose(img, add_img, mask, face_mask):
     return out
 
 
-def resize2d(x, size, mode="bilinear"):
-    """F.interpolate(x, size=size, mode=mode, align_corners=False) for 4-D x; mode 'bilinear' or 'bicubic'"""
+def resize2d(x, size, mode="bilinear", window=None, clamp01=False):
+    """F.interpolate(x[..., y0:y0+h, x0:x0+w], size=size, mode=mode, align_corners=False) for 4-D x; mode 'bilinear' or
+    'bicubic'; window = (x0, y0, w, h) reads a crop of the frame in place (default: the whole frame)"""
     lib = hip.load()
     hip.require_cuda_f32(x)
     N, C, H, W = x.shape
+    x0, y0, w, h = window if window is not None else (0, 0, W, H)
+    if not (0 <= x0 and 0 <= y0 and w > 0 and h > 0 and x0 + w <= W and y0 + h <= H):
+        raise ValueError(f"resize window {(x0, y0, w, h)} is not inside the {W}x{H} frame")
     Ho, Wo = size
     out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
-    hip.check(lib.emo_resize2d_f32(hip.ptr(x), hip.ptr(out), N * C, H, W, Ho, Wo, {"bilinear": 0, "bicubic": 1}[mode],
-                                   hip.current_stream()), "emo_resize2d_f32")
+    first = ctypes.c_void_p(x.data_ptr() + 4 * (y0 * W + x0))
+    hip.check(lib.emo_resize2d_f32(first, H * W, W, hip.ptr(out), N * C, h, w, Ho, Wo,
+                                   {"bilinear": 0, "bicubic": 1}[mode], int(clamp01), hip.current_stream()),
+              "emo_resize2d_f32")
     return out
 
 

@@ -142,9 +142,12 @@ int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC, int D, in
 int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int kd, int kh, int kw, void* stream);
 int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, float alpha, void* stream);
 
-/* f4 -- F.interpolate(x, size=(Ho, Wo), mode='bilinear' (bicubic = 0) | 'bicubic' (1), align_corners=False) on
- * [NC, H, W] planes: the wrappers' crop resize (notebooks/infer.py:399-401,548-552; notebooks/infer_s2.py:360-362). */
-int emo_resize2d_f32(const float* x, float* out, int64_t NC, int H, int W, int Ho, int Wo, int bicubic, void* stream);
+/* f4 -- F.interpolate(x, size=(Ho, Wo), mode='bilinear' (bicubic = 0) | 'bicubic' (1), align_corners=False) on NC
+ * planes of H x W: the wrappers' crop resize (notebooks/infer.py:346,399-401,548-552; notebooks/infer_s2.py:360-362).
+ * The input is strided (plane_stride / row_stride in floats; H*W / W when contiguous) so that a crop window of a larger
+ * frame is read in place; clamp01 clips the result to [0,1] (crop_image, infer.py:350). */
+int emo_resize2d_f32(const float* x, int64_t plane_stride, int64_t row_stride, float* out, int64_t NC, int H, int W,
+                     int Ho, int Wo, int bicubic, int clamp01, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f1 -- embedder ResNets (networks/volumetric_avatar/identity_embedder.py:59-69, expression_embedder.py:424-459,

@@ -13,6 +13,7 @@ Fixtures
                      coordinates, three padding modes.
   pose_theta.npz     utils/point_transforms.py:188-242 get_transform_matrix + the rotation warp of
                      va.py:101-105 / notebooks/infer.py:441-444,583-588 (incl. rotation clamp edge cases).
+  hostglue.pt        crop windows / crops of InferenceWrapper.crop_image and poses of get_mixing_theta (notebooks/infer.py).
   embedders.pt       seeds + outputs of the reference's IdtEmbed / HeadPoseRegressor / ExpressionEmbed at full width.
   tiny_hotpath.pt    reduced-width released architecture (same code paths: SN, WS, ada-GN, up/down sampling):
                      raw state_dict + synthetic inputs + per-stage outputs of the reference source and driver passes.
@@ -198,6 +199,82 @@ def embedders_golden():
     print("embedders.pt", os.path.getsize(path) / 1e3, "KB", checks)
 
 
+def hostglue_golden():
+    """notebooks/infer.py crop_image (:301-352, with remove_overflow :243-261 and the smoothed-crop state :317-327) and
+    get_mixing_theta (:686-736), called unbound on a stub `self`.  The crop windows are recovered from coordinate-coded
+    images by intercepting the module's F.interpolate (the crop the reference hands to the bicubic resize)."""
+    m, _ = R.reference_wrapper_stub(32)
+    rng = np.random.RandomState(5)
+    seen = []
+    real_interp = m.F.interpolate
+
+    def spy(x, *a, **kw):
+        seen.append((int(x[0, 0, 0, 0]), int(x[0, 1, 0, 0]), int(x.shape[-1]), int(x.shape[-2])))
+        return real_interp(x, *a, **kw)
+
+    def coded(h, w):
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        return torch.stack([xx, yy, torch.zeros_like(xx)])
+
+    cases = []
+    m.F.interpolate = spy
+    try:
+        for name, kw, frames in (
+            ("independent", dict(), 8), ("scaled", dict(scale=1.3), 6),
+            ("smoothed", dict(use_smoothed_crop=True), 8), ("smoothed_fast", dict(use_smoothed_crop=True, momentum=0.5), 8),
+            ("fixed", dict(use_smoothed_crop=True, fixed_bounding_box=True), 5),
+        ):
+            _, stub = R.reference_wrapper_stub(32, momentum=kw.pop("momentum", 0.01),
+                                               fixed_bounding_box=kw.pop("fixed_bounding_box", False))
+            sizes, faces = [], []
+            for i in range(frames):
+                h, w = int(rng.randint(90, 260)), int(rng.randint(90, 260))
+                if name != "independent":
+                    h, w = 200, 240
+                cx, cy, half = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(15, 90)     # boxes that overflow the image
+                faces.append(None if (name == "independent" and i == 3) else
+                             np.array([cx - half, cy - half * 1.2, cx + half, cy + half * 1.1]))
+                sizes.append((h, w))
+            seen.clear()
+            imgs = [coded(h, w) for h, w in sizes]
+            crops, check, scales = m.InferenceWrapper.crop_image(stub, imgs, faces, **kw)
+            windows, it = [], iter(seen)
+            for f in faces:
+                windows.append(None if f is None else next(it))
+            cases.append(dict(name=name, kwargs=kw, momentum=stub.momentum, fixed=stub.fixed_bounding_box, sizes=sizes,
+                              faces=faces, windows=windows, face_check=check, face_scale=scales))
+        # one pixel-valued case for the whole crop (window + bicubic resize + clip) at image_size 32
+        seen.clear()
+        _, stub = R.reference_wrapper_stub(32)
+        g = torch.Generator().manual_seed(9)
+        img = torch.rand(3, 150, 190, generator=g)
+        faces = [np.array([40.0, 30.0, 130.0, 140.0]), np.array([120.0, -20.0, 230.0, 95.0])]
+        crops, _, _ = m.InferenceWrapper.crop_image(stub, [img, img], faces)
+    finally:
+        m.F.interpolate = real_interp
+    pixel = dict(image=img, faces=faces, crops=crops)
+
+    from utils import point_transforms
+    mix = []
+    gm = torch.Generator().manual_seed(12)
+    for B, T in ((1, 1), (1, 3), (2, 2)):
+        srt = lambda n: (1 + 0.1 * torch.randn(n, 3, generator=gm), 0.4 * torch.randn(n, 3, generator=gm),
+                         0.1 * torch.randn(n, 3, generator=gm))
+        ths, tht = point_transforms.get_transform_matrix(*srt(B)), point_transforms.get_transform_matrix(*srt(B * T))
+        for mix_old in (True, False):
+            _, stub = R.reference_wrapper_stub(32, mix_old=mix_old)
+            out = m.InferenceWrapper.get_mixing_theta(stub, ths, tht)
+            mix.append(dict(source=ths, target=tht, mix_old=mix_old, out=out))
+    det = []
+    for _ in range(4):      # the bbox arithmetic of infer.py:385-391 evaluated literally
+        xmin, ymin, wd, ht, W, H = rng.uniform(0.1, 0.5), rng.uniform(0.05, 0.5), rng.uniform(0.2, 0.5), rng.uniform(0.2, 0.6), 640, 480
+        det.append(dict(rel=(xmin, ymin, wd, ht), size=(W, H),
+                        face=np.array([W * xmin, H * ymin * 0.9, W * (xmin + wd), min(H * (ymin + ht * 1.2), H - 1)])))
+    path = os.path.join(OUT, "hostglue.pt")
+    torch.save(dict(crop_cases=cases, pixel=pixel, mixing=mix, detections=det), path)
+    print("hostglue.pt", os.path.getsize(path) / 1e3, "KB;", sum(len(c["faces"]) for c in cases), "crop windows,", len(mix), "mixing cases")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -206,3 +283,4 @@ if __name__ == "__main__":
     tiny_hotpath()
     tiny_stage2()
     embedders_golden()
+    hostglue_golden()

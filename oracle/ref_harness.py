@@ -421,3 +421,29 @@ def reference_expression(h, crop, theta):
     with torch.no_grad():
         dd = h.expression_embedder_nw(dd, True, False)
     return dict(pose_embed=dd["target_pose_embed"], img_align=dd["target_img_align"], align_warp=dd["align_warp"])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# wrapper host glue: notebooks/infer.py crop_image / get_mixing_theta
+# ----------------------------------------------------------------------------------------------------------------
+def import_reference_infer():
+    """the reference's notebooks/infer.py as a module.  It imports `datasets.voxceleb2hq_pairs`, a file that is absent from
+    the reference tree: stubbed (only the dataset class name is taken from it)."""
+    install()
+    import importlib
+    import datasets as _ref_datasets  # noqa: F401  (the reference's own package, REF_ROOT is first on sys.path)
+    sys.modules.setdefault("datasets.voxceleb2hq_pairs", MagicMock(name="datasets.voxceleb2hq_pairs"))
+    nb = os.path.join(REF_ROOT, "notebooks")
+    if nb not in sys.path:
+        sys.path.insert(1, nb)
+    return importlib.import_module("infer")
+
+
+def reference_wrapper_stub(image_size, momentum=0.01, fixed_bounding_box=False, mix_old=True):
+    """a bare object carrying the attributes InferenceWrapper.crop_image / get_mixing_theta read from `self`
+    (notebooks/infer.py:142-150): the methods are called unbound on it, no model is built"""
+    m = import_reference_infer()
+    stub = types.SimpleNamespace(args=types.SimpleNamespace(image_size=image_size), center=None, size=None,
+                                 momentum=momentum, fixed_bounding_box=fixed_bounding_box, mix_old=mix_old,
+                                 remove_overflow=m.InferenceWrapper.remove_overflow)
+    return m, stub

@@ -148,3 +148,41 @@ def test_pack_generic_layout():
     wt = pack.pack_generic(w)
     assert wt.shape == (12, 64)
     assert torch.equal(wt[:, :5], w.reshape(5, 12).t()) and wt[:, 5:].abs().sum() == 0
+
+
+# ---- f4: wrapper host glue pinned to the reference's own methods ----------------------------------------------------
+@pytest.fixture(scope="module")
+def glue(golden_dir):
+    return torch.load(os.path.join(golden_dir, "hostglue.pt"), weights_only=False)
+
+
+def test_crop_windows_match_reference_crop_image(glue):
+    """every window InferenceWrapper.crop_image (notebooks/infer.py:301-352) cut -- overflowing boxes, missing faces,
+    the `scale` argument, the smoothed / fixed bounding-box state -- recovered from coordinate-coded images"""
+    from emoportraits_amd import hostglue as H
+    n = 0
+    for case in glue["crop_cases"]:
+        kw = case["kwargs"]
+        tracker = H.CropTracker(case["momentum"], case["fixed"]) if kw.get("use_smoothed_crop") else None
+        for (h, w), face, want, scale_ref, ok in zip(case["sizes"], case["faces"], case["windows"], case["face_scale"],
+                                                     case["face_check"]):
+            got = H.crop_window(face, w, h, tracker, kw.get("scale", 1))
+            if want is None:
+                assert got is None and not ok and scale_ref == 0
+                continue
+            x_lo, y_lo, side, face_scale = got
+            assert (x_lo, y_lo, side, side) == tuple(want), (case["name"], got, want)
+            assert face_scale == scale_ref
+            n += 1
+    assert n == 34
+
+
+def test_detection_box_and_mixing_theta_match_reference(glue):
+    import numpy as np
+    from emoportraits_amd import hostglue as H
+    for d in glue["detections"]:
+        assert np.array_equal(H.detection_to_face(*d["rel"], *d["size"]), d["face"])
+    for m in glue["mixing"]:
+        got = H.mixing_theta(m["source"].numpy(), m["target"].numpy(), m["mix_old"])
+        assert got.shape == tuple(m["out"].shape)
+        assert np.abs(got.astype(np.float32) - m["out"].numpy()).max() <= 1e-6

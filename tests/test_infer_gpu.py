@@ -111,7 +111,7 @@ def test_strict_checkpoint_loading_and_loud_failures(project, tiny):
     w = _wrapper(project)
     with pytest.raises(RuntimeError, match="source_image first"):
         w.forward(crop=False, custome_target_pose_embed=tiny["target_pose_embed"], custome_target_theta_embed=tiny["theta_drv"])
-    with pytest.raises(RuntimeError, match="cropper"):
+    with pytest.raises(RuntimeError, match="face_detector"):
         w.forward(source_image=tiny["img"], crop=True)
     with pytest.raises(RuntimeError, match="idt_embedder"):
         w.forward(source_image=tiny["img"], crop=False, source_mask=torch.ones(1, 1, 64, 64))
@@ -211,3 +211,44 @@ def test_graph_replay_equals_eager_and_follows_a_new_identity(project, tiny):
         assert torch.equal(x, y)
     assert torch.equal(outs["graphed"][0], outs["graphed"][1])
     assert not torch.equal(outs["graphed"][0], outs["graphed"][2])
+
+
+def test_crop_image_matches_reference_golden(project, golden_dir):
+    """InferenceWrapper.crop_image (notebooks/infer.py:301-352): window arithmetic + in-place bicubic resize + clip against
+    the crops the reference's own method produced (tests/golden/hostglue.pt)"""
+    glue = torch.load(os.path.join(golden_dir, "hostglue.pt"), weights_only=False)["pixel"]
+    w = _wrapper(project)
+    w.cfg["image_size"] = glue["crops"].shape[-1]
+    crops, check, scales = w.crop_image([glue["image"], glue["image"]], glue["faces"])
+    assert check.all() and crops.shape == glue["crops"].shape
+    assert (crops.cpu() - glue["crops"]).abs().max().item() <= 1e-5
+    # a missing face gives a zero crop and a False flag, like the reference
+    crops, check, scales = w.crop_image([glue["image"], glue["image"]], [None, glue["faces"][0]])
+    assert list(check) == [False, True] and crops[0].abs().max().item() == 0 and scales[0] == 0
+
+
+def test_crop_true_and_mix_true_paths(project, tiny):
+    """crop=True with a face-detector callable (mediapipe's relative box in the reference) and mix=True (source stretch
+    + driver rotation/translation, infer.py:568-569, 686-736) run end to end and equal the explicit formulation"""
+    from emoportraits_amd import hostglue
+    S = tiny["cfg"]["image_size"]
+    kw = dict(custome_idt_embed=tiny["idt_embed"], custome_source_pose_embed=tiny["source_pose_embed"],
+              custome_source_theta_embed=tiny["theta_src"])
+    big = torch.rand(3, 2 * S, 3 * S, generator=torch.Generator().manual_seed(4))
+    rel = (0.2, 0.25, 0.4, 0.45)
+    w = _wrapper(project, embedders={"face_detector": lambda img: rel})
+    w.forward(source_image=big, crop=True, source_mask=torch.ones(1, 1, S, S), **kw)
+    face = hostglue.detection_to_face(*rel, 3 * S, 2 * S)
+    want, _, _ = w.crop_image([big], [face])
+    assert torch.equal(w.source_image_crop, want)
+    drv_kw = dict(crop=False, custome_target_pose_embed=tiny["target_pose_embed"])
+    # mix=True == passing the mixed pose explicitly
+    th_t = tiny["theta_drv"].to(w.device)
+    w.embedders["head_pose_regressor"] = lambda crop, srt=False: (th_t, None, None, None)
+    dummy = torch.zeros(2, 3, S, S)
+    _, mixed_img = w.forward(driver_image=dummy, mix=True, **drv_kw)
+    mixed = torch.from_numpy(hostglue.mixing_theta(tiny["theta_src"].numpy(), tiny["theta_drv"].numpy(), True)).float()
+    assert (w.pred_target_theta.cpu() - mixed).abs().max().item() <= 1e-6
+    full = torch.cat([mixed, torch.tensor([[[0.0, 0, 0, 1]]]).expand(2, -1, -1)], dim=1)
+    _, explicit_img = w.forward(custome_target_theta_embed=full, **drv_kw)
+    assert torch.equal(mixed_img, explicit_img)
