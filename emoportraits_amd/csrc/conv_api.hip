@@ -29,11 +29,61 @@ extern "C" int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC) {
   return EMO_OK;
 }
 
+// second half of a split-K launch: out = act(sum_ks partial[ks] + bias + residual), ks ascending (deterministic)
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* __restrict__ partial,
+                                                                   const float* __restrict__ bias, const float* res,
+                                                                   float* out, long total, int ksplit, int Cout, int Dl,
+                                                                   int Hl, int Wl, int act, int res_ups) {
+  const long ovol = (long)Dl * Hl * Wl;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    float v = partial[i];
+    for (int k = 1; k < ksplit; ++k) v += partial[(long)k * total + i];
+    const long nc = i / ovol;
+    if (bias) v += bias[nc % Cout];
+    if (res) {
+      if (res_ups) {
+        const long sp = i - nc * ovol;
+        const int x = (int)(sp % Wl);
+        const long r = sp / Wl;
+        const int y = (int)(r % Hl), z = (int)(r / Hl);
+        const int Wr = Wl >> 1, Hr = Hl >> 1;
+        v += res[nc * ((long)Dl * Hr * Wr) + ((long)z * Hr + (y >> 1)) * Wr + (x >> 1)];
+      } else {
+        v += res[i];
+      }
+    }
+    out[i] = emo_act(v, act);
+  }
+}
+
+static int kc_of(int KH, int KW) {
+  if (KH == 3 && KW == 3) return EMO_CONV_KC_3X3;
+  if (KH == 1 && KW == 1) return EMO_CONV_KC_1X1;
+  if (KH == 1 && KW == 7) return EMO_CONV_KC_1X7;
+  return 0;
+}
+
+// launch heuristic: split the K loop until the launch has >= 2 blocks per CU, keeping >= 8 stages per split
+extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW, int ups,
+                                     int cfg) {
+  const int kc = kc_of(KH, KW);
+  if (!kc || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 || cfg < 0 || cfg >= N_CFGS) return EMO_ERR_BAD_ARG;
+  const int bm = cfg == CFG_A ? 128 : cfg == CFG_B ? 64 : 32;
+  const long pos = (long)N * D * (ups ? 4 : 1) * H * W;
+  const long blocks = ((pos + 127) / 128) * ((Cout + bm - 1) / bm);
+  const int nstages = ((Cin + kc - 1) / kc) * KD;
+  long want = blocks >= 512 ? 1 : (512 + blocks - 1) / blocks;
+  if (want > nstages / 8) want = nstages / 8;
+  if (want > 16) want = 16;
+  return want < 1 ? 1 : (int)want;
+}
+
 extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias, const float* scale,
                                   const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
                                   int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
-                                  int cfg, void* stream) {
+                                  int cfg, int ksplit, float* workspace, void* stream) {
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
+  if (ksplit < 1 || (ksplit > 1 && !workspace)) return EMO_ERR_BAD_ARG;
   if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMO_ERR_BAD_ARG;
   if (KD != 1 && KD != 3 && KD != 7) return EMO_ERR_UNSUPPORTED;
@@ -62,5 +112,17 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
     return EMO_ERR_UNSUPPORTED;
   }
   if (!fn) return EMO_ERR_UNSUPPORTED;
-  return fn(a, (hipStream_t)stream);
+  const int nstages = ((Cin + kc_of(KH, KW) - 1) / kc_of(KH, KW)) * KD;
+  if (ksplit > nstages) ksplit = nstages;
+  a.stages_per_split = (nstages + ksplit - 1) / ksplit;
+  a.ksplit = (nstages + a.stages_per_split - 1) / a.stages_per_split;   // no empty split
+  a.partial = a.ksplit > 1 ? workspace : nullptr;
+  const int rc = fn(a, (hipStream_t)stream);
+  if (rc != EMO_OK || a.ksplit == 1) return rc;
+  const long total = (long)N * Cout * a.Dl * a.Hl * a.Wl;
+  long blocks = (total + 255) / 256;
+  if (blocks > 262144) blocks = 262144;
+  hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, workspace, bias,
+                     res, out, total, a.ksplit, Cout, a.Dl, a.Hl, a.Wl, act, res_ups);
+  return emo_launch_status();
 }

@@ -44,6 +44,10 @@ struct ConvArgs {
   int n_cchunks;       // ceil(Cin / KC)
   int tiles_x, tiles_y, tiles_z;
   int n_cotiles;       // ceil(Cout / BM)
+  int ksplit;          // >= 1: the (channel chunk x depth tap) stages are divided over ksplit blocks per output tile
+  int stages_per_split;
+  float* partial;      // ksplit > 1: raw partial sums [ksplit][N][Cout][Dl][Hl][Wl]; bias / residual / activation are
+                       // applied by conv_splitk_epilogue_kernel (conv_api.hip), which adds the splits in fixed order
 };
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
 #ifndef EMO_CONV_XCD_ORDER
 #define EMO_CONV_XCD_ORDER 1   /* 1: 1-D grid, XCD-contiguous, output-channel tile fastest (see below); 0: (ptile, cotile, n) grid */
 #endif
-  int n, cotile, bx;
+  int n, cotile, bx, ks = 0;
   if (EMO_CONV_XCD_ORDER) {
     // Block b runs on XCD b % 8 (private 4 MiB L2 each).  Re-map so that every XCD walks one contiguous eighth of the
     // (sample, position tile, output-channel tile) work with the channel tile fastest: all channel tiles of a position
@@ -127,7 +131,11 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     cotile = L % a.n_cotiles;
-    const int rest = L / a.n_cotiles;
+    int rest = L / a.n_cotiles;
+    if (a.ksplit > 1) {   // K splits of one tile sit next to each other: same patch rows, different channels
+      ks = rest % a.ksplit;
+      rest /= a.ksplit;
+    }
     const int nptiles = a.tiles_x * a.tiles_y * a.tiles_z;
     n = rest / nptiles;
     bx = rest - n * nptiles;
@@ -175,8 +183,10 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
     p_pz[i] = pz;
   }
 
-  const int nstages = a.n_cchunks * a.KD;
-  const float4* wsrc = reinterpret_cast<const float4*>(a.wpk) + ((long)cotile * nstages) * (ASZ / 4);
+  const int nstages_all = a.n_cchunks * a.KD;
+  const int st_begin = ks * a.stages_per_split;                       // this block's share of the K loop
+  const int st_end = min(nstages_all, st_begin + a.stages_per_split);
+  const float4* wsrc = reinterpret_cast<const float4*>(a.wpk) + ((long)cotile * nstages_all) * (ASZ / 4);
 
   float pv[NPE];        // staged patch values (raw)
   bool pvz[NPE];        // per-element depth validity (only varies per element when TZ > 1)
@@ -272,17 +282,17 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
   constexpr int STORE_PAIR = EMO_CONV_STORE_AT ? (KC / 4) : -1;   // the idle LDS buffer is free for the whole stage
 
   if (stages_data) {
-    EMO_ISSUE_LOADS(0, smem);
-    EMO_STORE_STAGE(0, smem);
+    EMO_ISSUE_LOADS(st_begin, smem);
+    EMO_STORE_STAGE(st_begin, smem);
   }
   __syncthreads();
 
   if (is_producer) {
     // ---- loader waves (wave specialisation): the whole stage time to fetch, transform and park the next stage.
     //      Same number of barriers as the MFMA waves; no accumulators live on this path. ----
-    for (int st = 0; st < nstages; ++st) {
-      float* nxt = smem + ((st + 1) & 1) * BUF;
-      const int stn = (st + 1) < nstages ? (st + 1) : st;
+    for (int st = st_begin; st < st_end; ++st) {
+      float* nxt = smem + ((st - st_begin + 1) & 1) * BUF;
+      const int stn = (st + 1) < st_end ? (st + 1) : st;
       EMO_ISSUE_LOADS(stn, nxt);
       EMO_STORE_STAGE(stn, nxt);
       __syncthreads();
@@ -328,12 +338,12 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
     }                                                                                                 \
   }
 
-  for (int st = 0; st < nstages; ++st) {
-    float* cur = smem + (st & 1) * BUF;
-    float* nxt = smem + ((st + 1) & 1) * BUF;
+  for (int st = st_begin; st < st_end; ++st) {
+    float* cur = smem + ((st - st_begin) & 1) * BUF;
+    float* nxt = smem + ((st - st_begin + 1) & 1) * BUF;
     // prefetch the next stage while this one computes; on the last stage the (clamped) prefetch re-reads the
     // last stage and its LDS write lands in the idle buffer -- harmless, and it keeps the loop branch-free
-    const int stn = (st + 1) < nstages ? (st + 1) : st;
+    const int stn = (st + 1) < st_end ? (st + 1) : st;
     const float* As = cur;
     const float* Ps = cur + ASZ;
     if (NPW == 0) {
@@ -377,7 +387,9 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = cotile * BM + m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a.Cout) {
+        if (co < a.Cout && a.partial) {
+          a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc[i][j][r];
+        } else if (co < a.Cout) {
           float v = acc[i][j][r];
           if (a.bias) v += a.bias[co];
           if (a.res) v += a.res[((long)n * a.Cout + co) * rvol + rsp];
@@ -418,8 +430,10 @@ int conv_igemm_launch(ConvArgs a, hipStream_t s) {
     }
   }
   a.n_cotiles = cot;
-  if (nt * cot * a.N > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  dim3 g = EMO_CONV_XCD_ORDER ? dim3((unsigned)(nt * cot * a.N)) : dim3((unsigned)nt, cot, a.N);
+  if (a.ksplit < 1 || (a.ksplit > 1 && (!EMO_CONV_XCD_ORDER || !a.partial))) return EMO_ERR_BAD_ARG;
+  if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }
+  if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  dim3 g = EMO_CONV_XCD_ORDER ? dim3((unsigned)(nt * cot * a.N * a.ksplit)) : dim3((unsigned)nt, cot, a.N);
   hipLaunchKernelGGL(kern, g, dim3(Cfg::THREADS), lds, s, a);
   return emo_launch_status();
 }

@@ -27,7 +27,8 @@ SIGNATURES = {
     "emo_groupnorm_affine_f32": [_c_void, _c_int, _c_int, _c_i64, _c_int, _c_float] + [_c_void] * 4 + [_c_i64]
                                 + [_c_void] * 5 + [_c_i64, _c_void],
     "emo_conv_pack_info": [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
-    "emo_conv_igemm_f32": [_c_void] * 7 + [_c_int] * 14 + [_c_void],
+    "emo_conv_igemm_f32": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void],
+    "emo_conv_igemm_ksplit": [_c_int] * 11,
     "emo_upsample_trilinear_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_add_f32": [_c_void, _c_void, _c_void, _c_i64, _c_i64, _c_float, _c_void],

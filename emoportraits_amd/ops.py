@@ -149,8 +149,9 @@ def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, gr
 # implicit-GEMM convolution
 # ----------------------------------------------------------------------------------------------------------------
 def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=None, res_ups=False, act="none",
-               out=None):
-    """layer: emoportraits_amd.pack.PackedConv.  x [N,Cin,H,W] or [N,Cin,D,H,W]."""
+               out=None, ksplit=None):
+    """layer: emoportraits_amd.pack.PackedConv.  x [N,Cin,H,W] or [N,Cin,D,H,W].
+    ksplit: K-loop split of the launch (None: pack.plan_launch decides together with the block config)."""
     lib = hip.load()
     hip.require_cuda_f32(x, scale, shift, res)
     three_d = x.dim() == 5
@@ -173,11 +174,14 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         want = (N, layer.cout, D, Hl // 2, Wl // 2) if res_ups else (N, layer.cout, D, Hl, Wl)
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
             raise ValueError("bad residual shape")
-    cfg = layer.cfg_for(N * D * Hl * Wl // 128)
+    cfg, ks = layer.plan_for(N * D * Hl * Wl // 128)
+    if ksplit is not None:
+        ks = int(ksplit)
+    ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None
     rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
                                 hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
-                                layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg,
-                                hip.current_stream())
+                                layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
+                                hip.ptr(ws), hip.current_stream())
     hip.check(rc, f"emo_conv_igemm_f32[{layer.name}]")
     return out
 

@@ -109,6 +109,34 @@ def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
     return best[1]
 
 
+_KC = {(3, 3): 4, (1, 1): 16, (1, 7): 4}   # input channels per K stage (emo_conv_pack_info)
+_MAX_KSPLIT = 16
+
+
+def ksplit_for(blocks, nstages):
+    """split the K loop until the launch has _FILL_BLOCKS blocks, keeping >= 8 stages per split
+    (same rule as emo_conv_igemm_ksplit in csrc/conv_api.hip)"""
+    if blocks >= _FILL_BLOCKS:
+        return 1
+    return max(1, min(-(-_FILL_BLOCKS // blocks), nstages // 8, _MAX_KSPLIT))
+
+
+def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
+    """(block config, K split) of one launch: fill the 256 CUs first (by splitting K if the tile grid is small), then
+    least channel padding, then the larger tile"""
+    nstages = -(-cin // _KC[(kh, kw)]) * kd
+    best = None
+    for cfg in allowed:
+        bm = _BM[cfg]
+        cot = -(-cout // bm)
+        blocks = cot * n_pos_tiles
+        ks = ksplit_for(blocks, nstages)
+        score = min(blocks * ks, _FILL_BLOCKS) / _FILL_BLOCKS * (cout / (cot * bm)) * _CFG_EFF[cfg] * (0.97 if ks > 1 else 1.0)
+        if best is None or score > best[0] + 1e-9:
+            best = (score, cfg, ks)
+    return best[1], best[2]
+
+
 class PackedConv:
     """One convolution of the hot path, ready for emo_conv_igemm_f32.  Weights are packed lazily per block config
     (the best config depends on the batch size of the call); `cfg` pins one config (tests / benchmarks)."""
@@ -139,6 +167,11 @@ class PackedConv:
         if self.pinned_cfg is not None:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
+
+    def plan_for(self, n_pos_tiles):
+        """(cfg, ksplit) for a launch over n_pos_tiles 128-position tiles"""
+        allowed = (self.pinned_cfg,) if self.pinned_cfg is not None else self.allowed
+        return plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, allowed)
 
     @classmethod
     def from_state_dict(cls, sd, prefix, kind, device, cfg=None):

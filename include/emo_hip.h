@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 1
+#define EMO_ABI_VERSION 2
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
@@ -121,13 +121,19 @@ int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S, int G, flo
  *         shape when res_ups != 0.  May alias `out`.
  *   act   EMO_ACT_* applied last (tanh head warp_generator_resnet.py:99-107; sigmoid head decoder.py:347-358).
  *   cfg   0: 128 output channels x 128 positions per block, 1: 64 x 128, 2: 32 x 128.
+ *   ksplit / workspace   ksplit > 1 divides the K loop (input-channel chunks x depth taps) of every output tile over
+ *         ksplit blocks -- small launches (64x64 maps at batch 1, the 8^3 / 16^3 WarpGenerator layers) otherwise leave most
+ *         of the 256 CUs idle; partial sums go to workspace [ksplit][N*Cout*D*Hl*Wl] floats and a second kernel adds them
+ *         in fixed order and applies bias / residual / activation (deterministic; `out` may alias `res`).  ksplit = 1,
+ *         workspace = NULL: single pass.  emo_conv_igemm_ksplit returns the split count the launch heuristic wants.
  * Supported output widths: multiples of 128, or 64 / 32 / 16 / 8 (with H resp. D divisible by the tile).
  */
 int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC);
 int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias,
                        const float* scale, const float* shift, const float* res, float* out,
                        int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
-                       int ups, int relu_in, int act, int res_ups, int cfg, void* stream);
+                       int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace, void* stream);
+int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW, int ups, int cfg);
 
 /* ---------------------------------------------------------------------------------------------
  * resampling / pointwise helpers (HBM-bound, one pass)

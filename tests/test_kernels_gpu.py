@@ -27,7 +27,7 @@ def rel_err(got, ref):
 
 
 def run_conv(N, Cin, Cout, dims, k, cfg, affine=False, relu_in=False, ups=False, res=False, res_ups=False,
-             bias=True, act="none", seed=0):
+             bias=True, act="none", seed=0, ksplit=None, inplace=False):
     g = torch.Generator().manual_seed(seed)
     three_d = len(dims) == 3
     x = torch.randn(N, Cin, *dims, generator=g)
@@ -62,9 +62,10 @@ def run_conv(N, Cin, Cout, dims, k, cfg, affine=False, relu_in=False, ups=False,
     elif act == "relu":
         ref = F.relu(ref)
     layer = pack.PackedConv("test", w, b, DEV, cfg=cfg)
+    rd = None if r is None else r.to(DEV)
     got = ops.conv_igemm(x.to(DEV), layer, None if scale is None else scale.to(DEV),
                          None if shift is None else shift.to(DEV), relu_in=relu_in, ups=ups,
-                         res=None if r is None else r.to(DEV), res_ups=res_ups, act=act)
+                         res=rd, res_ups=res_ups, act=act, ksplit=ksplit, out=rd if inplace else None)
     return rel_err(got, ref), got, ref
 
 
@@ -88,6 +89,23 @@ def test_conv2d_1x1(cfg, hw):
 def test_conv3d_3x3x3(cfg, dims):
     e, _, _ = run_conv(1, 6, 33, dims, 3, cfg, seed=sum(dims) + cfg)
     assert e < 2e-5, e
+
+
+@pytest.mark.parametrize("ksplit", [2, 5, 64])
+@pytest.mark.parametrize("case", [
+    dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=0, affine=True, relu_in=True, res=True, inplace=True),
+    dict(N=2, Cin=64, Cout=40, dims=(16, 16), k=3, cfg=1, ups=True, res=True, res_ups=True, act="tanh"),
+    dict(N=1, Cin=70, Cout=33, dims=(8, 8, 8), k=3, cfg=1, affine=True, relu_in=True, bias=False),
+    dict(N=1, Cin=200, Cout=48, dims=(32, 32), k=1, cfg=2, act="sigmoid"),
+])
+def test_conv_split_k_equals_single_pass(case, ksplit):
+    """K split over gridDim (workspace + fixed-order epilogue): same function as the single pass, incl. the fused
+    bias / residual (plain, nearest-x2, in place) / activation, ragged channel chunks and more splits than stages"""
+    e, got, ref = run_conv(seed=7, ksplit=ksplit, **case)
+    assert got.shape == ref.shape
+    assert e < 2e-5, e
+    e1, got1, _ = run_conv(seed=7, ksplit=1, **case)
+    assert (got - got1).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
 def test_conv3d_1x1x1():
