@@ -13,6 +13,7 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_bench_2ranks_1gpu.json", f"{tag}_bench_2ranks_on_1gpu_gloo.json"),
                  (f"{tag}_stage2.jsonl", f"{tag}_stage2_bench.jsonl"), (f"{tag}_sampler.jsonl", f"{tag}_sampler_microbench.jsonl"),
                  (f"{tag}_conv.jsonl", f"{tag}_conv_microbench.jsonl"), (f"{tag}_driver512.jsonl", f"{tag}_driver_breakdown_r512.jsonl"),
+                 (f"{tag}_pipeline.jsonl", f"{tag}_pipeline_images_in_out.jsonl"), (f"{tag}_embedders.txt", f"{tag}_embedders.txt"),
                  (f"{tag}_smoke.log", f"{tag}_smoke.txt")):
     if os.path.exists(g + src):
         shutil.copy(g + src, p + dst)

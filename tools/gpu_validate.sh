@@ -1,7 +1,8 @@
 #!/bin/bash
 # Full round-end validation on the GPU box (what the driver runs, plus the evidence kept under profiles/):
 #   all GPU parity tests, smoke(), the bench line (N=1; R512 and R256), a 2-rank run on one GPU (gloo, test hook),
-#   stage-2 throughput, sampler / conv microbenchmarks, rocprofv3 kernel stats + PMC passes.
+#   stage-2 throughput, sampler / conv microbenchmarks, images-in/images-out pipeline, embedder parity + timing,
+#   rocprofv3 kernel stats + PMC passes.
 # usage: gpurun -- 'bash tools/gpu_validate.sh r1'   then   python tools/collect_profiles.py r1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r1}
@@ -17,5 +18,7 @@ timeout 300 python tools/bench_stage2.py 8 2>&1 | grep -v amdgpu.ids > gpurun_ou
 timeout 300 python tools/bench_sampler.py 64 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_sampler.jsonl
 timeout 300 python tools/bench_conv.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_conv.jsonl
 timeout 300 python tools/bench_driver.py 512 1 4 16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_driver512.jsonl
+timeout 300 python tools/bench_pipeline.py 512 1 16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pipeline.jsonl
+timeout 300 python tools/probe_embedders.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_embedders.txt
 bash tools/profile_bench.sh ${TAG}
 tail -3 gpurun_out/${TAG}_pytest.log; tail -1 gpurun_out/${TAG}_smoke.log; cut -c1-200 gpurun_out/${TAG}_bench.json
