@@ -25,6 +25,8 @@
 #include "common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));   // native vector: stays an SSA value (HIP's float4 struct kept the
+                                                             // prefetched weight tile in a scratch alloca once it was loop-carried)
 
 struct ConvArgs {
   const float* x;      // [N, Cin, D, H, W]  (source dims; logical dims are (D, 2H, 2W) when UPS)
@@ -93,7 +95,12 @@ template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WG
 #ifndef EMO_CONV_MIN_WAVES
 #define EMO_CONV_MIN_WAVES 2   /* __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocation must allow */
 #endif
-__global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) void conv_igemm_kernel(const ConvArgs a) {
+#ifndef EMO_CONV_MAX_WAVES
+#define EMO_CONV_MAX_WAVES 5   /* occupancy the register allocation is planned for: LDS holds 3-5 blocks of 4 waves per CU.  Measured
+                                  on the 64-row config (64x64..256x256 layers): 4 -> 127.5, 5 -> 129.5, 6 -> 118 TF */
+#endif
+__global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS) __attribute__((amdgpu_waves_per_eu(EMO_CONV_MIN_WAVES, EMO_CONV_MAX_WAVES)))
+void conv_igemm_kernel(const ConvArgs a) {
   using Cfg = ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS;
   constexpr int PATCH = Cfg::PATCH, ASZ = Cfg::ASZ, BUF = Cfg::BUF, NPE = Cfg::NPE, NA4 = Cfg::NA4;
@@ -155,8 +162,13 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
   const bool has_affine = a.scale != nullptr;
   const bool relu_in = a.relu_in != 0;
   const int padD = a.KD >> 1;
-  const float* scale_n = has_affine ? a.scale + (long)n * a.Cin : nullptr;
-  const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : nullptr;
+  // Branch-free input transform: v = max(v * sc + sh, floor).  Without an affine the scalar loads still happen (from the
+  // input itself, any readable address) and are replaced by (1, 0); without ReLU the floor is -inf.  No conditional code
+  // in the K loop: a conditionally used load is sunk by the compiler next to its use, which serialises load -> wait ->
+  // LDS write in the middle of the stage instead of prefetching a stage ahead.
+  const float* scale_n = has_affine ? a.scale + (long)n * a.Cin : a.x;
+  const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : a.x;
+  const float relu_floor = relu_in ? 0.0f : -__builtin_huge_valf();
 
   // ---- patch staging map: wave w stages input channels {w, w+4, ...} of the chunk; lane l element l + 64*i of the
   //      channel's [TZ][PR][PW] patch.  Per element only a plane offset and a validity bit are kept (constant over
@@ -186,22 +198,29 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
   const int nstages_all = a.n_cchunks * a.KD;
   const int st_begin = ks * a.stages_per_split;                       // this block's share of the K loop
   const int st_end = min(nstages_all, st_begin + a.stages_per_split);
-  const float4* wsrc = reinterpret_cast<const float4*>(a.wpk) + ((long)cotile * nstages_all) * (ASZ / 4);
+  const floatx4* wsrc = reinterpret_cast<const floatx4*>(a.wpk) + ((long)cotile * nstages_all) * (ASZ / 4);
+
+  // per-lane dump slots behind the two stage buffers (written, never read)
+  floatx4* const dump4 = reinterpret_cast<floatx4*>(smem + 2 * BUF) + lane;
+  float* const dump1 = smem + 2 * BUF + lane;
 
   float pv[NPE];        // staged patch values (raw)
   bool pvz[NPE];        // per-element depth validity (only varies per element when TZ > 1)
   bool sv[CPW];         // wave-uniform: channel exists (and, for TZ == 1, the depth slice is inside the volume)
   float sc[CPW], sh[CPW];
-  float4 av[NA4];
+  floatx4 av[NA4];
 #ifndef EMO_CONV_GLDS_A
-#define EMO_CONV_GLDS_A 0   /* 0: weight tile through VGPRs + ds_write_b128; 1: by LDS-DMA (global_load_lds).  Measured on
-                               MI355X: 0 is 1 % faster end to end and 5-8 % faster on the 64-row block config */
+#define EMO_CONV_GLDS_A 1   /* 1: weight tile by LDS-DMA (global_load_lds), issued at the top of the stage straight into the idle
+                               buffer: no VGPR round trip, and -- being a side-effecting builtin -- it stays where it is put;
+                               0: through VGPRs + ds_write_b128 (the scheduler sinks those loads next to the ds_write) */
 #endif
   constexpr int NGL = (ASZ * 4 + 1024 * SW - 1) / (1024 * SW);   // 1-KiB LDS-DMA pieces per staging wave
 
 // Both staging halves are macros (not lambdas / conditionals) so that pv[] / av[] are unconditionally defined
 // straight-line values and stay in VGPRs (a conditional or lambda-captured definition sent them to scratch).
-#define EMO_ISSUE_LOADS(stage_, dst_)                                                                 \
+#define EMO_ISSUE_LOADS(stage_, dst_) { EMO_ISSUE_PATCH(stage_); EMO_ISSUE_WEIGHTS(stage_, dst_); }
+
+#define EMO_ISSUE_PATCH(stage_)                                                                       \
   {                                                                                                   \
     const int cc_ = (stage_) / a.KD;                                                                  \
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
@@ -214,7 +233,8 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
       const bool zv_ = (unsigned)zu_ < (unsigned)a.D;                                                 \
       const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;            \
       sv[g] = cv_ && (TZ > 1 || zv_);                                                                 \
-      if (has_affine) { sc[g] = scale_n[cs_]; sh[g] = shift_n[cs_]; }                                 \
+      { const float s1_ = scale_n[cs_], s0_ = shift_n[cs_];                                           \
+        sc[g] = has_affine ? s1_ : 1.0f; sh[g] = has_affine ? s0_ : 0.0f; }                           \
       _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
         if (TZ == 1) {                                                                                \
           pvz[g * EPC + i] = true;                                                                    \
@@ -227,7 +247,11 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
         }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
-    const float4* ws_ = wsrc + (long)(stage_) * (ASZ / 4);                                            \
+  }
+
+#define EMO_ISSUE_WEIGHTS(stage_, dst_)                                                               \
+  {                                                                                                   \
+    const floatx4* ws_ = wsrc + (long)(stage_) * (ASZ / 4);                                           \
     if (EMO_CONV_GLDS_A) {                                                                            \
       /* weight tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), no VGPR round trip. */ \
       /* The LDS image is lane-linear = exactly the packed weight order.                               */ \
@@ -247,13 +271,15 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
     }                                                                                                 \
   }
 
+/* Stores are unconditional: lanes beyond the tile write to a private dump slot (address select, no branch). */ \
 #define EMO_STORE_STAGE(stage_, buf_)                                                                 \
   {                                                                                                   \
     if (!EMO_CONV_GLDS_A) {                                                                           \
-      float4* As4_ = reinterpret_cast<float4*>(buf_);                                                 \
+      floatx4* As4_ = reinterpret_cast<floatx4*>(buf_);                                               \
       _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                               \
         const int idx = stid + i * ST;                                                                \
-        if (idx < ASZ / 4) As4_[idx] = av[i];                                                         \
+        floatx4* d4_ = ((i + 1) * ST <= ASZ / 4 || idx < ASZ / 4) ? As4_ + idx : dump4;               \
+        *d4_ = av[i];                                                                                 \
       }                                                                                               \
     }                                                                                                 \
     float* Ps_ = (buf_) + ASZ;                                                                        \
@@ -261,20 +287,33 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
       float* Pc_ = Ps_ + (g * SW + sw) * CHS;                                                         \
       _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
         const int e = lane + i * 64;                                                                  \
-        if (e < CHS) {                                                                                \
-          float v = pv[g * EPC + i];                                                                  \
-          if (has_affine) v = __fmaf_rn(v, sc[g], sh[g]);                                             \
-          if (relu_in) v = fmaxf(v, 0.0f);                                                            \
-          /* zero padding applies to the transformed tensor */                                        \
-          Pc_[e] = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                 \
-        }                                                                                             \
+        float v = fmaxf(__fmaf_rn(pv[g * EPC + i], sc[g], sh[g]), relu_floor);                        \
+        /* zero padding applies to the transformed tensor */                                          \
+        v = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                        \
+        float* d_ = ((i + 1) * 64 <= CHS || e < CHS) ? Pc_ + e : dump1;                               \
+        *d_ = v;                                                                                      \
       }                                                                                               \
     }                                                                                                 \
   }
 
 #ifndef EMO_CONV_ABLATE
-#define EMO_CONV_ABLATE 0   /* timing experiments only: 1 = no global loads / LDS stores in the loop, 2 = also no barrier,
+#define EMO_CONV_ABLATE 0   /* timing experiments only: 4 = global loads issued but never written to LDS, 5 = LDS writes of
+                               stale registers without global loads, 1 = no global loads / LDS stores in the loop, 2 = also no barrier,
                                3 = MFMA stream only (operands read once) -- results are WRONG for any value != 0 */
+#endif
+#ifndef EMO_CONV_SCHED_FENCE
+#define EMO_CONV_SCHED_FENCE 0   /* 1: __builtin_amdgcn_sched_barrier around the prefetch (measured: makes the backend spill the
+                                    prefetched weight tile to scratch); 0: scheduler's choice */
+#endif
+#ifndef EMO_CONV_PIPE_W
+#define EMO_CONV_PIPE_W 0   /* with EMO_CONV_PIPE and register-staged weights (EMO_CONV_GLDS_A == 0): 1 = the weight tile is loop-carried
+                               in VGPRs like the patch; 0 = loaded at the top of the stage */
+#endif
+#ifndef EMO_CONV_PIPE
+#define EMO_CONV_PIPE 1   /* where the global loads of stage s+1 are issued: 0 = at the top of stage s (the scheduler then sinks
+                             them down to their first use at STORE_PAIR: ~0 prefetch distance, the memory latency is exposed once
+                             per stage); 1 = at the end of stage s-1, BEFORE that stage's closing barrier -- loads cannot be moved
+                             across the barrier's fences, so they are in flight for at least the first half of stage s */
 #endif
 #ifndef EMO_CONV_STORE_AT
 #define EMO_CONV_STORE_AT 1   /* 0: write the next stage into LDS after all MFMAs of this stage; 1: after half of them */
@@ -284,6 +323,11 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
   if (stages_data) {
     EMO_ISSUE_LOADS(st_begin, smem);
     EMO_STORE_STAGE(st_begin, smem);
+    if (EMO_CONV_PIPE && NPW == 0) {   // second stage in flight across the barrier (registers are loop-carried)
+      const int st1_ = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
+      EMO_ISSUE_PATCH(st1_);
+      if (EMO_CONV_PIPE_W && !EMO_CONV_GLDS_A) { EMO_ISSUE_WEIGHTS(st1_, smem); }
+    }
   }
   __syncthreads();
 
@@ -348,19 +392,44 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
     const float* Ps = cur + ASZ;
     if (NPW == 0) {
       // every wave stages and multiplies: loads first, LDS write of the next stage half way through the MFMAs
-      if (EMO_CONV_ABLATE == 0) { EMO_ISSUE_LOADS(stn, nxt); }
+      if (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 4) {
+        if (!EMO_CONV_PIPE) { EMO_ISSUE_PATCH(stn); }
+        if (!(EMO_CONV_PIPE && EMO_CONV_PIPE_W && !EMO_CONV_GLDS_A)) {
+          EMO_ISSUE_WEIGHTS(stn, nxt);   // LDS-DMA straight into the idle buffer (or through VGPRs when EMO_CONV_GLDS_A == 0)
+        }
+      }
+      // pin the software pipeline: the next stage's global loads are ISSUED here, before this stage's MFMAs, and are
+      // first touched (s_waitcnt + transform + LDS write) at STORE_PAIR -- without the fences the scheduler moves the
+      // loads down next to their use and the whole memory latency is exposed once per stage
+      if (EMO_CONV_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
+      if (EMO_CONV_ABLATE == 4) {   /* keep the loads alive without touching LDS */
+        _Pragma("unroll") for (int q = 0; q < NPE; ++q) asm volatile("" ::"v"(pv[q]));
+        _Pragma("unroll") for (int q = 0; q < NA4; ++q) asm volatile("" ::"v"(av[q].x), "v"(av[q].w));
+      }
 #pragma unroll
       for (int pair = 0; pair < KC / 2; ++pair) {
-        if (pair == STORE_PAIR && STORE_PAIR > 0 && EMO_CONV_ABLATE == 0) { EMO_STORE_STAGE(stn, nxt); }
+        if (pair == STORE_PAIR && STORE_PAIR > 0 && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 5)) {
+          if (EMO_CONV_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
+          EMO_STORE_STAGE(stn, nxt);
+        }
         EMO_MFMA_PAIR(pair);
       }
-      if (STORE_PAIR <= 0 && EMO_CONV_ABLATE == 0) { EMO_STORE_STAGE(stn, nxt); }
+      if (STORE_PAIR <= 0 && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 5)) {
+        if (EMO_CONV_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
+        EMO_STORE_STAGE(stn, nxt);
+      }
+      if (EMO_CONV_PIPE && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 4)) {
+        // the registers were consumed by EMO_STORE_STAGE above: refill them with stage st+2, before the barrier
+        const int stn2 = (st + 2) < st_end ? (st + 2) : (st_end - 1);
+        EMO_ISSUE_PATCH(stn2);
+        if (EMO_CONV_PIPE_W && !EMO_CONV_GLDS_A) { EMO_ISSUE_WEIGHTS(stn2, nxt); }
+      }
     } else {
       // MFMA waves of the wave-specialised variant: nothing but LDS reads and matrix instructions
 #pragma unroll
       for (int pair = 0; pair < KC / 2; ++pair) { EMO_MFMA_PAIR(pair); }
     }
-    if (EMO_CONV_ABLATE < 2) __syncthreads();
+    if (EMO_CONV_ABLATE < 2 || EMO_CONV_ABLATE >= 4) __syncthreads();
   }
 #undef EMO_MFMA_PAIR
 
@@ -402,6 +471,8 @@ __global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS, EMO_CONV_MIN_WAVES) 
 }
 
 #undef EMO_ISSUE_LOADS
+#undef EMO_ISSUE_PATCH
+#undef EMO_ISSUE_WEIGHTS
 #undef EMO_STORE_STAGE
 
 // host-side launcher for one instantiation
@@ -416,7 +487,7 @@ int conv_igemm_launch(ConvArgs a, hipStream_t s) {
   const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
   if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
-  const size_t lds = (size_t)(2 * Cfg::BUF) * sizeof(float);
+  const size_t lds = (size_t)(2 * Cfg::BUF + 256) * sizeof(float);   // two stage buffers + 64 float4 dump slots
   if (lds > 160 * 1024) return EMO_ERR_UNSUPPORTED;
   auto kern = conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   if (lds > 64 * 1024) {
