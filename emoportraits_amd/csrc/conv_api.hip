@@ -19,14 +19,18 @@ static int shape_of_width(int Wl) {
   return -1;
 }
 
+static int kc_of(int KH, int KW, int cfg) {
+  if (KH == 3 && KW == 3) return cfg == CFG_A ? EMO_CONV_KC_3X3_A : EMO_CONV_KC_3X3;
+  if (KH == 1 && KW == 1) return EMO_CONV_KC_1X1;
+  if (KH == 1 && KW == 7) return EMO_CONV_KC_1X7;
+  return 0;
+}
+
 extern "C" int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC) {
   if (!BM || !KC) return EMO_ERR_BAD_ARG;
   if (cfg == CFG_A) *BM = 128; else if (cfg == CFG_B) *BM = 64; else if (cfg == CFG_C) *BM = 32; else return EMO_ERR_BAD_ARG;
-  if (KH == 3 && KW == 3) *KC = EMO_CONV_KC_3X3;
-  else if (KH == 1 && KW == 1) *KC = EMO_CONV_KC_1X1;
-  else if (KH == 1 && KW == 7) *KC = EMO_CONV_KC_1X7;
-  else return EMO_ERR_UNSUPPORTED;
-  return EMO_OK;
+  *KC = kc_of(KH, KW, cfg);
+  return *KC ? EMO_OK : EMO_ERR_UNSUPPORTED;
 }
 
 // second half of a split-K launch: out = act(sum_ks partial[ks] + bias + residual), ks ascending (deterministic)
@@ -56,17 +60,11 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* 
   }
 }
 
-static int kc_of(int KH, int KW) {
-  if (KH == 3 && KW == 3) return EMO_CONV_KC_3X3;
-  if (KH == 1 && KW == 1) return EMO_CONV_KC_1X1;
-  if (KH == 1 && KW == 7) return EMO_CONV_KC_1X7;
-  return 0;
-}
 
 // launch heuristic: split the K loop until the launch has >= 2 blocks per CU, keeping >= 8 stages per split
 extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW, int ups,
                                      int cfg) {
-  const int kc = kc_of(KH, KW);
+  const int kc = kc_of(KH, KW, cfg);
   if (!kc || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 || cfg < 0 || cfg >= N_CFGS) return EMO_ERR_BAD_ARG;
   const int bm = cfg == CFG_A ? 128 : cfg == CFG_B ? 64 : 32;
   const long pos = (long)N * D * (ups ? 4 : 1) * H * W;
@@ -112,7 +110,7 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
     return EMO_ERR_UNSUPPORTED;
   }
   if (!fn) return EMO_ERR_UNSUPPORTED;
-  const int nstages = ((Cin + kc_of(KH, KW) - 1) / kc_of(KH, KW)) * KD;
+  const int nstages = ((Cin + kc_of(KH, KW, cfg) - 1) / kc_of(KH, KW, cfg)) * KD;
   if (ksplit > nstages) ksplit = nstages;
   a.stages_per_split = (nstages + ksplit - 1) / ksplit;
   a.ksplit = (nstages + a.stages_per_split - 1) / a.stages_per_split;   // no empty split

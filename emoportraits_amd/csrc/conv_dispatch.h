@@ -14,6 +14,9 @@ typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 #ifndef EMO_CONV_KC_3X3
 #define EMO_CONV_KC_3X3 4
 #endif
+#ifndef EMO_CONV_KC_3X3_A
+#define EMO_CONV_KC_3X3_A EMO_CONV_KC_3X3   /* the 128-row config may use a shorter stage (smaller LDS tiles -> 4 instead of 3 blocks/CU) */
+#endif
 #define EMO_CONV_KC_1X1 16   /* 32 measured slower (64 KiB+ LDS, 163 VGPR: 67 vs 73 TF on 1536->512 @64^2) */
 #define EMO_CONV_KC_1X7 4
 

@@ -72,13 +72,14 @@ struct ConvCfg {
   static constexpr int SW = NPW ? NPW : 4;          // waves that stage
   static constexpr int ST = SW * 64;                // threads that stage
   static constexpr int THREADS = 256 + 64 * NPW;
-  static constexpr int CPW = KC / SW;               // channels staged per staging wave per stage
-  static constexpr int EPC = (CHS + 63) / 64;       // patch elements per lane per channel
+  static constexpr int WPC = KC >= SW ? 1 : SW / KC;           // staging waves that share one input channel's patch
+  static constexpr int CPW = KC >= SW ? KC / SW : 1;           // channels staged per staging wave per stage
+  static constexpr int EPC = (CHS + 64 * WPC - 1) / (64 * WPC); // patch elements per lane per channel
   static constexpr int NPE = CPW * EPC;             // patch elements per thread per stage
   static constexpr int NA4 = (ASZ / 4 + SW * 64 - 1) / (SW * 64); // float4 weight loads per staging thread
   static_assert(WGM * WGP == 4, "4 waves per block");
   static_assert(TZ * TR * TW == BP, "position tile must equal BP");
-  static_assert(KC % 4 == 0, "one input channel per wave and stage group");
+  static_assert(KC % 2 == 0 && (KC % SW == 0 || SW % KC == 0), "whole channels per wave, or whole waves per channel");
   static_assert(EMO_CONV_PRODUCERS == 0 || EMO_CONV_PRODUCERS == 2, "0 or 2 loader waves");
   static_assert(ASZ % 4 == 0, "weight tile must be float4-copyable");
   static_assert(TM * TP <= 4, "accumulator budget");
@@ -119,6 +120,9 @@ void conv_igemm_kernel(const ConvArgs a) {
   const bool stages_data = NPW == 0 || is_producer;
   const int sw = NPW ? (wave >= 4 ? wave - 4 : 0) : wave; // index among the staging waves
   const int stid = sw * 64 + lane;                        // index among the staging threads
+  constexpr int WPC = Cfg::WPC;
+  const int chan0 = KC >= SW ? sw : sw % KC;           // channel (within a chunk) this wave stages; further ones at + g*SW
+  const int part = KC >= SW ? 0 : sw / KC;               // which 64-element slices of that channel's patch (WPC waves share it)
   const int cwave = wave & 3;
   const int wm = cwave / WGP, wp = cwave % WGP;
   const int m0 = wm * TM * 32, p0 = wp * TP * 32;
@@ -180,7 +184,7 @@ void conv_igemm_kernel(const ConvArgs a) {
   bool p_ok[EPC];      // element exists and its (y, x) lies inside the logical image
 #pragma unroll
   for (int i = 0; i < EPC; ++i) {
-    const int e = lane + i * 64;
+    const int e = lane + (i * WPC + part) * 64;
     const int pz = e / (PR * PW);
     const int rem2 = e - pz * (PR * PW);
     const int pr = rem2 / PW;
@@ -226,7 +230,7 @@ void conv_igemm_kernel(const ConvArgs a) {
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
     const int ci0_ = cc_ * KC;                                                                        \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
-      const int c_ = ci0_ + g * SW + sw;                                                              \
+      const int c_ = ci0_ + g * SW + chan0;                                                           \
       const bool cv_ = c_ < a.Cin;                                                                    \
       const int cs_ = cv_ ? c_ : 0;                                                                   \
       const int zu_ = z0 + t_ - padD;           /* depth of tile slice 0 */                           \
@@ -284,13 +288,13 @@ void conv_igemm_kernel(const ConvArgs a) {
     }                                                                                                 \
     float* Ps_ = (buf_) + ASZ;                                                                        \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
-      float* Pc_ = Ps_ + (g * SW + sw) * CHS;                                                         \
+      float* Pc_ = Ps_ + (g * SW + chan0) * CHS;                                                      \
       _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
-        const int e = lane + i * 64;                                                                  \
+        const int e = lane + (i * WPC + part) * 64;                                                   \
         float v = fmaxf(__fmaf_rn(pv[g * EPC + i], sc[g], sh[g]), relu_floor);                        \
         /* zero padding applies to the transformed tensor */                                          \
         v = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                        \
-        float* d_ = ((i + 1) * 64 <= CHS || e < CHS) ? Pc_ + e : dump1;                               \
+        float* d_ = ((i + 1) * WPC * 64 <= CHS || e < CHS) ? Pc_ + e : dump1;                         \
         *d_ = v;                                                                                      \
       }                                                                                               \
     }                                                                                                 \

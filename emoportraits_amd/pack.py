@@ -7,6 +7,7 @@ path.  The folding formulas restate what the reference recomputes on every forwa
   weight std     networks/volumetric_avatar/utils.py:893-900, :908-914      (W - mean) / (std_unbiased + 1e-5)
 """
 import ctypes
+import functools
 
 import torch
 
@@ -109,7 +110,12 @@ def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
     return best[1]
 
 
-_KC = {(3, 3): 4, (1, 1): 16, (1, 7): 4}   # input channels per K stage (emo_conv_pack_info)
+@functools.lru_cache(maxsize=None)
+def _kc(kh, kw, cfg):
+    """input channels per K stage of a block config (emo_conv_pack_info)"""
+    return conv_pack_info(kh, kw, cfg)[1]
+
+
 _MAX_KSPLIT = 16
 
 
@@ -124,9 +130,9 @@ def ksplit_for(blocks, nstages):
 def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
     """(block config, K split) of one launch: fill the 256 CUs first (by splitting K if the tile grid is small), then
     least channel padding, then the larger tile"""
-    nstages = -(-cin // _KC[(kh, kw)]) * kd
     best = None
     for cfg in allowed:
+        nstages = -(-cin // _kc(kh, kw, cfg)) * kd
         bm = _BM[cfg]
         cot = -(-cout // bm)
         blocks = cot * n_pos_tiles
