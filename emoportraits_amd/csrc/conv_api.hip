@@ -9,6 +9,12 @@ conv_launch_fn conv_lookup_1x1_B(int, int);
 conv_launch_fn conv_lookup_1x1_C(int, int);
 conv_launch_fn conv_lookup_1x7_A(int, int);
 conv_launch_fn conv_lookup_1x7_B(int, int);
+conv_launch_fn conv_lookup_f16_3x3_A(int, int);
+conv_launch_fn conv_lookup_f16_3x3_B(int, int);
+conv_launch_fn conv_lookup_f16_1x1_A(int, int);
+conv_launch_fn conv_lookup_f16_1x1_B(int, int);
+
+enum { PREC_F32 = 0, PREC_F16 = 1 };   // MFMA operand format (accumulation and all tensors in HBM are fp32 either way)
 
 static int shape_of_width(int Wl) {
   if (Wl >= 128 && Wl % 128 == 0) return SHAPE_W128;
@@ -19,7 +25,11 @@ static int shape_of_width(int Wl) {
   return -1;
 }
 
-static int kc_of(int KH, int KW, int cfg) {
+static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
+  if (prec == PREC_F16) {
+    if (cfg != CFG_A && cfg != CFG_B) return 0;
+    return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : (KH == 1 && KW == 1) ? EMO_CONV_KC_F16_1X1 : 0;
+  }
   if (KH == 3 && KW == 3) return cfg == CFG_A ? EMO_CONV_KC_3X3_A : EMO_CONV_KC_3X3;
   if (KH == 1 && KW == 1) return EMO_CONV_KC_1X1;
   if (KH == 1 && KW == 7) return EMO_CONV_KC_1X7;
@@ -62,6 +72,13 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* 
 
 
 // launch heuristic: split the K loop until the launch has >= 2 blocks per CU, keeping >= 8 stages per split
+extern "C" int emo_conv_pack_info_f16(int KH, int KW, int cfg, int* BM, int* KC) {
+  if (!BM || !KC) return EMO_ERR_BAD_ARG;
+  if (cfg == CFG_A) *BM = 128; else if (cfg == CFG_B) *BM = 64; else return EMO_ERR_UNSUPPORTED;
+  *KC = kc_of(KH, KW, cfg, PREC_F16);
+  return *KC ? EMO_OK : EMO_ERR_UNSUPPORTED;
+}
+
 extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW, int ups,
                                      int cfg) {
   const int kc = kc_of(KH, KW, cfg);
@@ -76,10 +93,10 @@ extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int
   return want < 1 ? 1 : (int)want;
 }
 
-extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias, const float* scale,
-                                  const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
-                                  int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
-                                  int cfg, int ksplit, float* workspace, void* stream) {
+static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const float* bias, const float* scale,
+                               const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D, int H,
+                               int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups, int cfg,
+                               int ksplit, float* workspace, void* stream) {
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
   if (ksplit < 1 || (ksplit > 1 && !workspace)) return EMO_ERR_BAD_ARG;
   if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
@@ -92,7 +109,7 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
   if (ups && D != 1) return EMO_ERR_UNSUPPORTED;
   if ((long)Cin * D * H * W >= (1L << 31)) return EMO_ERR_UNSUPPORTED;   // 32-bit per-sample element offsets
   ConvArgs a;
-  a.x = x; a.wpk = wpk; a.bias = bias; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
+  a.x = x; a.wpk = reinterpret_cast<const float*>(wpk); a.bias = bias; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
   a.Dl = D; a.Hl = ups ? 2 * H : H; a.Wl = ups ? 2 * W : W;
   a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
@@ -100,7 +117,12 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;
-  if (KH == 3 && KW == 3) {
+  if (prec == PREC_F16) {
+    if (KD != 1 && !(KD == 3 && KH == 3)) return EMO_ERR_UNSUPPORTED;
+    if (KH == 3 && KW == 3) fn = cfg == CFG_A ? conv_lookup_f16_3x3_A(shape, ups) : cfg == CFG_B ? conv_lookup_f16_3x3_B(shape, ups) : nullptr;
+    else if (KH == 1 && KW == 1) fn = cfg == CFG_A ? conv_lookup_f16_1x1_A(shape, ups) : cfg == CFG_B ? conv_lookup_f16_1x1_B(shape, ups) : nullptr;
+    else return EMO_ERR_UNSUPPORTED;
+  } else if (KH == 3 && KW == 3) {
     fn = cfg == CFG_A ? conv_lookup_3x3_A(shape, ups) : cfg == CFG_B ? conv_lookup_3x3_B(shape, ups) : conv_lookup_3x3_C(shape, ups);
   } else if (KH == 1 && KW == 1) {
     fn = cfg == CFG_A ? conv_lookup_1x1_A(shape, ups) : cfg == CFG_B ? conv_lookup_1x1_B(shape, ups) : conv_lookup_1x1_C(shape, ups);
@@ -110,7 +132,9 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
     return EMO_ERR_UNSUPPORTED;
   }
   if (!fn) return EMO_ERR_UNSUPPORTED;
-  const int nstages = ((Cin + kc_of(KH, KW, cfg) - 1) / kc_of(KH, KW, cfg)) * KD;
+  const int kc = kc_of(KH, KW, cfg, prec);
+  if (!kc) return EMO_ERR_UNSUPPORTED;
+  const int nstages = ((Cin + kc - 1) / kc) * KD;
   if (ksplit > nstages) ksplit = nstages;
   a.stages_per_split = (nstages + ksplit - 1) / ksplit;
   a.ksplit = (nstages + a.stages_per_split - 1) / a.stages_per_split;   // no empty split
@@ -123,4 +147,20 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
   hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, workspace, bias,
                      res, out, total, a.ksplit, Cout, a.Dl, a.Hl, a.Wl, act, res_ups);
   return emo_launch_status();
+}
+
+extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias, const float* scale,
+                                  const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
+                                  int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
+                                  int cfg, int ksplit, float* workspace, void* stream) {
+  return conv_igemm_dispatch(PREC_F32, x, wpk, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
+                             relu_in, act, res_ups, cfg, ksplit, workspace, stream);
+}
+
+extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias, const float* scale,
+                                       const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
+                                       int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
+                                       int cfg, int ksplit, float* workspace, void* stream) {
+  return conv_igemm_dispatch(PREC_F16, x, wpk16, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
+                             relu_in, act, res_ups, cfg, ksplit, workspace, stream);
 }

@@ -94,7 +94,7 @@ class InferenceWrapper:
                  fixed_bounding_box=False, project_dir='./', folder='mp_logs', model_='va',
                  torch_home='', debug=False, print_model=False, print_params=True, args_overwrite={}, state_dict=None,
                  pose_momentum=0.5, rank=0, args_path=None, embedders=None, head_pose_regressor_path=None,
-                 use_graphs=False):
+                 use_graphs=False, precision="f32"):
         if not use_gpu:
             raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
         if model_ != 'va':
@@ -125,7 +125,7 @@ class InferenceWrapper:
         self.model_checkpoint = pathlib.Path(project_dir) / folder / experiment_name / 'checkpoints' / model_file_name
         self.model_dict = torch.load(self.model_checkpoint, map_location='cpu') if state_dict is None else state_dict
         schema.check_state_dict(self.model_dict, self.cfg)        # strict: the reference's strict=False hides mismatches
-        self.hot_path = nets.HotPath(self.model_dict, self.cfg, self.device)
+        self.hot_path = nets.HotPath(self.model_dict, self.cfg, self.device, precision=precision)   # 'f16': opt-in, see nets.HotPath
         self.model = HipModel(self.hot_path, self.args)
         if rank == 0 and print_params:
             n = sum(v.numel() for k, v in self.model_dict.items() if k.startswith(schema.HOT_PATH_PREFIXES))

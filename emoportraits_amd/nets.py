@@ -264,22 +264,27 @@ class HotPath:
     driver_pass replays notebooks/infer.py:583-637 for a BATCH of driver frames sharing one source identity
     (the reference loops batch-1 calls, F5).  source_pass replays infer.py:433-507."""
 
-    def __init__(self, state_dict, cfg, device="cuda:0", with_source=True):
+    def __init__(self, state_dict, cfg, device="cuda:0", with_source=True, precision="f32"):
+        """precision: 'f32' (default: exact-fp32 MFMA everywhere) or 'f16' (opt-in reduced precision, BASELINE configs[4]:
+        fp16 MFMA operands with fp32 accumulation in the 3x3 / 1x1 convolutions; tensors in HBM stay fp32)"""
         self.cfg = cfg
         self.device = torch.device(device)
+        self.precision = precision
         sd = state_dict
-        self.embed = WarpEmbed(sd, cfg, self.device)
-        self.uv_generator = WarpGenerator(sd, "uv_generator_nw", cfg, self.device)
-        self.decoder = Decoder(sd, "decoder_nw", cfg, self.device)
         self.pad = cfg["grid_sample_padding_mode"]
         self.c, self.d, self.s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
         self.with_source = with_source
-        if with_source:
-            self.xy_generator = WarpGenerator(sd, "xy_generator_nw", cfg, self.device)
-            self.volume_source = VPNResBlocks(sd, "volume_source_nw", cfg, self.device)
-            self.volume_process = Unet3D(sd, "volume_process_nw", cfg, self.device)
-            from .encoder import LocalEncoder
-            self.local_encoder = LocalEncoder(sd, "local_encoder_nw", cfg, self.device)
+        from .pack import conv_precision
+        with conv_precision(precision):
+            self.embed = WarpEmbed(sd, cfg, self.device)
+            self.uv_generator = WarpGenerator(sd, "uv_generator_nw", cfg, self.device)
+            self.decoder = Decoder(sd, "decoder_nw", cfg, self.device)
+            if with_source:
+                self.xy_generator = WarpGenerator(sd, "xy_generator_nw", cfg, self.device)
+                self.volume_source = VPNResBlocks(sd, "volume_source_nw", cfg, self.device)
+                self.volume_process = Unet3D(sd, "volume_process_nw", cfg, self.device)
+                from .encoder import LocalEncoder
+                self.local_encoder = LocalEncoder(sd, "local_encoder_nw", cfg, self.device)
 
     # ---- per identity -------------------------------------------------------------------------------
     def source_pass(self, source_img_masked, idt_embed, source_pose_embed, theta_src, keep=False):

@@ -178,11 +178,12 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
     if ksplit is not None:
         ks = int(ksplit)
     ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None
-    rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
-                                hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
-                                layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
-                                hip.ptr(ws), hip.current_stream())
-    hip.check(rc, f"emo_conv_igemm_f32[{layer.name}]")
+    entry = lib.emo_conv_igemm_f16acc32 if layer.precision == "f16" else lib.emo_conv_igemm_f32
+    rc = entry(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
+               hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
+               layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
+               hip.ptr(ws), hip.current_stream())
+    hip.check(rc, f"emo_conv_igemm_{layer.precision}[{layer.name}]")
     return out
 
 

@@ -6,6 +6,7 @@ path.  The folding formulas restate what the reference recomputes on every forwa
   spectral norm  utils/spectral_norm.py:96-168 (eval: no power iteration)   W / (u . (W_mat v))
   weight std     networks/volumetric_avatar/utils.py:893-900, :908-914      (W - mean) / (std_unbiased + 1e-5)
 """
+import contextlib
 import ctypes
 import functools
 
@@ -74,6 +75,29 @@ def conv_pack_info(kh, kw, cfg):
     return bm.value, kc.value
 
 
+def conv_pack_info_f16(kh, kw, cfg):
+    lib = hip.load()
+    bm, kc = ctypes.c_int(), ctypes.c_int()
+    hip.check(lib.emo_conv_pack_info_f16(kh, kw, cfg, ctypes.byref(bm), ctypes.byref(kc)), "emo_conv_pack_info_f16")
+    return bm.value, kc.value
+
+
+def pack_weight_f16(w, cfg):
+    """fp16 operand layout of emo_conv_igemm_f16acc32: [co_tile][cin chunk][kd][k-group of 8][tap][half][BM][4] with
+    channel-in-chunk = 8*group + 4*half + 0..3  ->  flat fp16 tensor (round-to-nearest-even of the folded fp32 weight)"""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, kd, kh, kw = w.shape
+    bm, kc = conv_pack_info_f16(kh, kw, cfg)
+    n_cot = -(-cout // bm)
+    n_cc = -(-cin // kc)
+    wp = torch.zeros((n_cot * bm, n_cc * kc, kd, kh * kw), dtype=torch.float32)
+    wp[:cout, :cin] = w.reshape(cout, cin, kd, kh * kw).float()
+    # [cot, BM, cc, group, half, k4, kd, tap] -> [cot, cc, kd, group, tap, half, BM, k4]
+    wp = wp.view(n_cot, bm, n_cc, kc // 8, 2, 4, kd, kh * kw).permute(0, 2, 6, 3, 7, 4, 1, 5).contiguous()
+    return wp.view(-1).to(torch.float16)
+
+
 def pack_weight(w, cfg):
     """w [Cout, Cin, KH, KW] or [Cout, Cin, KD, KH, KW] -> flat fp32 tensor
     [co_tile][cin chunk][kd][pair][tap][half][BM]   (stage index = chunk*KD + kd; k-local = (pair*TAPS+tap)*2+half)"""
@@ -111,9 +135,9 @@ def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
 
 
 @functools.lru_cache(maxsize=None)
-def _kc(kh, kw, cfg):
-    """input channels per K stage of a block config (emo_conv_pack_info)"""
-    return conv_pack_info(kh, kw, cfg)[1]
+def _kc(kh, kw, cfg, precision="f32"):
+    """input channels per K stage of a block config (emo_conv_pack_info / emo_conv_pack_info_f16)"""
+    return (conv_pack_info_f16 if precision == "f16" else conv_pack_info)(kh, kw, cfg)[1]
 
 
 _MAX_KSPLIT = 16
@@ -127,12 +151,12 @@ def ksplit_for(blocks, nstages):
     return max(1, min(-(-_FILL_BLOCKS // blocks), nstages // 8, _MAX_KSPLIT))
 
 
-def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
+def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C), precision="f32"):
     """(block config, K split) of one launch: fill the 256 CUs first (by splitting K if the tile grid is small), then
     least channel padding, then the larger tile"""
     best = None
     for cfg in allowed:
-        nstages = -(-cin // _kc(kh, kw, cfg)) * kd
+        nstages = -(-cin // _kc(kh, kw, cfg, precision)) * kd
         bm = _BM[cfg]
         cot = -(-cout // bm)
         blocks = cot * n_pos_tiles
@@ -143,11 +167,35 @@ def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C
     return best[1], best[2]
 
 
+_build_precision = "f32"
+
+
+@contextlib.contextmanager
+def conv_precision(precision):
+    """precision requested for the PackedConvs built inside the block ('f32' | 'f16'); layers the fp16-operand kernel
+    does not cover (7x7 stem, heads with fewer than 32 output channels) stay fp32.  Used by HotPath / Stage2
+    constructors; construction is single-threaded."""
+    global _build_precision
+    if precision not in ("f32", "f16"):
+        raise ValueError("precision must be 'f32' or 'f16'")
+    old, _build_precision = _build_precision, precision
+    try:
+        yield
+    finally:
+        _build_precision = old
+
+
+def supports_f16(cout, kd, kh, kw):
+    return (kh, kw) in ((3, 3), (1, 1)) and kd in (1, 3) and cout >= 32
+
+
 class PackedConv:
     """One convolution of the hot path, ready for emo_conv_igemm_f32.  Weights are packed lazily per block config
-    (the best config depends on the batch size of the call); `cfg` pins one config (tests / benchmarks)."""
+    (the best config depends on the batch size of the call); `cfg` pins one config (tests / benchmarks).
+    precision="f16" (opt-in, BASELINE configs[4]): fp16 MFMA operands with fp32 accumulation, emo_conv_igemm_f16acc32;
+    available for 3x3 / 1x1 kernels on the 128- and 64-row configs, anything else raises."""
 
-    def __init__(self, name, weight, bias, device, cfg=None):
+    def __init__(self, name, weight, bias, device, cfg=None, precision="f32"):
         if weight.dim() == 4:
             cout, cin, kh, kw = weight.shape
             kd = 1
@@ -159,14 +207,21 @@ class PackedConv:
         self._weight = weight.float().contiguous()      # folded fp32 weight kept on the host for lazy packing
         self._packed = {}
         self.pinned_cfg = cfg
-        self.allowed = (CFG_A, CFG_B) if (kh, kw) == (1, 7) else (CFG_A, CFG_B, CFG_C)
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        if precision == "f16" and ((kh, kw) not in ((3, 3), (1, 1)) or kd not in (1, 3) or cfg == CFG_C):
+            raise ValueError(f"{name}: the fp16-operand kernel covers 3x3 / 1x1 convolutions on block configs 0 and 1")
+        self.precision = precision
+        self.allowed = (CFG_A, CFG_B) if ((kh, kw) == (1, 7) or precision == "f16") else (CFG_A, CFG_B, CFG_C)
         self.bias = None if bias is None else bias.float().contiguous().to(device)
         self.macs_per_position = cout * cin * kd * kh * kw
-        self.packed(choose_cfg(cout) if cfg is None else cfg)
+        first = choose_cfg(cout) if cfg is None else cfg
+        self.packed(first if first in self.allowed else CFG_B)
 
     def packed(self, cfg):
         if cfg not in self._packed:
-            self._packed[cfg] = pack_weight(self._weight, cfg).to(self.device)
+            fn = pack_weight_f16 if self.precision == "f16" else pack_weight
+            self._packed[cfg] = fn(self._weight, cfg).to(self.device)
         return self._packed[cfg]
 
     def cfg_for(self, n_pos_tiles):
@@ -177,9 +232,13 @@ class PackedConv:
     def plan_for(self, n_pos_tiles):
         """(cfg, ksplit) for a launch over n_pos_tiles 128-position tiles"""
         allowed = (self.pinned_cfg,) if self.pinned_cfg is not None else self.allowed
-        return plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, allowed)
+        return plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, allowed, self.precision)
 
     @classmethod
-    def from_state_dict(cls, sd, prefix, kind, device, cfg=None):
+    def from_state_dict(cls, sd, prefix, kind, device, cfg=None, precision=None):
+        """precision None: the ambient conv_precision() request, applied where the fp16-operand kernel exists"""
         w, b = folded_conv(sd, prefix, kind)
-        return cls(prefix, w, b, device, cfg)
+        if precision is None:
+            kd = w.shape[2] if w.dim() == 5 else 1
+            precision = _build_precision if supports_f16(w.shape[0], kd, w.shape[-2], w.shape[-1]) else "f32"
+        return cls(prefix, w, b, device, cfg, precision)

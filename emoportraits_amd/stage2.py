@@ -204,12 +204,17 @@ class DecoderStage2:
 
 
 class Stage2:
-    def __init__(self, state_dict, cfg, device="cuda:0"):
+    def __init__(self, state_dict, cfg, device="cuda:0", precision="f32"):
+        """precision 'f16': the "fp16 MFMA convs" mode of BASELINE.json configs[4] (fp16 operands, fp32 accumulation,
+        fp32 tensors); 'f32' (default): exact fp32"""
+        from .pack import conv_precision
         self.cfg = cfg
         self.device = torch.device(device)
-        self.encoder = LocalEncoder(state_dict, "local_encoder", cfg, self.device, image_size=cfg["output_size_s2"],
-                                    latent_size=cfg["gen_latent_texture_size2"], ws=_uses_ws(cfg))
-        self.decoder = DecoderStage2(state_dict, "decoder", cfg, self.device)
+        self.precision = precision
+        with conv_precision(precision):
+            self.encoder = LocalEncoder(state_dict, "local_encoder", cfg, self.device, image_size=cfg["output_size_s2"],
+                                        latent_size=cfg["gen_latent_texture_size2"], ws=_uses_ws(cfg))
+            self.decoder = DecoderStage2(state_dict, "decoder", cfg, self.device)
 
     def refine(self, img, mask, face_mask, keep=False):
         """img [B,3,S2,S2] in [0,1] (stage-1 output at output_size_s2), mask = matte [B,1,S2,S2], face_mask [B,1,S2,S2]
@@ -230,7 +235,7 @@ class InferenceWrapper:
     def __init__(self, experiment_name, which_epoch='latest', model_file_name='', use_gpu=True, num_gpus=1,
                  fixed_bounding_box=False, project_dir='./', torch_home='', debug=False, print_model=False,
                  args_overwrite={}, pose_momentum=0.5, experiment_name_s1=None, model_file_name_s1=None, cloth=False,
-                 state_dict=None, args_path=None, embedders=None):
+                 state_dict=None, args_path=None, embedders=None, precision="f32"):
         if not use_gpu:
             raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
         self.cloth = cloth
@@ -250,7 +255,7 @@ class InferenceWrapper:
         self.model_checkpoint_s2 = pathlib.Path(project_dir) / 'logs_s2' / experiment_name / 'checkpoints' / model_file_name
         self.model_dict_s2 = torch.load(self.model_checkpoint_s2, map_location='cpu') if state_dict is None else state_dict
         check_state_dict(self.model_dict_s2, self.cfg)                              # the reference loads strict=False (:116)
-        self.model_two = Stage2(self.model_dict_s2, self.cfg, self.device)
+        self.model_two = Stage2(self.model_dict_s2, self.cfg, self.device, precision=precision)   # 'f16': configs[4] mode
         self.embedders = dict(embedders or {})
 
     def forward(self, img, cloth=False, mask=None, face_mask=None):

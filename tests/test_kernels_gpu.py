@@ -27,7 +27,7 @@ def rel_err(got, ref):
 
 
 def run_conv(N, Cin, Cout, dims, k, cfg, affine=False, relu_in=False, ups=False, res=False, res_ups=False,
-             bias=True, act="none", seed=0, ksplit=None, inplace=False):
+             bias=True, act="none", seed=0, ksplit=None, inplace=False, precision="f32"):
     g = torch.Generator().manual_seed(seed)
     three_d = len(dims) == 3
     x = torch.randn(N, Cin, *dims, generator=g)
@@ -61,7 +61,7 @@ def run_conv(N, Cin, Cout, dims, k, cfg, affine=False, relu_in=False, ups=False,
         ref = torch.sigmoid(ref)
     elif act == "relu":
         ref = F.relu(ref)
-    layer = pack.PackedConv("test", w, b, DEV, cfg=cfg)
+    layer = pack.PackedConv("test", w, b, DEV, cfg=cfg, precision=precision)
     rd = None if r is None else r.to(DEV)
     got = ops.conv_igemm(x.to(DEV), layer, None if scale is None else scale.to(DEV),
                          None if shift is None else shift.to(DEV), relu_in=relu_in, ups=ups,
@@ -106,6 +106,27 @@ def test_conv_split_k_equals_single_pass(case, ksplit):
     assert e < 2e-5, e
     e1, got1, _ = run_conv(seed=7, ksplit=1, **case)
     assert (got - got1).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, Cin=40, Cout=72, dims=(64, 64), k=3, cfg=0, affine=True, relu_in=True, res=True),
+    dict(N=2, Cin=64, Cout=40, dims=(16, 16), k=3, cfg=1, ups=True, res=True, res_ups=True, act="tanh"),
+    dict(N=1, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=1, affine=True, relu_in=True),
+    dict(N=1, Cin=70, Cout=33, dims=(8, 8, 8), k=3, cfg=1, affine=True, relu_in=True, bias=False),
+    dict(N=1, Cin=200, Cout=48, dims=(32, 32), k=1, cfg=1, act="sigmoid"),
+    dict(N=2, Cin=96, Cout=130, dims=(64, 64), k=1, cfg=0, ups=True),
+    dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=0, affine=True, relu_in=True, ksplit=3),
+])
+def test_conv_fp16_operands(case):
+    """opt-in reduced-precision mode (BASELINE configs[4]): fp16 MFMA operands, fp32 accumulation.  Operand rounding is
+    2^-11 relative, so the output agrees with the fp32 reference to ~1e-3 of max|out| (bound 3e-3); same fused prologue /
+    epilogue, ragged channel chunks (Cin not a multiple of 8 / 32), up-sampling gather, 3-D taps and K split."""
+    e, got, ref = run_conv(seed=11, precision="f16", **case)
+    assert got.shape == ref.shape
+    print("PARITY conv fp16 operands:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    assert e < 3e-3, e
+    with pytest.raises(ValueError):
+        pack.PackedConv("bad", torch.zeros(8, 8, 7, 7), None, DEV, precision="f16")
 
 
 def test_conv3d_1x1x1():

@@ -30,6 +30,7 @@ def timeit(fn, iters=10, warmup=2):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     quick = "--quick" in sys.argv
+    f16 = "--f16" in sys.argv     # also time the opt-in fp16-operand kernels (emo_conv_igemm_f16acc32)
     torch.backends.cudnn.benchmark = True
     # (Cin, Cout, dims, k, ups)
     shapes = [(1536, 512, (64, 64), 1, False), (512, 512, (64, 64), 3, False),
@@ -67,6 +68,12 @@ def main():
             ms = timeit(lambda: ops.conv_igemm(x, layer, scale, shift, relu_in=True, ups=ups, out=out))
             rec[f"hip_cfg{cfg}_ms"] = round(ms, 3)
             rec[f"hip_cfg{cfg}_tflops"] = round(flops / ms / 1e9, 1)
+            if f16 and cfg in (0, 1) and k in (1, 3):
+                lh = pack.PackedConv("b16", w, None, DEV, cfg=cfg, precision="f16")
+                ops.conv_igemm(x, lh, scale, shift, relu_in=True, ups=ups, out=out)
+                msh = timeit(lambda: ops.conv_igemm(x, lh, scale, shift, relu_in=True, ups=ups, out=out))
+                rec[f"f16_cfg{cfg}_ms"] = round(msh, 3)
+                rec[f"f16_cfg{cfg}_tflops"] = round(flops / msh / 1e9, 1)
         rec["auto_cfg"] = pack.choose_cfg(cout)
         print(json.dumps(rec), flush=True)
     # GroupNorm statistics kernel vs torch group_norm+relu (which the conv staging makes unnecessary)

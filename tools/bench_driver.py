@@ -26,10 +26,11 @@ def timeit(fn, iters=5, warmup=2):
 
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    Bs = [int(a) for a in sys.argv[2:]] or [1, 4, 8, 16]
+    precision = "f16" if "--f16" in sys.argv else "f32"      # --f16: opt-in fp16-operand convs (not the bench mode)
+    Bs = [int(a) for a in sys.argv[2:] if not a.startswith("--")] or [1, 4, 8, 16]
     cfg = config.hot_path_config(overrides={"image_size": S})
     sd = random_init.random_state_dict(cfg, seed=0, with_source=False)
-    hp = nets.HotPath(sd, cfg, DEV, with_source=False)
+    hp = nets.HotPath(sd, cfg, DEV, with_source=False, precision=precision)
     g = torch.Generator().manual_seed(1)
     canonical = torch.randn(1, 96, 16, 64, 64, generator=g).to(DEV)
     ccl = hp.prepare_canonical(canonical)
@@ -44,7 +45,7 @@ def main():
         warped = ops.grid_sample3d(ccl, delta=delta, in_layout="ndhwc", out_layout="ndhwc")
         aligned = ops.grid_sample3d(warped, theta=theta, in_layout="ndhwc", out_layout="ncdhw")
         feat = aligned.view(B, 96 * 16, 64, 64)
-        rec = dict(S=S, B=B)
+        rec = dict(S=S, B=B, conv_operands=precision)
         rec["embed_ms"] = timeit(lambda: hp.embed(pose, idt))
         rec["warpgen_ms"] = timeit(lambda: hp.uv_generator(emb))
         rec["sampler_uv_ms"] = timeit(lambda: ops.grid_sample3d(ccl, delta=delta, in_layout="ndhwc", out_layout="ndhwc"))
