@@ -10,8 +10,9 @@
 //       patch   Ph[channel group of 4][patch element][4]   (wave w writes channel 4g + w: ds_write_b16)
 //       weights Ah[k-group of 8][tap][half][BM][4]          (packed like that on the host, copied by LDS-DMA)
 //   * a stage is KC = 8 (3x3) or 32 (1x1) channels: per wave 18 / 36 MFMAs of 32 cycles instead of 36 / 72 of 64.
-// Rounding: operands carry 11 significand bits, products and sums are exact fp32 MFMA accumulation; measured error on
-// the decoder layer shapes ~3e-4 of max|out| (tests/test_kernels_gpu.py).
+// Rounding: operands carry 11 significand bits (activations saturate at +-65504 instead of overflowing to inf), products
+// and sums are exact fp32 MFMA accumulation; measured error on the decoder layer shapes ~3e-4 of max|out|
+// (tests/test_kernels_gpu.py).
 #pragma once
 #include "conv_igemm.h"
 
@@ -169,6 +170,7 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
         const int e = lane + i * 64;                                                                  \
         float v = fmaxf(__fmaf_rn(pv[g * EPC + i], sc[g], sh[g]), relu_floor);                        \
         v = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                        \
+        v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);   /* saturate instead of overflowing to inf */ \
         _Float16* d_ = ((i + 1) * 64 <= CHS || e < CHS) ? Ph_ + ((g * CHS + e) * 4 + wave) : dumph;   \
         *d_ = (_Float16)v;                                                                            \
       }                                                                                               \

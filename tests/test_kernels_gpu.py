@@ -129,6 +129,18 @@ def test_conv_fp16_operands(case):
         pack.PackedConv("bad", torch.zeros(8, 8, 7, 7), None, DEV, precision="f16")
 
 
+def test_conv_fp16_operands_saturate():
+    """activations beyond the fp16 range are clamped to +-65504 on the way into LDS, not turned into inf / NaN"""
+    x = torch.full((1, 8, 16, 16), 1.0e6)
+    x[0, :, 8:] = -3.0e5
+    w = torch.zeros(32, 8, 3, 3)
+    w[:, 0, 1, 1] = 1.0
+    layer = pack.PackedConv("sat", w, None, DEV, cfg=1, precision="f16")
+    out = ops.conv_igemm(x.to(DEV), layer).cpu()
+    assert torch.isfinite(out).all()
+    assert out[0, 0, 2, 2].item() == 65504.0 and out[0, 0, 12, 2].item() == -65504.0
+
+
 def test_conv3d_1x1x1():
     e, _, _ = run_conv(2, 20, 12, (8, 16, 16), 1, 2, seed=5)
     assert e < 2e-5, e
