@@ -53,13 +53,14 @@ class ConvMeter:
         def wrapped(x, layer, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = meter._orig(x, layer, *a, **kw)
+            ret = meter._orig(x, layer, *a, **kw)
             e1.record()
             meter.events.append((e0, e1))
+            out = ret[0] if isinstance(ret, tuple) else ret         # (out, tile statistics) with want_stats=True
             positions = out.numel() // layer.cout
             meter.flops += 2.0 * positions * layer.macs_per_position
             meter.launches += 1
-            return out
+            return ret
 
         ops.conv_igemm = wrapped
         nets.ops.conv_igemm = wrapped
@@ -106,13 +107,45 @@ class SamplerMeter:
         return sum(a.elapsed_time(b) for a, b in self.events)
 
 
+def host_cpu():
+    """(physical cores, logical cpus, model string) of this box from /proc/cpuinfo"""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    return (len(cores) or logical), logical, model
+
+
 def cpu_baseline(cfg, sd, inputs, budget_s=25.0):
-    """oracle driver pass on the host cores, batch 1 per call as the reference does (bounded sample)"""
+    """SURVEY.md section 8(d) 'CPU baseline timing': the oracle driver pass (oracle/restate.py -- a restatement of the
+    reference's PyTorch forward that oracle/validate_restatement.py pins BIT-EXACTLY, max |delta| = 0.0 on every stage,
+    against the reference's own nn.Modules; /root/reference does not exist on the GPU box) on ALL physical host cores,
+    batch 1 per call as the reference does, 1 warm-up + up to 5 timed frames (bounded sample), median.  Plus the
+    1-thread figure of the 3-D sampler alone: ATen's CPU grid_sampler_3d (what the reference calls, va.py:264-265) does
+    not parallelise at N = 1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restate as O
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores // 2 if cores > 8 else cores, 64))
-    torch.set_num_threads(threads)
+    import torch.nn.functional as F
+    physical, logical, model = host_cpu()
+    torch.set_num_threads(physical)
     times = []
     t_start = time.time()
     with torch.no_grad():
@@ -123,12 +156,60 @@ def cpu_baseline(cfg, sd, inputs, budget_s=25.0):
             times.append(time.time() - t0)
             if time.time() - t_start > budget_s and len(times) >= 2:
                 break
-    timed = sorted(times[1:]) if len(times) > 1 else times
-    med = timed[len(timed) // 2]
-    return dict(value=round(1.0 / med, 4), unit="frames/s", cores=threads, kind="port",
+        timed = sorted(times[1:]) if len(times) > 1 else times
+        med = timed[len(timed) // 2]
+        # the sampler alone, 1 thread, the reference's call at its own batch size (N = 1, explicit grid)
+        torch.set_num_threads(1)
+        c, d, s_ = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
+        g = torch.Generator().manual_seed(2)
+        lin = lambda n: torch.linspace(-1, 1, n)
+        w, v, u = torch.meshgrid(lin(d), lin(s_), lin(s_), indexing="ij")
+        grid = (torch.stack([u, v, w], -1)[None] + 0.05 * torch.tanh(torch.randn(1, d, s_, s_, 3, generator=g))).contiguous()
+        vol = inputs["canonical"]
+        F.grid_sample(vol, grid, padding_mode=cfg["grid_sample_padding_mode"], align_corners=False)
+        ts = []
+        for _ in range(3):
+            t0 = time.time()
+            F.grid_sample(vol, grid, padding_mode=cfg["grid_sample_padding_mode"], align_corners=False)
+            ts.append(time.time() - t0)
+        samp_ms = sorted(ts)[1] * 1e3
+        torch.set_num_threads(physical)
+    ref = None
+    try:
+        vj = json.load(open(os.path.join(ROOT, "oracle", f"VALIDATION_{cfg['image_size']}.json")))
+        ref = {"reference_driver_s_per_frame": round(vj["reference_driver_s"], 3), "threads": vj["threads"],
+               "where": "the reference's own nn.Modules timed in the build container by oracle/validate_restatement.py "
+                        "(different host CPU; the restatement matched them bit for bit there)"}
+    except Exception:
+        pass
+    return dict(value=round(1.0 / med, 4), unit="frames/s", cores=physical, kind="port",
+                physical_cores=physical, logical_cpus=logical, cpu_model=model, threads=physical,
                 sample=f"{len(timed)} driver frames at {cfg['image_size']}x{cfg['image_size']}, batch 1 per call "
-                       f"(1 warm-up call excluded), oracle/restate.py on torch CPU fp32, median",
-                s_per_frame=round(med, 4))
+                       f"(1 warm-up call excluded), median; oracle/restate.py = bit-exact restatement of the reference "
+                       f"PyTorch forward, torch CPU fp32, torch.set_num_threads(all {physical} physical cores)",
+                s_per_frame=round(med, 4),
+                sampler_1thread={"ms_per_call": round(samp_ms, 1), "threads": 1,
+                                 "what": f"F.grid_sample (ATen CPU grid_sampler_3d, the reference's call) on "
+                                         f"[1,{c},{d},{s_},{s_}] with an explicit [1,{d},{s_},{s_},3] grid, median of 3",
+                                 "GBps_algorithmic": round((2 * vol.numel() + grid.numel()) * 4 / (samp_ms * 1e-3) / 1e9, 3)},
+                reference_classes=ref)
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous environment: start N ranks ourselves (one process per GPU,
+    RCCL backend) exactly as the driver would -- python -m torch.distributed.run on 127.0.0.1 -- and relay its output."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: needed by RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -145,9 +226,16 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        visible = torch.cuda.device_count()
+        if visible < a.gpus and os.environ.get("EMO_FORCE_DEVICE") is None:
+            raise SystemExit(f"--gpus {a.gpus} but only {visible} GPU(s) are visible (EMO_FORCE_DEVICE=0 + "
+                             f"EMO_DIST_BACKEND=gloo shares one GPU between ranks: a functional test, not a measurement)")
+        relaunch_under_torchrun(a.gpus)
     rank, world = parallel.init_distributed()
-    if world != max(1, a.gpus) and world != 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != max(1, a.gpus):
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus {a.gpus} does it itself when no WORLD_SIZE is set)")
     dev = torch.device("cuda", parallel.local_device_index())
     torch.cuda.set_device(dev)
 
@@ -178,12 +266,22 @@ def main():
         torch.cuda.synchronize()
         source_ms = (time.time() - t0) * 1e3
         cache = {"canonical": canonical, "idt_embed": idt_cpu.to(dev), "theta_src": th_s}
-    t0 = time.time()
-    cache = parallel.broadcast_source_cache(
-        cache, dict(canonical=(1, c, d, s, s), idt_embed=(1, cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4)),
-        src=0, device=dev, world=world, rank=rank)
-    torch.cuda.synchronize()
-    broadcast_ms = (time.time() - t0) * 1e3
+    shapes = dict(canonical=(1, c, d, s, s), idt_embed=(1, cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4))
+    names = list(shapes)
+    bc = lambda: parallel.broadcast_source_cache(cache, shapes if rank == 0 else None, src=0, device=dev, world=world,
+                                                 rank=rank, names=names)
+    broadcast_ms = None
+    if world > 1:
+        bc()                               # first collective: communicator set-up, not the steady-state cost
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out_cache = bc()
+        torch.cuda.synchronize()
+        broadcast_ms = parallel.max_over_ranks(time.perf_counter() - t0, device=dev) * 1e3
+        cache = out_cache
+    else:
+        cache = bc()
     ccl = hp.prepare_canonical(cache["canonical"])
     idt = cache["idt_embed"]
 
@@ -247,7 +345,7 @@ def main():
                              "frac": round(samp_gbps / PEAK_HBM_GBPS, 4),
                              "avg_launch_ms": round(samp_ms / max(1, len(samp_meter.events)), 4)},
         "source_pass_ms": None if source_ms is None else round(source_ms, 2),
-        "broadcast_ms": round(broadcast_ms, 3),
+        "broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 3),   # one flat RCCL broadcast of the source cache, max over ranks
     }
     if world == 1 and not a.no_cpu_baseline:
         inputs = dict(canonical=cache["canonical"].cpu(), idt=idt_cpu, pose=pose.cpu(), theta=ops.pose_theta(*srt).cpu())

@@ -96,8 +96,10 @@ extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int
 static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const float* bias, const float* scale,
                                const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D, int H,
                                int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups, int cfg,
-                               int ksplit, float* workspace, void* stream) {
+                               int ksplit, float* workspace, float* gn_stats, void* stream) {
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
+  if (gn_stats && (ksplit > 1 || prec != PREC_F32)) return EMO_ERR_UNSUPPORTED;   // tile statistics: single-pass fp32 kernel only
+  if ((long)D * H * W >= (1L << 30)) return EMO_ERR_UNSUPPORTED;                 // 32-bit byte offsets inside one channel
   if (ksplit < 1 || (ksplit > 1 && !workspace)) return EMO_ERR_BAD_ARG;
   if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMO_ERR_BAD_ARG;
@@ -113,6 +115,7 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
   a.Dl = D; a.Hl = ups ? 2 * H : H; a.Wl = ups ? 2 * W : W;
   a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
+  a.gn_stats = gn_stats;
   a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0;
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
@@ -152,9 +155,9 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
 extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias, const float* scale,
                                   const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
                                   int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
-                                  int cfg, int ksplit, float* workspace, void* stream) {
+                                  int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
   return conv_igemm_dispatch(PREC_F32, x, wpk, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
-                             relu_in, act, res_ups, cfg, ksplit, workspace, stream);
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
 }
 
 extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias, const float* scale,
@@ -162,5 +165,5 @@ extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const 
                                        int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
                                        int cfg, int ksplit, float* workspace, void* stream) {
   return conv_igemm_dispatch(PREC_F16, x, wpk16, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
-                             relu_in, act, res_ups, cfg, ksplit, workspace, stream);
+                             relu_in, act, res_ups, cfg, ksplit, workspace, nullptr, stream);
 }

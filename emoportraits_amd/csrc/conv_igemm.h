@@ -5,11 +5,15 @@
 // (networks/volumetric_avatar/utils.py:661-788) together with the pointwise work around them:
 //   * the GroupNorm-apply + ReLU that precedes every conv of a ResBlock (utils.py:711-731) is folded into the
 //     conv's input staging as a per-(sample, channel) affine  x*scale + shift  followed by max(.,0)
-//     (scale/shift come from emo_groupnorm_affine_f32); zero padding is applied AFTER that transform, exactly
-//     as F.conv does on the normalised tensor;
+//     (scale/shift come from emo_groupnorm_affine_f32 / emo_groupnorm_affine_from_tiles_f32); zero padding is
+//     applied AFTER that transform, exactly as F.conv does on the normalised tensor;
 //   * the nearest-neighbour x2 upsampling of the decoder's up-blocks (utils.py:684-688,764-781) is folded
 //     into the input gather (source index = logical index >> 1);
-//   * bias, the residual/skip addition (utils.py:783) and tanh/sigmoid heads are applied in the epilogue.
+//   * bias, the residual/skip addition (utils.py:783) and tanh/sigmoid heads are applied in the epilogue;
+//   * the statistics of the NEXT GroupNorm (utils.py:711-731 of the following block) are reduced from the
+//     accumulators in the epilogue: per (sample, position tile, channel) the mean and the centred sum of squares of
+//     the tile's 128 output values (gn_stats; combined exactly by emo_groupnorm_affine_from_tiles_f32), so the
+//     output tensor is never re-read for its normalisation.
 // Spectral norm / weight standardisation are folded into the weights once at load time.
 //
 // GEMM view: D[co][p] = sum_k A[co][k] * B[k][p],  k = (ci, kd, kh, kw), p = output position.
@@ -19,14 +23,32 @@
 //   expansion): lane (half=l>>5, j=l&31) reads patch[2*pair+half][.. + r][.. + s], i.e. the two k-values of an
 //   MFMA step are two CHANNELS at the same tap, so every LDS address is lane_base + compile-time immediate.
 //   Weights are pre-packed on the host as [co_tile][stage][pair][tap][half][BM] so a stage's A tile is one
-//   contiguous block copied with 16-byte loads.
+//   contiguous block copied by LDS-DMA.
 // Block = 256 threads = 4 waves; wave tile = (TM x 32) x (TP x 32); LDS double-buffered, one barrier/stage.
+//
+// Software pipeline of one stage s (EMO_CONV_PIPE == 2, the default):
+//     top      LDS-DMA of the weight tile of stage s+1 into the idle buffer; global loads of the patch of stage s+1
+//              into registers (inline asm: see below)
+//     ...      MFMAs of stage s, operands from the current buffer
+//     5/8      s_waitcnt for the patch registers, input transform, ds_write into the idle buffer
+//     ...      remaining MFMAs
+//     end      barrier
+// Why the patch loads are inline asm: with an LDS-DMA in flight hipcc (ROCm 7.2) waits vmcnt(0) at the first use of
+// any ordinary global load and before __syncthreads(), and its scheduler sinks ordinary loads down to their first
+// use.  The round-1 kernel issued the loads of stage s+2 just before the closing barrier of stage s to keep them
+// from sinking -- and the compiler drained them right there (s_waitcnt vmcnt(0); s_barrier): the full memory latency
+// was exposed once per stage in every wave (ablation: 125 TF with the loads, 143 TF without).  Loads written as asm
+// volatile stay where they are put, are invisible to the compiler's counters, and are waited for by hand.
 #pragma once
 #include "common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));   // native vector: stays an SSA value (HIP's float4 struct kept the
-                                                             // prefetched weight tile in a scratch alloca once it was loop-carried)
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#ifndef EMO_CONV_MAX_WAVES
+#define EMO_CONV_MAX_WAVES 5   /* blocks per CU (= waves per SIMD) the register allocation is planned for when LDS would hold more.
+                                  Measured on the 64-row config (64x64..256x256 layers): 4 -> 127.5, 5 -> 129.5, 6 -> 118 TF */
+#endif
 
 struct ConvArgs {
   const float* x;      // [N, Cin, D, H, W]  (source dims; logical dims are (D, 2H, 2W) when UPS)
@@ -50,6 +72,8 @@ struct ConvArgs {
   int stages_per_split;
   float* partial;      // ksplit > 1: raw partial sums [ksplit][N][Cout][Dl][Hl][Wl]; bias / residual / activation are
                        // applied by conv_splitk_epilogue_kernel (conv_api.hip), which adds the splits in fixed order
+  float* gn_stats;     // or null (needs ksplit == 1): [N][position tiles][Cout][2] = (mean, centred sum of squares) of
+                       // the 128 final output values of every (sample, position tile, channel)
 };
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
@@ -64,25 +88,24 @@ struct ConvCfg {
   static constexpr int PATCH = KC * CHS;
   static constexpr int ASZ = KLOC * BM;             // floats of one stage's weight tile
   static constexpr int BUF = ASZ + ((PATCH + 3) & ~3);
-#ifndef EMO_CONV_PRODUCERS
-#define EMO_CONV_PRODUCERS 0   /* 0: all 4 waves stage AND multiply; 2: two extra loader waves do all the staging
-                                  (wave specialisation), the 4 MFMA waves only read LDS and multiply */
-#endif
-  static constexpr int NPW = EMO_CONV_PRODUCERS;    // loader ("producer") waves
-  static constexpr int SW = NPW ? NPW : 4;          // waves that stage
-  static constexpr int ST = SW * 64;                // threads that stage
-  static constexpr int THREADS = 256 + 64 * NPW;
+  static constexpr int SW = 4;                      // waves that stage (all of them)
+  static constexpr int THREADS = 256;
   static constexpr int WPC = KC >= SW ? 1 : SW / KC;           // staging waves that share one input channel's patch
   static constexpr int CPW = KC >= SW ? KC / SW : 1;           // channels staged per staging wave per stage
   static constexpr int EPC = (CHS + 64 * WPC - 1) / (64 * WPC); // patch elements per lane per channel
   static constexpr int NPE = CPW * EPC;             // patch elements per thread per stage
-  static constexpr int NA4 = (ASZ / 4 + SW * 64 - 1) / (SW * 64); // float4 weight loads per staging thread
+  static constexpr int NSTEPS = (KC / 2) * TAPS;    // MFMA steps (one A/B operand fetch each) per stage
   static_assert(WGM * WGP == 4, "4 waves per block");
   static_assert(TZ * TR * TW == BP, "position tile must equal BP");
   static_assert(KC % 2 == 0 && (KC % SW == 0 || SW % KC == 0), "whole channels per wave, or whole waves per channel");
-  static_assert(EMO_CONV_PRODUCERS == 0 || EMO_CONV_PRODUCERS == 2, "0 or 2 loader waves");
   static_assert(ASZ % 4 == 0, "weight tile must be float4-copyable");
   static_assert(TM * TP <= 4, "accumulator budget");
+  static_assert(2 * BUF >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the stage buffers");
+  static constexpr int LDS_BYTES = (2 * BUF + 256) * 4;             // two stage buffers + 64 float4 dump slots
+  // blocks per CU that LDS admits, capped: the register allocator must fit that many waves per SIMD (1 wave per block
+  // and SIMD) -- without a floor it spends up to 256 VGPRs on epilogue ILP and silently halves the occupancy
+  static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
+  static constexpr int OCC = BY_LDS < 2 ? 2 : (BY_LDS > EMO_CONV_MAX_WAVES ? EMO_CONV_MAX_WAVES : BY_LDS);
 };
 
 __device__ __forceinline__ float emo_act(float v, int act) {
@@ -92,19 +115,58 @@ __device__ __forceinline__ float emo_act(float v, int act) {
   return v;
 }
 
+// global_load_dword with a scalar base and a 32-bit per-lane byte offset, hidden from the compiler's vmcnt
+// bookkeeping and from its scheduler (stays where it is written; cdna_hip_programming.md section 5.7).  The destination
+// is valid only after emo_wait_vmem0() + emo_touch().
+__device__ __forceinline__ float emo_gload_pinned(const float* sbase, unsigned voff) {
+  float v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
+__device__ __forceinline__ void emo_wait_vmem0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// makes v opaque at this point: no consumer of v is scheduled above it (volatile asm statements keep their order, so
+// after emo_wait_vmem0() this pins every use behind the wait)
+__device__ __forceinline__ void emo_touch(float& v) { asm volatile("" : "+v"(v)); }
+
+// sum over the 32 lanes of a half wave (lanes 0-31 / 32-63 separately), result in every lane: four DPP adds inside the
+// rows of 16 (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) + one ds_swizzle (xor 16).  No address registers.
+__device__ __forceinline__ float emo_sum32(float v) {
+#define EMO_DPP_ADD(ctrl_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, true))
+  EMO_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  EMO_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  EMO_DPP_ADD(0x141);   // row_half_mirror
+  EMO_DPP_ADD(0x140);   // row_mirror
+#undef EMO_DPP_ADD
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // bit mode: lane ^ 16
+  return v;
+}
+
+#ifndef EMO_CONV_XCD_ORDER
+#define EMO_CONV_XCD_ORDER 1   /* 1: 1-D grid, XCD-contiguous, output-channel tile fastest (see below); 0: (ptile, cotile, n) grid */
+#endif
+#ifndef EMO_CONV_PIPE
+#define EMO_CONV_PIPE 2   /* 2: patch loads of stage s+1 as pinned asm at the top of stage s (header comment);
+                             1: round-1 schedule, kept for A/B measurements: ordinary loads of stage s+2 issued before the
+                                closing barrier of stage s (drained there by the compiler's vmcnt(0)) */
+#endif
+#ifndef EMO_CONV_STORE_EIGHTHS
+#define EMO_CONV_STORE_EIGHTHS 5   /* the next stage's patch is transformed and written to LDS after this many eighths of the
+                                      stage's MFMA steps (PIPE 1 used 4) */
+#endif
+#ifndef EMO_CONV_ABLATE
+#define EMO_CONV_ABLATE 0   /* timing experiments only (results are WRONG for any value != 0): 1 = no global loads, no LDS-DMA and
+                               no LDS stores in the loop; 5 = LDS stores of stale registers, no global loads, no LDS-DMA */
+#endif
+
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
-#ifndef EMO_CONV_MIN_WAVES
-#define EMO_CONV_MIN_WAVES 2   /* __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocation must allow */
-#endif
-#ifndef EMO_CONV_MAX_WAVES
-#define EMO_CONV_MAX_WAVES 5   /* occupancy the register allocation is planned for: LDS holds 3-5 blocks of 4 waves per CU.  Measured
-                                  on the 64-row config (64x64..256x256 layers): 4 -> 127.5, 5 -> 129.5, 6 -> 118 TF */
-#endif
-__global__ __launch_bounds__(256 + 64 * EMO_CONV_PRODUCERS) __attribute__((amdgpu_waves_per_eu(EMO_CONV_MIN_WAVES, EMO_CONV_MAX_WAVES)))
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>::OCC,
+                                   ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>::OCC)))
 void conv_igemm_kernel(const ConvArgs a) {
   using Cfg = ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS;
-  constexpr int PATCH = Cfg::PATCH, ASZ = Cfg::ASZ, BUF = Cfg::BUF, NPE = Cfg::NPE, NA4 = Cfg::NA4;
+  constexpr int ASZ = Cfg::ASZ, BUF = Cfg::BUF, NPE = Cfg::NPE, NSTEPS = Cfg::NSTEPS;
+  constexpr int SW = Cfg::SW, WPC = Cfg::WPC, CPW = Cfg::CPW, EPC = Cfg::EPC;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -114,22 +176,11 @@ void conv_igemm_kernel(const ConvArgs a) {
   // wave-uniform and handled by the scalar unit instead of costing VALU issue slots next to the MFMA stream
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
-  constexpr int NPW = Cfg::NPW, SW = Cfg::SW, ST = Cfg::ST;
-  const bool is_producer = NPW > 0 && wave >= 4;          // wave-uniform role
-  const bool is_consumer = wave < 4;
-  const bool stages_data = NPW == 0 || is_producer;
-  const int sw = NPW ? (wave >= 4 ? wave - 4 : 0) : wave; // index among the staging waves
-  const int stid = sw * 64 + lane;                        // index among the staging threads
-  constexpr int WPC = Cfg::WPC;
-  const int chan0 = KC >= SW ? sw : sw % KC;           // channel (within a chunk) this wave stages; further ones at + g*SW
-  const int part = KC >= SW ? 0 : sw / KC;               // which 64-element slices of that channel's patch (WPC waves share it)
-  const int cwave = wave & 3;
-  const int wm = cwave / WGP, wp = cwave % WGP;
+  const int chan0 = KC >= SW ? wave : wave % KC;         // channel (within a chunk) this wave stages; further ones at + g*SW
+  const int part = KC >= SW ? 0 : wave / KC;             // which 64-element slices of that channel's patch (WPC waves share it)
+  const int wm = wave / WGP, wp = wave % WGP;
   const int m0 = wm * TM * 32, p0 = wp * TP * 32;
 
-#ifndef EMO_CONV_XCD_ORDER
-#define EMO_CONV_XCD_ORDER 1   /* 1: 1-D grid, XCD-contiguous, output-channel tile fastest (see below); 0: (ptile, cotile, n) grid */
-#endif
   int n, cotile, bx, ks = 0;
   if (EMO_CONV_XCD_ORDER) {
     // Block b runs on XCD b % 8 (private 4 MiB L2 each).  Re-map so that every XCD walks one contiguous eighth of the
@@ -155,6 +206,7 @@ void conv_igemm_kernel(const ConvArgs a) {
     cotile = blockIdx.y;
     bx = blockIdx.x;
   }
+  const int ptile = bx;
   const int tx = bx % a.tiles_x; bx /= a.tiles_x;
   const int ty = bx % a.tiles_y; bx /= a.tiles_y;
   const int tz = bx;
@@ -166,10 +218,8 @@ void conv_igemm_kernel(const ConvArgs a) {
   const bool has_affine = a.scale != nullptr;
   const bool relu_in = a.relu_in != 0;
   const int padD = a.KD >> 1;
-  // Branch-free input transform: v = max(v * sc + sh, floor).  Without an affine the scalar loads still happen (from the
-  // input itself, any readable address) and are replaced by (1, 0); without ReLU the floor is -inf.  No conditional code
-  // in the K loop: a conditionally used load is sunk by the compiler next to its use, which serialises load -> wait ->
-  // LDS write in the middle of the stage instead of prefetching a stage ahead.
+  // Branch-free input transform: v = max(v * sc + sh, floor).  Without an affine the loads still happen (from the
+  // input itself, any readable address) and are replaced by (1, 0); without ReLU the floor is -inf.
   const float* scale_n = has_affine ? a.scale + (long)n * a.Cin : a.x;
   const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : a.x;
   const float relu_floor = relu_in ? 0.0f : -__builtin_huge_valf();
@@ -177,9 +227,7 @@ void conv_igemm_kernel(const ConvArgs a) {
   // ---- patch staging map: wave w stages input channels {w, w+4, ...} of the chunk; lane l element l + 64*i of the
   //      channel's [TZ][PR][PW] patch.  Per element only a plane offset and a validity bit are kept (constant over
   //      stages); the channel / depth part of the address is a scalar base per stage. ----
-  constexpr int CPW = Cfg::CPW, EPC = Cfg::EPC;
-  unsigned p_off[EPC]; // BYTE offset (ys*W + xs)*4 inside an input plane (0 when the element is outside the image);
-                       // unsigned 32-bit so that loads take the scalar-base + vector-offset addressing form
+  unsigned p_off[EPC]; // BYTE offset (ys*W + xs)*4 inside an input plane (0 when the element is outside the image)
   int p_pz[EPC];       // z within the tile (non-zero only for TZ > 1)
   bool p_ok[EPC];      // element exists and its (y, x) lies inside the logical image
 #pragma unroll
@@ -204,27 +252,19 @@ void conv_igemm_kernel(const ConvArgs a) {
   const int st_end = min(nstages_all, st_begin + a.stages_per_split);
   const floatx4* wsrc = reinterpret_cast<const floatx4*>(a.wpk) + ((long)cotile * nstages_all) * (ASZ / 4);
 
-  // per-lane dump slots behind the two stage buffers (written, never read)
-  floatx4* const dump4 = reinterpret_cast<floatx4*>(smem + 2 * BUF) + lane;
+  // per-lane dump slot behind the two stage buffers (written, never read)
   float* const dump1 = smem + 2 * BUF + lane;
 
   float pv[NPE];        // staged patch values (raw)
   bool pvz[NPE];        // per-element depth validity (only varies per element when TZ > 1)
   bool sv[CPW];         // wave-uniform: channel exists (and, for TZ == 1, the depth slice is inside the volume)
   float sc[CPW], sh[CPW];
-  floatx4 av[NA4];
-#ifndef EMO_CONV_GLDS_A
-#define EMO_CONV_GLDS_A 1   /* 1: weight tile by LDS-DMA (global_load_lds), issued at the top of the stage straight into the idle
-                               buffer: no VGPR round trip, and -- being a side-effecting builtin -- it stays where it is put;
-                               0: through VGPRs + ds_write_b128 (the scheduler sinks those loads next to the ds_write) */
-#endif
   constexpr int NGL = (ASZ * 4 + 1024 * SW - 1) / (1024 * SW);   // 1-KiB LDS-DMA pieces per staging wave
 
-// Both staging halves are macros (not lambdas / conditionals) so that pv[] / av[] are unconditionally defined
-// straight-line values and stay in VGPRs (a conditional or lambda-captured definition sent them to scratch).
-#define EMO_ISSUE_LOADS(stage_, dst_) { EMO_ISSUE_PATCH(stage_); EMO_ISSUE_WEIGHTS(stage_, dst_); }
-
-#define EMO_ISSUE_PATCH(stage_)                                                                       \
+// The staging steps are macros (not lambdas / conditionals) so that pv[] is an unconditionally defined straight-line value
+// and stays in VGPRs (a conditional or lambda-captured definition sent it to scratch).
+// PINNED_: loads as asm volatile (EMO_CONV_PIPE 2) or ordinary loads (EMO_CONV_PIPE 1)
+#define EMO_ISSUE_PATCH(stage_, PINNED_)                                                              \
   {                                                                                                   \
     const int cc_ = (stage_) / a.KD;                                                                  \
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
@@ -237,61 +277,61 @@ void conv_igemm_kernel(const ConvArgs a) {
       const bool zv_ = (unsigned)zu_ < (unsigned)a.D;                                                 \
       const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;            \
       sv[g] = cv_ && (TZ > 1 || zv_);                                                                 \
-      { const float s1_ = scale_n[cs_], s0_ = shift_n[cs_];                                           \
-        sc[g] = has_affine ? s1_ : 1.0f; sh[g] = has_affine ? s0_ : 0.0f; }                           \
+      if (PINNED_) {                                                                                  \
+        sc[g] = emo_gload_pinned(scale_n + cs_, 0u);                                                  \
+        sh[g] = emo_gload_pinned(shift_n + cs_, 0u);                                                  \
+      } else {                                                                                        \
+        sc[g] = scale_n[cs_]; sh[g] = shift_n[cs_];                                                   \
+      }                                                                                               \
       _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
+        unsigned off_ = p_off[i];                                                                     \
         if (TZ == 1) {                                                                                \
           pvz[g * EPC + i] = true;                                                                    \
-          pv[g * EPC + i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + p_off[i]); \
         } else {                                                                                      \
           const int zi = zu_ + p_pz[i];                                                               \
           const bool zok = (unsigned)zi < (unsigned)a.D;                                              \
           pvz[g * EPC + i] = zok;                                                                     \
-          pv[g * EPC + i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + (p_off[i] + (unsigned)((zok ? zi : 0) * HW) * 4u)); \
+          off_ += (unsigned)((zok ? zi : 0) * HW) * 4u;                                               \
         }                                                                                             \
+        if (PINNED_) pv[g * EPC + i] = emo_gload_pinned(base_, off_);                                 \
+        else pv[g * EPC + i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + off_); \
       }                                                                                               \
     }                                                                                                 \
   }
 
+/* wait for the pinned loads of EMO_ISSUE_PATCH and pin every consumer behind the wait */
+#define EMO_WAIT_PATCH()                                                                              \
+  {                                                                                                   \
+    emo_wait_vmem0();                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < NPE; ++q_) emo_touch(pv[q_]);                             \
+    _Pragma("unroll") for (int g = 0; g < CPW; ++g) { emo_touch(sc[g]); emo_touch(sh[g]); }           \
+  }
+
+/* weight tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), no VGPR round trip. */
+/* The LDS image is lane-linear = exactly the packed weight order.                               */
 #define EMO_ISSUE_WEIGHTS(stage_, dst_)                                                               \
   {                                                                                                   \
     const floatx4* ws_ = wsrc + (long)(stage_) * (ASZ / 4);                                           \
-    if (EMO_CONV_GLDS_A) {                                                                            \
-      /* weight tile: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), no VGPR round trip. */ \
-      /* The LDS image is lane-linear = exactly the packed weight order.                               */ \
-      _Pragma("unroll") for (int i = 0; i < NGL; ++i) {                                               \
-        const int j = sw + SW * i;                                                                    \
-        const int boff = j * 1024 + lane * 16;                                                        \
-        if (boff < ASZ * 4)                                                                           \
-          __builtin_amdgcn_global_load_lds(                                                           \
-              (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(ws_) + boff), \
-              (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(dst_) + j * 1024), 16, 0, 0); \
-      }                                                                                               \
-    } else {                                                                                          \
-      _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                               \
-        const int idx = stid + i * ST;                                                                \
-        av[i] = ws_[idx < ASZ / 4 ? idx : ASZ / 4 - 1];                                               \
-      }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NGL; ++i) {                                                 \
+      const int j = wave + SW * i;                                                                    \
+      const int boff = j * 1024 + lane * 16;                                                          \
+      if (boff < ASZ * 4)                                                                             \
+        __builtin_amdgcn_global_load_lds(                                                             \
+            (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(ws_) + boff), \
+            (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(dst_) + j * 1024), 16, 0, 0); \
     }                                                                                                 \
   }
 
 /* Stores are unconditional: lanes beyond the tile write to a private dump slot (address select, no branch). */ \
-#define EMO_STORE_STAGE(stage_, buf_)                                                                 \
+#define EMO_STORE_STAGE(buf_)                                                                         \
   {                                                                                                   \
-    if (!EMO_CONV_GLDS_A) {                                                                           \
-      floatx4* As4_ = reinterpret_cast<floatx4*>(buf_);                                               \
-      _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                               \
-        const int idx = stid + i * ST;                                                                \
-        floatx4* d4_ = ((i + 1) * ST <= ASZ / 4 || idx < ASZ / 4) ? As4_ + idx : dump4;               \
-        *d4_ = av[i];                                                                                 \
-      }                                                                                               \
-    }                                                                                                 \
     float* Ps_ = (buf_) + ASZ;                                                                        \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
       float* Pc_ = Ps_ + (g * SW + chan0) * CHS;                                                      \
+      const float sc_ = has_affine ? sc[g] : 1.0f, sh_ = has_affine ? sh[g] : 0.0f;                   \
       _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
         const int e = lane + (i * WPC + part) * 64;                                                   \
-        float v = fmaxf(__fmaf_rn(pv[g * EPC + i], sc[g], sh[g]), relu_floor);                        \
+        float v = fmaxf(__fmaf_rn(pv[g * EPC + i], sc_, sh_), relu_floor);                            \
         /* zero padding applies to the transformed tensor */                                          \
         v = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                        \
         float* d_ = ((i + 1) * WPC * 64 <= CHS || e < CHS) ? Pc_ + e : dump1;                         \
@@ -300,53 +340,19 @@ void conv_igemm_kernel(const ConvArgs a) {
     }                                                                                                 \
   }
 
-#ifndef EMO_CONV_ABLATE
-#define EMO_CONV_ABLATE 0   /* timing experiments only: 4 = global loads issued but never written to LDS, 5 = LDS writes of
-                               stale registers without global loads, 1 = no global loads / LDS stores in the loop, 2 = also no barrier,
-                               3 = MFMA stream only (operands read once) -- results are WRONG for any value != 0 */
-#endif
-#ifndef EMO_CONV_SCHED_FENCE
-#define EMO_CONV_SCHED_FENCE 0   /* 1: __builtin_amdgcn_sched_barrier around the prefetch (measured: makes the backend spill the
-                                    prefetched weight tile to scratch); 0: scheduler's choice */
-#endif
-#ifndef EMO_CONV_PIPE_W
-#define EMO_CONV_PIPE_W 0   /* with EMO_CONV_PIPE and register-staged weights (EMO_CONV_GLDS_A == 0): 1 = the weight tile is loop-carried
-                               in VGPRs like the patch; 0 = loaded at the top of the stage */
-#endif
-#ifndef EMO_CONV_PIPE
-#define EMO_CONV_PIPE 1   /* where the global loads of stage s+1 are issued: 0 = at the top of stage s (the scheduler then sinks
-                             them down to their first use at STORE_PAIR: ~0 prefetch distance, the memory latency is exposed once
-                             per stage); 1 = at the end of stage s-1, BEFORE that stage's closing barrier -- loads cannot be moved
-                             across the barrier's fences, so they are in flight for at least the first half of stage s */
-#endif
-#ifndef EMO_CONV_STORE_AT
-#define EMO_CONV_STORE_AT 1   /* 0: write the next stage into LDS after all MFMAs of this stage; 1: after half of them */
-#endif
-  constexpr int STORE_PAIR = EMO_CONV_STORE_AT ? (KC / 4) : -1;   // the idle LDS buffer is free for the whole stage
+  constexpr bool PINNED = EMO_CONV_PIPE == 2;
+  constexpr int STORE_STEP = (NSTEPS * (PINNED ? EMO_CONV_STORE_EIGHTHS : 4)) / 8;
 
-  if (stages_data) {
-    EMO_ISSUE_LOADS(st_begin, smem);
-    EMO_STORE_STAGE(st_begin, smem);
-    if (EMO_CONV_PIPE && NPW == 0) {   // second stage in flight across the barrier (registers are loop-carried)
-      const int st1_ = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
-      EMO_ISSUE_PATCH(st1_);
-      if (EMO_CONV_PIPE_W && !EMO_CONV_GLDS_A) { EMO_ISSUE_WEIGHTS(st1_, smem); }
-    }
+  // ---- prologue: stage st_begin into buffer 0 ----
+  EMO_ISSUE_WEIGHTS(st_begin, smem);
+  EMO_ISSUE_PATCH(st_begin, PINNED);
+  if (PINNED) { EMO_WAIT_PATCH(); }
+  EMO_STORE_STAGE(smem);
+  if (!PINNED) {   // round-1 schedule: the second stage is in flight across the barrier (registers are loop-carried)
+    const int st1_ = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
+    EMO_ISSUE_PATCH(st1_, false);
   }
   __syncthreads();
-
-  if (is_producer) {
-    // ---- loader waves (wave specialisation): the whole stage time to fetch, transform and park the next stage.
-    //      Same number of barriers as the MFMA waves; no accumulators live on this path. ----
-    for (int st = st_begin; st < st_end; ++st) {
-      float* nxt = smem + ((st - st_begin + 1) & 1) * BUF;
-      const int stn = (st + 1) < st_end ? (st + 1) : st;
-      EMO_ISSUE_LOADS(stn, nxt);
-      EMO_STORE_STAGE(stn, nxt);
-      __syncthreads();
-    }
-    return;
-  }
 
   floatx16 acc[TM][TP];
 #pragma unroll
@@ -368,24 +374,6 @@ void conv_igemm_kernel(const ConvArgs a) {
     b_base[j] = half * CHS + pz * (PR * PW) + row * PW + col;
   }
 
-// all MFMAs of one channel pair of the current stage: per tap 1 A read + 1 B read per 32x32 tile, TM*TP MFMAs
-#define EMO_MFMA_PAIR(pair_)                                                                          \
-  {                                                                                                   \
-    _Pragma("unroll") for (int r = 0; r < KH; ++r) {                                                  \
-      _Pragma("unroll") for (int s = 0; s < KW; ++s) {                                                \
-        const int tap = r * KW + s;                                                                   \
-        float av_[TM], bv_[TP];                                                                       \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
-          av_[i] = As[a_base + (EMO_CONV_ABLATE == 3 ? 0 : (((pair_) * TAPS + tap) * 2) * BM) + i * 32]; \
-        _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                \
-          bv_[j] = Ps[b_base[j] + (EMO_CONV_ABLATE == 3 ? 0 : ((pair_) * 2) * CHS + r * PW + s)];     \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
-          _Pragma("unroll") for (int j = 0; j < TP; ++j)                                              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc[i][j], 0, 0, 0);     \
-      }                                                                                               \
-    }                                                                                                 \
-  }
-
   for (int st = st_begin; st < st_end; ++st) {
     float* cur = smem + ((st - st_begin) & 1) * BUF;
     float* nxt = smem + ((st - st_begin + 1) & 1) * BUF;
@@ -394,90 +382,163 @@ void conv_igemm_kernel(const ConvArgs a) {
     const int stn = (st + 1) < st_end ? (st + 1) : st;
     const float* As = cur;
     const float* Ps = cur + ASZ;
-    if (NPW == 0) {
-      // every wave stages and multiplies: loads first, LDS write of the next stage half way through the MFMAs
-      if (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 4) {
-        if (!EMO_CONV_PIPE) { EMO_ISSUE_PATCH(stn); }
-        if (!(EMO_CONV_PIPE && EMO_CONV_PIPE_W && !EMO_CONV_GLDS_A)) {
-          EMO_ISSUE_WEIGHTS(stn, nxt);   // LDS-DMA straight into the idle buffer (or through VGPRs when EMO_CONV_GLDS_A == 0)
-        }
-      }
-      // pin the software pipeline: the next stage's global loads are ISSUED here, before this stage's MFMAs, and are
-      // first touched (s_waitcnt + transform + LDS write) at STORE_PAIR -- without the fences the scheduler moves the
-      // loads down next to their use and the whole memory latency is exposed once per stage
-      if (EMO_CONV_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
-      if (EMO_CONV_ABLATE == 4) {   /* keep the loads alive without touching LDS */
-        _Pragma("unroll") for (int q = 0; q < NPE; ++q) asm volatile("" ::"v"(pv[q]));
-        _Pragma("unroll") for (int q = 0; q < NA4; ++q) asm volatile("" ::"v"(av[q].x), "v"(av[q].w));
-      }
-#pragma unroll
-      for (int pair = 0; pair < KC / 2; ++pair) {
-        if (pair == STORE_PAIR && STORE_PAIR > 0 && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 5)) {
-          if (EMO_CONV_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
-          EMO_STORE_STAGE(stn, nxt);
-        }
-        EMO_MFMA_PAIR(pair);
-      }
-      if (STORE_PAIR <= 0 && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 5)) {
-        if (EMO_CONV_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
-        EMO_STORE_STAGE(stn, nxt);
-      }
-      if (EMO_CONV_PIPE && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 4)) {
-        // the registers were consumed by EMO_STORE_STAGE above: refill them with stage st+2, before the barrier
-        const int stn2 = (st + 2) < st_end ? (st + 2) : (st_end - 1);
-        EMO_ISSUE_PATCH(stn2);
-        if (EMO_CONV_PIPE_W && !EMO_CONV_GLDS_A) { EMO_ISSUE_WEIGHTS(stn2, nxt); }
-      }
-    } else {
-      // MFMA waves of the wave-specialised variant: nothing but LDS reads and matrix instructions
-#pragma unroll
-      for (int pair = 0; pair < KC / 2; ++pair) { EMO_MFMA_PAIR(pair); }
+    if (EMO_CONV_ABLATE == 0) {
+      EMO_ISSUE_WEIGHTS(stn, nxt);
+      if (PINNED) { EMO_ISSUE_PATCH(stn, true); }
     }
-    if (EMO_CONV_ABLATE < 2 || EMO_CONV_ABLATE >= 4) __syncthreads();
+#pragma unroll
+    for (int step = 0; step < NSTEPS; ++step) {
+      if (step == STORE_STEP && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 5)) {
+        if (PINNED && EMO_CONV_ABLATE == 0) { EMO_WAIT_PATCH(); }
+        EMO_STORE_STAGE(nxt);
+      }
+      // one MFMA step = one channel pair x one tap: 1 A read + 1 B read per 32x32 tile, TM*TP MFMAs
+      const int pair = step / TAPS, tap = step % TAPS;
+      const int r = tap / KW, s = tap % KW;
+      float av_[TM], bv_[TP];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av_[i] = As[a_base + ((pair * TAPS + tap) * 2) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TP; ++j) bv_[j] = Ps[b_base[j] + (pair * 2) * CHS + r * PW + s];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc[i][j], 0, 0, 0);
+    }
+    if (!PINNED && EMO_CONV_ABLATE == 0) {
+      // round-1 schedule: refill the registers with stage st+2 before the barrier
+      const int stn2 = (st + 2) < st_end ? (st + 2) : (st_end - 1);
+      EMO_ISSUE_PATCH(stn2, false);
+    }
+    __syncthreads();
   }
-#undef EMO_MFMA_PAIR
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  //      Bias and residual are fetched in batches of 16 under wave-uniform branches (a per-element `if (a.res) v += ...`
+  //      makes the compiler wait vmcnt(0) behind every single load: 128 dependent round trips per lane). ----
   const long plane = (long)a.Hl * a.Wl;
   const long ovol = (long)a.Dl * plane;
+  const bool to_partial = a.partial != nullptr;
+  const bool has_bias = a.bias != nullptr && !to_partial;
+  const bool has_res = a.res != nullptr && !to_partial;
+  const int co_base = cotile * BM + m0 + 4 * half;
 #pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int p = p0 + j * 32 + l32;
-    const int col = p % TW;
-    const int row = (p / TW) % TR;
-    const int pz = p / (TW * TR);
-    const int z = z0 + pz, y = y0 + row, x = x0 + col;
-    const long sp = (long)z * plane + (long)y * a.Wl + x;
-    long rsp = sp;
-    long rvol = ovol;
-    if (a.res_ups) {
-      const int Wr = a.Wl >> 1, Hr = a.Hl >> 1;
-      rsp = ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
-      rvol = (long)a.Dl * Hr * Wr;
+  for (int i = 0; i < TM; ++i) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
+    if (has_bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = a.bias[min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
     }
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      const int p = p0 + j * 32 + l32;
+      const int col = p % TW;
+      const int row = (p / TW) % TR;
+      const int pz = p / (TW * TR);
+      const int z = z0 + pz, y = y0 + row, x = x0 + col;
+      const long sp = (long)z * plane + (long)y * a.Wl + x;
+      if (to_partial) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (co < a.Cout) a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc[i][j][r];
+        }
+      } else {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.0f;
+        if (has_res) {
+          long rsp = sp, rvol = ovol;
+          if (a.res_ups) {
+            const int Wr = a.Wl >> 1, Hr = a.Hl >> 1;
+            rsp = ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
+            rvol = (long)a.Dl * Hr * Wr;
+          }
+          const float* rp = a.res + (long)n * a.Cout * rvol + rsp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = rp[(long)min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1) * rvol];
+        }
+        float* op = a.out + (long)n * a.Cout * ovol + sp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
+          const float v = emo_act(acc[i][j][r] + bv[r] + rv[r], a.act);
+          if (co < a.Cout) op[(long)co * ovol] = v;
+          acc[i][j][r] = v;   // the stored value: what the next GroupNorm normalises
+        }
+      }
+    }
+  }
+
+  // ---- GroupNorm statistics of the output tile (wave-uniform branch).  Per channel row of this wave: mean over its
+  //      TP*32 positions (DPP butterfly over the 32 lanes that hold the row), then the sum of squares centred at that mean --
+  //      a two-pass variance on values that are still in registers.  The WGP waves that share the row combine their
+  //      (mean, M2) through LDS with the pairwise update of Chan et al. (equal counts).  No E[x^2] - mean^2 anywhere. ----
+  if (a.gn_stats != nullptr && !to_partial) {
+    float* st_lds = smem;   // [WGP][BM][2]: the stage buffers are idle (the K loop ended with a barrier)
+    constexpr float inv_cnt = 1.0f / (float)(TP * 32);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = cotile * BM + m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a.Cout && a.partial) {
-          a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc[i][j][r];
-        } else if (co < a.Cout) {
-          float v = acc[i][j][r];
-          if (a.bias) v += a.bias[co];
-          if (a.res) v += a.res[((long)n * a.Cout + co) * rvol + rsp];
-          v = emo_act(v, a.act);
-          a.out[((long)n * a.Cout + co) * ovol + sp] = v;
+        float s = acc[i][0][r];
+#pragma unroll
+        for (int j = 1; j < TP; ++j) s += acc[i][j][r];
+        const float mean = emo_sum32(s) * inv_cnt;
+        float m2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) { const float d = acc[i][j][r] - mean; m2 = __fmaf_rn(d, d, m2); }
+        m2 = emo_sum32(m2);
+        if (l32 == 0) {
+          const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          *reinterpret_cast<float2*>(st_lds + (wp * BM + m) * 2) = make_float2(mean, m2);
         }
+      }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cotile * BM + tid;
+      if (co < a.Cout) {
+        float mean = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WGP; ++w) mean += st_lds[(w * BM + tid) * 2 + 0];
+        mean *= 1.0f / (float)WGP;
+#pragma unroll
+        for (int w = 0; w < WGP; ++w) {
+          const float d = st_lds[(w * BM + tid) * 2 + 0] - mean;
+          m2 += st_lds[(w * BM + tid) * 2 + 1] + (float)(TP * 32) * d * d;
+        }
+        const long nptiles = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+        float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)n * nptiles + ptile) * a.Cout + co;
+        *dst = make_float2(mean, m2);
       }
     }
   }
 }
 
-#undef EMO_ISSUE_LOADS
 #undef EMO_ISSUE_PATCH
+#undef EMO_WAIT_PATCH
 #undef EMO_ISSUE_WEIGHTS
 #undef EMO_STORE_STAGE
+
+// opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) once per (kernel, device)
+template <typename K>
+static int emo_raise_dynamic_lds(K kern) {
+  static bool raised[64] = {};   // per device; idempotent, so a benign race
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= 64) return EMO_ERR_UNSUPPORTED;
+  if (!raised[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    raised[dev] = true;
+  }
+  return EMO_OK;
+}
 
 // host-side launcher for one instantiation
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
@@ -491,22 +552,17 @@ int conv_igemm_launch(ConvArgs a, hipStream_t s) {
   const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
   if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
-  const size_t lds = (size_t)(2 * Cfg::BUF + 256) * sizeof(float);   // two stage buffers + 64 float4 dump slots
+  const size_t lds = (size_t)Cfg::LDS_BYTES;
   if (lds > 160 * 1024) return EMO_ERR_UNSUPPORTED;
   auto kern = conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   if (lds > 64 * 1024) {
-    // opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU); idempotent, so a benign race
-    static bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      raised = true;
-    }
+    const int rc = emo_raise_dynamic_lds(kern);
+    if (rc != EMO_OK) return rc;
   }
   a.n_cotiles = cot;
   if (a.ksplit < 1 || (a.ksplit > 1 && (!EMO_CONV_XCD_ORDER || !a.partial))) return EMO_ERR_BAD_ARG;
   if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }
+  if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
   if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
   dim3 g = EMO_CONV_XCD_ORDER ? dim3((unsigned)(nt * cot * a.N * a.ksplit)) : dim3((unsigned)nt, cot, a.N);
   hipLaunchKernelGGL(kern, g, dim3(Cfg::THREADS), lds, s, a);

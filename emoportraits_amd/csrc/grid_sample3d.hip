@@ -594,6 +594,27 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
   return emo_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The rotation warp itself (row a2): grid[n,z,y,x,:] = theta[n,:3,:4] . (u_x, v_y, w_z, 1) -- exactly the coordinates
+// the MODE_THETA samplers generate on the fly, materialised for callers that want the reference's cached
+// `source_rotation_warp` tensor (notebooks/infer.py:441-444) and for the parity tests that compare them with the
+// reference's `identity_grid_3d.bmm(theta[:, :3].transpose(1, 2))`.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_grid3d_kernel(const float* __restrict__ theta,
+                                                            const float* __restrict__ lin_x,
+                                                            const float* __restrict__ lin_y,
+                                                            const float* __restrict__ lin_z, float* __restrict__ grid,
+                                                            int Do, int Ho, int Wo) {
+  const int nvox = Do * Ho * Wo;
+  const int vox = blockIdx.x * 256 + threadIdx.x;
+  if (vox >= nvox) return;
+  const int n = blockIdx.y;
+  float gx, gy, gz;
+  load_coord<MODE_THETA>(nullptr, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
+  float* g = grid + ((long)n * nvox + vox) * 3;
+  g[0] = gx; g[1] = gy; g[2] = gz;
+}
+
 template <int PAD>
 int launch_pad(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
@@ -637,6 +658,16 @@ extern "C" int emo_grid_sample3d_f32(const float* vol, const float* grid, const 
     default:
       return EMO_ERR_BAD_ARG;
   }
+}
+
+extern "C" int emo_affine_grid3d_f32(const float* theta, const float* lin_x, const float* lin_y, const float* lin_z,
+                                     float* grid, int N, int Do, int Ho, int Wo, void* stream) {
+  if (!theta || !lin_x || !lin_y || !lin_z || !grid) return EMO_ERR_BAD_ARG;
+  if (N <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return EMO_ERR_BAD_ARG;
+  if (N > 65535 || (long)Do * Ho * Wo >= (1L << 31) / 4) return EMO_ERR_UNSUPPORTED;
+  dim3 g(emo_cdiv((long)Do * Ho * Wo, 256), N);
+  hipLaunchKernelGGL(affine_grid3d_kernel, g, dim3(256), 0, (hipStream_t)stream, theta, lin_x, lin_y, lin_z, grid, Do, Ho, Wo);
+  return emo_launch_status();
 }
 
 extern "C" int emo_volume_repack_f32(const float* in, float* out, int N, int C, int DHW, int to_channels_last,

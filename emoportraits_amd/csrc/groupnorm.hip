@@ -101,6 +101,69 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
+// GroupNorm affine from the per-tile statistics the convolution epilogue leaves behind (conv_igemm.h, gn_stats):
+// stats [N][T][C][2] = (mean, M2) of `cnt` values each.  One block per (sample, group); the cpg*T entries of a group are
+// combined in fp64 with the equal-count form of Chan's update
+//     mean = avg(mean_i),   M2 = sum(M2_i) + cnt * (sum(mean_i^2) - K * mean^2)
+// (the fp64 subtraction loses nothing that matters: mean_i are fp32 values).  Then gamma / beta / adaptive weights are
+// folded exactly as in gn_finalize_kernel.
+__global__ __launch_bounds__(256) void gn_from_tiles_kernel(const float2* __restrict__ stats, int T, int C, int G, int cnt,
+                                                            float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ ada_gamma,
+                                                            const float* __restrict__ ada_beta, long ada_stride,
+                                                            float* __restrict__ scale, float* __restrict__ shift,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+  const int cpg = C / G;
+  const float2* base = stats + (long)n * T * C + (long)g * cpg;
+  double s1 = 0.0, s2 = 0.0, sm = 0.0;
+  const long K = (long)T * cpg;
+  for (long i = threadIdx.x; i < K; i += 256) {
+    const long t = i / cpg;
+    const int c = (int)(i - t * cpg);
+    const float2 e = base[t * C + c];
+    s1 += (double)e.x;
+    s2 += (double)e.x * (double)e.x;
+    sm += (double)e.y;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2); sm = wave_sum(sm);
+  __shared__ double red[3][4];
+  __shared__ double fin[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; red[2][wave] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double a1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double a2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double am = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    const double mean = a1 / (double)K;
+    double m2 = am + (double)cnt * (a2 - (double)K * mean * mean);
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / ((double)K * (double)cnt);
+    fin[0] = mean;
+    fin[1] = 1.0 / sqrt(var + (double)eps);
+    if (mean_out) { mean_out[n * G + g] = (float)mean; rstd_out[n * G + g] = (float)fin[1]; }
+  }
+  __syncthreads();
+  const double mean = fin[0], rstd = fin[1];
+  for (int k = threadIdx.x; k < cpg; k += 256) {
+    const int c = g * cpg + k;
+    const double gm = gamma ? (double)gamma[c] : 1.0;
+    const double bt = beta ? (double)beta[c] : 0.0;
+    double sc = rstd * gm;
+    double sh = bt - mean * sc;
+    if (ada_gamma) {
+      const double ag = ada_gamma[(long)n * ada_stride + c];
+      const double ab = ada_beta[(long)n * ada_stride + c];
+      sc = sc * ag;
+      sh = sh * ag + ab;
+    }
+    scale[(long)n * C + c] = (float)sc;
+    shift[(long)n * C + c] = (float)sh;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t emo_groupnorm_workspace_bytes(int N, int G) {
@@ -129,5 +192,21 @@ extern "C" int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S,
   if (rc) return rc;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(emo_cdiv((long)N * C, 256)), dim3(256), 0, s, part, split, N, C, G, L,
                      eps, gamma, beta, ada_gamma, ada_beta, (long)ada_stride, scale, shift, mean_out, rstd_out);
+  return emo_launch_status();
+}
+
+extern "C" int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_t T, int cnt, int G, float eps,
+                                                   const float* gamma, const float* beta, const float* ada_gamma,
+                                                   const float* ada_beta, int64_t ada_stride, float* scale, float* shift,
+                                                   float* mean_out, float* rstd_out, void* stream) {
+  if (!stats || !scale || !shift) return EMO_ERR_BAD_ARG;
+  if (N <= 0 || C <= 0 || T <= 0 || cnt <= 0 || G <= 0 || C % G) return EMO_ERR_BAD_ARG;
+  if ((ada_gamma == nullptr) != (ada_beta == nullptr)) return EMO_ERR_BAD_ARG;
+  if ((mean_out == nullptr) != (rstd_out == nullptr)) return EMO_ERR_BAD_ARG;
+  if ((long)N * G > 0x7fffffffL || T > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  if ((((uintptr_t)stats) & 7u) != 0) return EMO_ERR_ALIGN;
+  hipLaunchKernelGGL(gn_from_tiles_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(stats), (int)T, C, G, cnt, eps, gamma, beta, ada_gamma, ada_beta,
+                     (long)ada_stride, scale, shift, mean_out, rstd_out);
   return emo_launch_status();
 }

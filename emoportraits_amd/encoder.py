@@ -28,12 +28,14 @@ class LocalEncoder:
         self.nh = Norm(sd, prefix + ".finale_layers.0", device)
         self.finale = PackedConv.from_state_dict(sd, prefix + ".finale_layers.2", kind, device)
 
-    def __call__(self, img):
+    def __call__(self, img, want_stats=False):
         N, C, H, W = img.shape
         if H != self.image_size or W != self.image_size:
             raise ValueError(f"LocalEncoder was built for {self.image_size}px inputs (layer names embed the size)")
-        x = ops.conv_igemm(img.view(N, C, H, 1, W), self.from_rgb).view(N, -1, H, W)
+        x, st = ops.conv_igemm(img.view(N, C, H, 1, W), self.from_rgb, want_stats=True)
+        x = x.view(N, -1, H, W)
         for blk in self.blocks:
-            x = blk(x, down=(2, 2))
+            x = blk(x, down=(2, 2), x_stats=st)
+            st = None                       # the pooled block output has no tile statistics
         s, h = self.nh.affine(x)
-        return ops.conv_igemm(x, self.finale, s, h, relu_in=True)
+        return ops.conv_igemm(x, self.finale, s, h, relu_in=True, want_stats=want_stats)

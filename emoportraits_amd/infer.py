@@ -143,7 +143,7 @@ class InferenceWrapper:
             if hp_net is not None and self.embedders['head_pose_regressor'] is hp_net:
                 self._graphed['head_pose_regressor'] = graphs.Graphed(lambda crop: hp_net.forward(crop, True))
             if ex_net is not None and self.embedders['expression_embedder'] is ex_net:
-                self._graphed['expression_embedder'] = graphs.Graphed(lambda crop, theta: ex_net(crop, theta))
+                self._graphed['expression_embedder'] = graphs.Graphed(lambda crop, theta: ex_net(crop, theta, True)[:2])
 
         self.fixed_bounding_box = fixed_bounding_box
         self.momentum = 0.01
@@ -201,10 +201,18 @@ class InferenceWrapper:
         return self._need('head_pose_regressor', 'a driver call')(crop, True)
 
     def _expression(self, crop, theta, what):
+        """-> (pose_embed, aligned crop or None).  The aligned 128^2 crop is what the reference exposes as
+        `target_img_align` (expression_embedder.py:233, infer.py:608); a user-supplied callable may return either the
+        embedding alone or a tuple (embedding, aligned, ...)."""
         g = self._graphed.get('expression_embedder')
         if g is not None:
-            return g(crop, theta.float().contiguous())
-        return self._need('expression_embedder', what)(crop, theta)
+            out = g(crop, theta.float().contiguous())
+        else:
+            fn = self._need('expression_embedder', what)
+            out = fn(crop, theta, True) if isinstance(fn, emb_mod.ExpressionEmbed) else fn(crop, theta)
+        if isinstance(out, (tuple, list)):
+            return out[0], (out[1] if len(out) > 1 else None)
+        return out, None
 
     def _drive(self, pose, theta):
         g = self._graphed.get('driver')
@@ -334,14 +342,17 @@ class InferenceWrapper:
                     source_img_crop = self._prepare_image(source_image)
                 self.source_image = source_image
                 self.source_image_crop = source_img_crop
-                if source_mask is not None:
-                    face_mask_source = source_mask.to(self.device).float()
-                elif 'face_parsing' in self.embedders:
+                # infer.py:408-420: the face-parsing mask (> 0.6) ALWAYS multiplies the crop; source_mask only replaces
+                # source_img_mask.  Deviation, only when no 'face_parsing' network is installed (BiSeNet is third party):
+                # source_mask then stands in for the face mask as well.
+                if 'face_parsing' in self.embedders:
                     face_mask_source = (self.embedders['face_parsing'](source_img_crop) > 0.6).float()  # infer.py:408-411
+                elif source_mask is not None:
+                    face_mask_source = source_mask.to(self.device).float()
                 else:
                     raise RuntimeError("a source call needs source_mask= (or a 'face_parsing' embedder): the reference "
                                        "masks the source with BiSeNet face parsing (infer.py:410-417)")
-                source_img_mask = face_mask_source
+                source_img_mask = source_mask.to(self.device).float() if source_mask is not None else face_mask_source
                 if modnet_mask:
                     source_img_mask = self._need('matting', 'modnet_mask=True')(source_img_crop)
                 if source_mask_add:
@@ -362,7 +373,8 @@ class InferenceWrapper:
                 if custome_source_pose_embed is not None:
                     source_pose_embed = custome_source_pose_embed.to(self.device).float().contiguous()
                 else:
-                    source_pose_embed = self._expression(source_img_crop, pred_source_theta, 'a source call')
+                    source_pose_embed, self.source_img_align = self._expression(source_img_crop, pred_source_theta,
+                                                                                'a source call')
                 self.pred_source_pose_embed = source_pose_embed
                 self.source_img = source_img_crop
 
@@ -394,6 +406,10 @@ class InferenceWrapper:
                 driver_img_crop = self._detect_and_crop(driver_image) if crop else self._prepare_image(driver_image)
             if custome_target_theta_embed is not None:                                                 # infer.py:565-566
                 pred_target_theta, self.pred_target_srt = self._theta_from(custome_target_theta_embed)
+            elif driver_img_crop is None:
+                raise RuntimeError("forward(driver_image=None, custome_target_pose_embed=...) also needs "
+                                   "custome_target_theta_embed=: without a driver frame there is nothing to regress the head "
+                                   "pose from (the reference dereferences the missing crop at infer.py:562)")
             else:
                 pred_target_theta, *srt = self._head_pose(driver_img_crop)                             # infer.py:562
                 self.pred_target_srt = tuple(srt)
@@ -409,10 +425,14 @@ class InferenceWrapper:
                 pred_target_theta = torch.stack(sm)
             self.pred_target_theta = pred_target_theta
             theta_used = pred_target_theta if target_theta else self.pred_source_theta
+            # the reference runs the expression embedder on every driver frame (infer.py:596-601) and only then overrides
+            # its output (:603-604); target_img_align (:608) comes from that run
+            self.target_img_align = None
+            if driver_img_crop is not None and (custome_target_pose_embed is None or 'expression_embedder' in self.embedders):
+                target_pose_embed, self.target_img_align = self._expression(driver_img_crop, pred_target_theta,
+                                                                            'a driver call')
             if custome_target_pose_embed is not None:                                                  # infer.py:603-604
                 target_pose_embed = custome_target_pose_embed.to(self.device).float().contiguous()
-            else:
-                target_pose_embed = self._expression(driver_img_crop, pred_target_theta, 'a driver call')   # :596-601
             self.target_pose_embed = target_pose_embed
             B = target_pose_embed.shape[0]
             if theta_used.shape[0] != B:
@@ -444,10 +464,16 @@ class InferenceWrapper:
         """RCCL broadcast of the per-identity cache computed on `src_rank`: canonical volume
         (25 MB) + idt_embed (32 KB) + source theta."""
         c, d, s = self.cfg["latent_volume_channels"], self.cfg["latent_volume_depth"], self.cfg["latent_volume_size"]
+        # idt_embed is [1, idt_output_channels, idt_output_size, idt_output_size] of the checkpoint's embedder config: the
+        # receivers learn its shape from the broadcast header; what the warp embedding needs is checked on the source rank
+        es = self.cfg["gen_embed_size"]
         cache = parallel.broadcast_source_cache(
             dict(canonical=self.target_latent_volume, idt_embed=getattr(self, 'idt_embed', None),
                  theta_src=getattr(self, 'pred_source_theta', None)),
-            shapes=dict(canonical=(1, c, d, s, s), idt_embed=(1, self.cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4)),
+            shapes=dict(canonical=(1, c, d, s, s), theta_src=(1, 4, 4)), names=['canonical', 'idt_embed', 'theta_src'],
             src=src_rank, device=self.device, world=self.world, rank=self.rank)
+        if cache["idt_embed"].numel() != self.cfg["gen_max_channels"] * es * es:
+            raise RuntimeError(f"idt_embed {tuple(cache['idt_embed'].shape)} does not match the warp embedding "
+                               f"({self.cfg['gen_max_channels']} channels x {es}x{es})")
         self.pred_source_theta = cache["theta_src"]
         self._set_source_cache(canonical=cache["canonical"], idt_embed=cache["idt_embed"])

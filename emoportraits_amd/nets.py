@@ -40,12 +40,13 @@ class Norm:
             sh = sd[prefix + ".bias"].double() - rm * sc
             self.scale, self.shift = _dev(sc.float()[None], device), _dev(sh.float()[None], device)
 
-    def affine(self, x, ada=None):
+    def affine(self, x, ada=None, stats=None):
+        """stats: ops.TileStats of x left behind by the conv that produced it (then x is not read again)"""
         if self.bn:
             n = x.shape[0]
             return self.scale.expand(n, -1).contiguous(), self.shift.expand(n, -1).contiguous()
         a = ada or (None, None)
-        return ops.groupnorm_affine(x, self.gamma, self.beta, a[0], a[1])
+        return ops.groupnorm_affine(x, self.gamma, self.beta, a[0], a[1], stats=stats)
 
 
 class ResBlock:
@@ -65,22 +66,37 @@ class ResBlock:
         self.n1 = Norm(sd, prefix + ".block_feats.0", device)
         self.n2 = Norm(sd, prefix + ".block_feats.3", device)
 
-    def __call__(self, x, ups=False, ada1=None, ada2=None, down=None):
+    def __call__(self, x, ups=False, ada1=None, ada2=None, down=None, x_stats=None, want_stats=False):
         """x: block input (pre-upsample when ups).  ada1/ada2: (ada_gamma, ada_beta) [N,C] views or None.
         down: avg-pool kernel applied to the block output.  The reference pools the main and the skip branch
         separately before adding them (utils.py:744-760); pooling is linear, so pool(main + skip) is the same
-        function evaluated with one pooling pass instead of two."""
+        function evaluated with one pooling pass instead of two.
+        x_stats: ops.TileStats of x (from the conv that produced it); want_stats: return (out, TileStats of out) -- the
+        GroupNorm statistics travel with the tensors instead of being reduced by a separate pass over them."""
         # GroupNorm statistics are invariant under nearest x2 upsampling (every element is replicated 4x),
-        # so they are reduced on the small pre-upsample tensor
-        s1, h1 = self.n1.affine(x, ada1)
-        h = ops.conv_igemm(x, self.conv1, s1, h1, relu_in=True, ups=ups)
-        s2, h2 = self.n2.affine(h, ada2)
-        if self.skip is not None:
+        # so they are those of the small pre-upsample tensor
+        need = not self.n1.bn
+        s1, h1 = self.n1.affine(x, ada1, stats=x_stats)
+        h, hst = ops.conv_igemm(x, self.conv1, s1, h1, relu_in=True, ups=ups, want_stats=need)
+        s2, h2 = self.n2.affine(h, ada2, stats=hst)
+        ws = want_stats and down is None and need
+        if self.skip is not None and ups and (self.skip.kh, self.skip.kw, self.skip.kd) == (1, 1, 1):
+            # a 1x1 convolution commutes with nearest upsampling: conv1x1(up(x)) == up(conv1x1(x)) element for element
+            # (same dot product, same order), so the skip runs on the small tensor -- a quarter of the work -- and the
+            # epilogue of conv2 reads it at (y>>1, x>>1)
+            r = ops.conv_igemm(x, self.skip)
+            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, res_ups=True, want_stats=ws)
+        elif self.skip is not None:
             r = ops.conv_igemm(x, self.skip, ups=ups)
-            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, out=r)
+            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, out=r, want_stats=ws)
         else:
-            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=x, res_ups=ups)
-        return ops.avgpool(out, down) if down is not None else out
+            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=x, res_ups=ups, want_stats=ws)
+        ost = None
+        if ws:
+            out, ost = out
+        if down is not None:
+            out = ops.avgpool(out, down)
+        return (out, ost) if want_stats else out
 
 
 class WarpEmbed:
@@ -184,13 +200,13 @@ class Decoder:
 
     def __call__(self, feat_2d):
         """feat_2d [B, c*d, s, s] -> (img [B,3,S,S], feat_2d after res_decoder, img_feat) as stage_two=True returns"""
-        x = ops.conv_igemm(feat_2d, self.first)
+        x, st = ops.conv_igemm(feat_2d, self.first, want_stats=True)
         for blk in self.trunk:
-            x = blk(x)
+            x, st = blk(x, x_stats=st, want_stats=True)
         feat = x
         for blk, ups in self.up:
-            x = blk(x, ups=ups)
-        s, h = self.nh.affine(x)
+            x, st = blk(x, ups=ups, x_stats=st, want_stats=True)
+        s, h = self.nh.affine(x, stats=st)
         img = ops.conv_igemm(x, self.head, s, h, relu_in=True, act="sigmoid")
         return img, feat, x
 
@@ -201,9 +217,9 @@ class VPNResBlocks:
     def __init__(self, sd, prefix, cfg, device):
         self.blocks = [ResBlock(sd, f"{prefix}.net.net.{i}", "sn", device) for i in range(cfg["source_volume_num_blocks"])]
 
-    def __call__(self, vol):
+    def __call__(self, vol, stats=None):
         for b in self.blocks:
-            vol = b(vol)
+            vol, stats = b(vol, x_stats=stats, want_stats=True)
         return vol
 
 
@@ -235,22 +251,22 @@ class Unet3D:
                 size[0] = depth_new
                 if up:
                     x = ops.upsample_trilinear(x, (2, 1, 1))
-            x = self.down[i](x)
-            feats.append(x)
+            x, st = self.down[i](x, want_stats=True)
+            feats.append((x, st))
             if i < nb - 1:
                 x = ops.avgpool(x, (2, 2, 2) if down else (1, 2, 2))
         feats = feats[::-1]
         B = vol.shape[0]
         x = self.input_tensor.expand(B, -1, -1, -1, -1).contiguous()
         size = [x.shape[2], x.shape[3], x.shape[4]]
-        for i, feat in enumerate(feats, 1):
+        for i, (feat, fst) in enumerate(feats, 1):
             size[1] *= 2
             size[2] *= 2
             depth_new = min(self.depth * 2 ** (nb - i), size[1])
             up, down = depth_new > size[0], depth_new < size[0]
             size[0] = depth_new
             x = ops.upsample_trilinear(x, (2, 2, 2) if up else (1, 2, 2))
-            skip = self.skipb[i - 1](feat)
+            skip = self.skipb[i - 1](feat, x_stats=fst)
             x = self.up[i - 1](ops.add(x, skip))
             if down:
                 x = ops.avgpool(x, (2, 1, 1))
@@ -290,10 +306,10 @@ class HotPath:
     def source_pass(self, source_img_masked, idt_embed, source_pose_embed, theta_src, keep=False):
         """-> canonical volume [1,c,d,s,s] (NCDHW, as the reference caches it in self.target_latent_volume)"""
         c, d, s = self.c, self.d, self.s
-        latents = self.local_encoder(source_img_masked)
+        latents, lst = self.local_encoder(source_img_masked, want_stats=True)
         emb = self.embed(source_pose_embed, idt_embed)
         delta_xy = self.xy_generator(emb)
-        vol = self.volume_source(latents.view(1, c, d, s, s))
+        vol = self.volume_source(latents.view(1, c, d, s, s), stats=lst)
         inv = torch.linalg.inv(theta_src.float().cpu()).to(self.device)   # 4x4 inverse on the host (infer.py:443)
         rot = ops.grid_sample3d(vol, theta=inv, padding_mode=self.pad)
         pre = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=self.pad)

@@ -80,6 +80,24 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     return out
 
 
+def affine_grid3d(theta, size):
+    """identity_grid_3d.bmm(theta[:, :3].transpose(1, 2)).view(N, d, s, s, 3) (notebooks/infer.py:441-444, :583-588): the
+    rotation warp the theta variant of grid_sample3d generates in-kernel, as a tensor.  size = (d, h, w)."""
+    lib = hip.load()
+    theta = theta.float()[:, :3].contiguous()
+    hip.require_cuda_f32(theta)
+    if theta.dim() != 3 or theta.shape[1:] != (3, 4):
+        raise ValueError("theta must be [N,3,4] or [N,4,4]")
+    N = theta.shape[0]
+    D, H, W = size
+    idx = theta.device.index if theta.device.index is not None else torch.cuda.current_device()
+    grid = torch.empty((N, D, H, W, 3), device=theta.device, dtype=torch.float32)
+    hip.check(lib.emo_affine_grid3d_f32(hip.ptr(theta), hip.ptr(_lattice(W, idx)), hip.ptr(_lattice(H, idx)),
+                                        hip.ptr(_lattice(D, idx)), hip.ptr(grid), N, D, H, W, hip.current_stream()),
+              "emo_affine_grid3d_f32")
+    return grid
+
+
 def volume_to_channels_last(vol):
     """[N,C,D,H,W] -> [N,D,H,W,C] (one pass through a 64x64 LDS tile)."""
     lib = hip.load()
@@ -113,13 +131,7 @@ def _gn_workspace(N, G, device):
     return torch.empty(need, dtype=torch.uint8, device=device), need
 
 
-def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, groups=32, eps=1e-5, want_stats=False):
-    """scale, shift [N,C] such that GroupNorm(x) == x*scale + shift (per sample and channel).
-    ada_gamma / ada_beta: [N, C] views (row stride arbitrary, unit column stride) of the adaptive weights."""
-    lib = hip.load()
-    hip.require_cuda_f32(x, gamma, beta)
-    N, C = x.shape[0], x.shape[1]
-    S = x.numel() // (N * C)
+def _ada_views(ada_gamma, ada_beta, N, C):
     ada_stride = 0
     if ada_gamma is not None:
         for t in (ada_gamma, ada_beta):
@@ -128,18 +140,42 @@ def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, gr
         if ada_gamma.stride(0) != ada_beta.stride(0):
             raise RuntimeError("ada_gamma/ada_beta must share the row stride")
         ada_stride = ada_gamma.stride(0)
+    return ada_stride
+
+
+def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, groups=32, eps=1e-5, want_stats=False,
+                     stats=None):
+    """scale, shift [N,C] such that GroupNorm(x) == x*scale + shift (per sample and channel).
+    ada_gamma / ada_beta: [N, C] views (row stride arbitrary, unit column stride) of the adaptive weights.
+    stats: the TileStats the producing conv_igemm(..., want_stats=True) returned for x -- the statistics are then
+    combined from the tiles and x itself is not read."""
+    lib = hip.load()
+    hip.require_cuda_f32(x, gamma, beta)
+    N, C = x.shape[0], x.shape[1]
+    S = x.numel() // (N * C)
+    ada_stride = _ada_views(ada_gamma, ada_beta, N, C)
     scale = torch.empty((N, C), device=x.device, dtype=torch.float32)
     shift = torch.empty((N, C), device=x.device, dtype=torch.float32)
     mean = rstd = None
     if want_stats:
         mean = torch.empty((N, groups), device=x.device, dtype=torch.float32)
         rstd = torch.empty((N, groups), device=x.device, dtype=torch.float32)
-    ws, need = _gn_workspace(N, groups, x.device)
-    rc = lib.emo_groupnorm_affine_f32(hip.ptr(x), N, C, S, groups, eps, hip.ptr(gamma), hip.ptr(beta),
-                                      hip.ptr(ada_gamma), hip.ptr(ada_beta), ada_stride, hip.ptr(scale),
-                                      hip.ptr(shift), hip.ptr(mean), hip.ptr(rstd), hip.ptr(ws), ws.numel(),
-                                      hip.current_stream())
-    hip.check(rc, "emo_groupnorm_affine_f32")
+    if stats is not None:
+        T = stats.stats.shape[1]
+        if tuple(stats.stats.shape) != (N, T, C, 2) or T * stats.cnt != S:
+            raise ValueError("tile statistics do not belong to this tensor")
+        rc = lib.emo_groupnorm_affine_from_tiles_f32(hip.ptr(stats.stats), N, C, T, stats.cnt, groups, eps, hip.ptr(gamma),
+                                                     hip.ptr(beta), hip.ptr(ada_gamma), hip.ptr(ada_beta), ada_stride,
+                                                     hip.ptr(scale), hip.ptr(shift), hip.ptr(mean), hip.ptr(rstd),
+                                                     hip.current_stream())
+        hip.check(rc, "emo_groupnorm_affine_from_tiles_f32")
+    else:
+        ws, need = _gn_workspace(N, groups, x.device)
+        rc = lib.emo_groupnorm_affine_f32(hip.ptr(x), N, C, S, groups, eps, hip.ptr(gamma), hip.ptr(beta),
+                                          hip.ptr(ada_gamma), hip.ptr(ada_beta), ada_stride, hip.ptr(scale),
+                                          hip.ptr(shift), hip.ptr(mean), hip.ptr(rstd), hip.ptr(ws), ws.numel(),
+                                          hip.current_stream())
+        hip.check(rc, "emo_groupnorm_affine_f32")
     if want_stats:
         return scale, shift, mean, rstd
     return scale, shift
@@ -148,10 +184,21 @@ def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, gr
 # ----------------------------------------------------------------------------------------------------------------
 # implicit-GEMM convolution
 # ----------------------------------------------------------------------------------------------------------------
+class TileStats:
+    """Per-tile GroupNorm statistics written by the conv epilogue: stats [N, T, C, 2] = (mean, centred sum of squares)
+    of `cnt` output values per (sample, tile, channel).  Handed to groupnorm_affine(..., stats=) instead of the tensor."""
+    __slots__ = ("stats", "cnt")
+
+    def __init__(self, stats, cnt):
+        self.stats, self.cnt = stats, cnt
+
+
 def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=None, res_ups=False, act="none",
-               out=None, ksplit=None):
+               out=None, ksplit=None, want_stats=False):
     """layer: emoportraits_amd.pack.PackedConv.  x [N,Cin,H,W] or [N,Cin,D,H,W].
-    ksplit: K-loop split of the launch (None: pack.plan_launch decides together with the block config)."""
+    ksplit: K-loop split of the launch (None: pack.plan_launch decides together with the block config).
+    want_stats: also return the TileStats of the output (None when this launch cannot produce them: K-split launches
+    and the fp16-operand kernel) -> (out, stats)."""
     lib = hip.load()
     hip.require_cuda_f32(x, scale, shift, res)
     three_d = x.dim() == 5
@@ -174,17 +221,27 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         want = (N, layer.cout, D, Hl // 2, Wl // 2) if res_ups else (N, layer.cout, D, Hl, Wl)
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
             raise ValueError("bad residual shape")
-    cfg, ks = layer.plan_for(N * D * Hl * Wl // 128)
+    positions = N * D * Hl * Wl
+    cfg, ks = layer.plan_for(max(1, -(-positions // 128)))
     if ksplit is not None:
         ks = int(ksplit)
     ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None
-    entry = lib.emo_conv_igemm_f16acc32 if layer.precision == "f16" else lib.emo_conv_igemm_f32
-    rc = entry(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
-               hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
-               layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
-               hip.ptr(ws), hip.current_stream())
+    stats = None
+    if layer.precision == "f16":
+        rc = lib.emo_conv_igemm_f16acc32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
+                                         hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
+                                         layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
+                                         hip.ptr(ws), hip.current_stream())
+    else:
+        if want_stats and ks == 1 and (D * Hl * Wl) % 128 == 0:
+            stats = TileStats(torch.empty((N, D * Hl * Wl // 128, layer.cout, 2), device=x.device, dtype=torch.float32), 128)
+        rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
+                                    hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
+                                    layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
+                                    hip.ptr(ws), hip.ptr(stats.stats) if stats is not None else None,
+                                    hip.current_stream())
     hip.check(rc, f"emo_conv_igemm_{layer.precision}[{layer.name}]")
-    return out
+    return (out, stats) if want_stats else out
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -191,15 +191,17 @@ class DecoderStage2:
         self.head = PackedConv.from_state_dict(sd, prefix + ".img_decoder.dec_img_head.2", kind, device)
 
     def __call__(self, feat_2d):
-        x = ops.conv_igemm(feat_2d, self.first)
+        # GroupNorm variant: the tile statistics of every conv output travel with the tensor (nets.ResBlock); the BatchNorm
+        # default has static affines and asks for none
+        x, st = ops.conv_igemm(feat_2d, self.first, want_stats=not self.nh.bn)
         for b in self.trunk:
-            x = b(x)
+            x, st = b(x, x_stats=st, want_stats=True)
         for b in self.up:
-            x = b(x, ups=True)
-        x = self.feat[0](x, ups=True)
+            x, st = b(x, ups=True, x_stats=st, want_stats=True)
+        x, st = self.feat[0](x, ups=True, x_stats=st, want_stats=True)
         for b in self.feat[1:]:
-            x = b(x)
-        s, h = self.nh.affine(x)
+            x, st = b(x, x_stats=st, want_stats=True)
+        s, h = self.nh.affine(x, stats=st)
         return ops.conv_igemm(x, self.head, s, h, relu_in=True, act="tanh")
 
 
@@ -263,6 +265,7 @@ class InferenceWrapper:
         images as uint8 [B,H,W,3] device tensors instead of PIL lists (pack on the device, one D2H when needed)."""
         S2 = self.cfg["output_size_s2"]
         img = img.to(self.device).float().contiguous()
+        img0 = img                                                                 # returned un-resized (infer_s2.py:377-378)
         if img.shape[-1] != S2 or img.shape[-2] != S2:
             img = ops.resize2d(img, (S2, S2), "bilinear")                          # infer_s2.py:360-362
         if mask is None:
@@ -279,6 +282,8 @@ class InferenceWrapper:
         mask = mask.to(self.device).float().contiguous()
         face_mask = face_mask.to(self.device).float().contiguous()
         out = self.model_two.refine(img, mask, face_mask)
-        return ops.pack_rgb8(img), ops.pack_rgb8(img), ops.pack_rgb8(out), mask
+        resized_u8 = ops.pack_rgb8(img)
+        first_u8 = resized_u8 if img0 is img else ops.pack_rgb8(img0)
+        return first_u8, resized_u8, ops.pack_rgb8(out), mask
 
     __call__ = forward

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 2
+#define EMO_ABI_VERSION 3
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
@@ -81,6 +81,13 @@ int emo_grid_sample3d_f32(const float* vol, const float* grid, const float* thet
                           int64_t vol_batch_stride, int padding_mode,
                           int in_layout, int out_layout, int variant, int grid_kind, void* stream);
 
+/* a2 alone -- the rotation warp as a tensor: grid[n,z,y,x,:] = theta[n,:3,:4] . (lin_x[x], lin_y[y], lin_z[z], 1), the same
+ * fma chain the theta variant of emo_grid_sample3d_f32 evaluates in-kernel.  Replaces
+ * `identity_grid_3d.bmm(theta[:, :3].transpose(1, 2)).view(-1, d, s, s, 3)` (notebooks/infer.py:441-444, :583-588; cached there
+ * as self.source_rotation_warp).  theta [N,3,4] row-major, grid [N,Do,Ho,Wo,3]. */
+int emo_affine_grid3d_f32(const float* theta, const float* lin_x, const float* lin_y, const float* lin_z,
+                          float* grid, int N, int Do, int Ho, int Wo, void* stream);
+
 /* NCDHW <-> NDHWC repack of a 5-D volume (used once per identity on the cached canonical volume,
  * notebooks/infer.py:507 `self.target_latent_volume`).  to_channels_last != 0: NCDHW -> NDHWC. */
 int emo_volume_repack_f32(const float* in, float* out, int N, int C, int DHW, int to_channels_last, void* stream);
@@ -102,6 +109,14 @@ int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S, int G, flo
                              const float* ada_gamma, const float* ada_beta, int64_t ada_stride,
                              float* scale, float* shift, float* mean_out, float* rstd_out,
                              void* workspace, int64_t workspace_bytes, void* stream);
+/* The same affine from the per-tile statistics emo_conv_igemm_f32 leaves in `gn_stats` (no pass over the activation):
+ *   stats [N][T][C][2] = (mean, centred sum of squares) of `cnt` values each, T tiles per sample and channel
+ *   (emo_conv_igemm_f32: T = D*Hl*Wl / 128, cnt = 128).  Combined per (sample, group) in fp64 with the equal-count
+ *   pairwise update (Chan et al.): no E[x^2] - mean^2 cancellation.  Other arguments as emo_groupnorm_affine_f32. */
+int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_t T, int cnt, int G, float eps,
+                                        const float* gamma, const float* beta,
+                                        const float* ada_gamma, const float* ada_beta, int64_t ada_stride,
+                                        float* scale, float* shift, float* mean_out, float* rstd_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a5/a9/a10 -- implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
@@ -126,13 +141,18 @@ int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S, int G, flo
  *         of the 256 CUs idle; partial sums go to workspace [ksplit][N*Cout*D*Hl*Wl] floats and a second kernel adds them
  *         in fixed order and applies bias / residual / activation (deterministic; `out` may alias `res`).  ksplit = 1,
  *         workspace = NULL: single pass.  emo_conv_igemm_ksplit returns the split count the launch heuristic wants.
+ *   gn_stats   NULL, or [N][D*Hl*Wl/128][Cout][2] floats (ksplit == 1 only): the epilogue also reduces, per sample,
+ *         128-position tile and output channel, the mean and the centred sum of squares of the FINAL output values
+ *         (after bias / residual / act) -- the statistics of the GroupNorm that follows in the next block
+ *         (utils.py:711-731), consumed by emo_groupnorm_affine_from_tiles_f32 instead of a pass over `out`.
  * Supported output widths: multiples of 128, or 64 / 32 / 16 / 8 (with H resp. D divisible by the tile).
  */
 int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC);
 int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias,
                        const float* scale, const float* shift, const float* res, float* out,
                        int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
-                       int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace, void* stream);
+                       int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
+                       float* gn_stats, void* stream);
 int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW, int ups, int cfg);
 
 /* Reduced-precision mode (BASELINE.json configs[4], "fp16 MFMA convs"; opt-in per layer, never the default): the same

@@ -36,7 +36,7 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     # null pointers -> EMO_ERR_BAD_ARG before any launch
     rc = lib.emo_grid_sample3d_f32(None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, None)
     assert rc == -1
-    rc = lib.emo_conv_igemm_f32(None, None, None, None, None, None, None, 1, 4, 4, 1, 8, 8, 1, 3, 3, 0, 0, 0, 0, 0, 1, None, None)
+    rc = lib.emo_conv_igemm_f32(None, None, None, None, None, None, None, 1, 4, 4, 1, 8, 8, 1, 3, 3, 0, 0, 0, 0, 0, 1, None, None, None)
     assert rc == -1
 
 

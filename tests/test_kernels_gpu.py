@@ -246,6 +246,86 @@ def test_groupnorm_large_mean_is_stable():
     assert (got - ref).abs().max().item() < 0.05   # fp32 x*scale+shift cancellation bound at |x|=1e3, rstd=1e2
 
 
+# ---- GroupNorm statistics reduced in the conv epilogue (conv_igemm.h gn_stats -> emo_groupnorm_affine_from_tiles_f32) ----
+@pytest.mark.parametrize("case", [
+    # (N, Cin, Cout, dims, k, cfg, res, bias)
+    (2, 64, 128, (64, 64), 3, 0, True, True),       # 128-row config, waves 2x2
+    (2, 64, 320, (32, 32), 3, 1, True, False),      # 64-row config, waves 1x4, 10 channels per group
+    (1, 32, 96, (8, 32, 32), 3, 2, False, True),    # 32-row config, 3-D, 3 channels per group
+    (3, 48, 192, (128, 128), 1, 1, False, False),   # 1x1, 6 channels per group
+    (2, 16, 32, (16, 16), 3, 2, True, True),        # one channel per group
+])
+def test_conv_epilogue_groupnorm_statistics(case):
+    """scale / shift from the tile statistics the conv epilogue writes == GroupNorm of the conv output (torch CPU, fp64
+    statistics), and identical (to fp32 rounding of the final affine) to the separate-pass kernel on the same tensor"""
+    N, Cin, Cout, dims, k, cfg, res, bias = case
+    g = torch.Generator().manual_seed(11)
+    three_d = len(dims) == 3
+    x = torch.randn(N, Cin, *dims, generator=g)
+    wshape = (Cout, Cin) + (k,) * len(dims)
+    w = torch.randn(*wshape, generator=g) / math.sqrt(Cin * k ** len(dims))
+    b = torch.randn(Cout, generator=g) if bias else None
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    layer = pack.PackedConv("test", w, b, DEV, cfg=cfg)
+    r = torch.randn(N, Cout, *dims, generator=g).to(DEV) if res else None
+    out, st = ops.conv_igemm(x.to(DEV), layer, res=r, want_stats=True)
+    assert st is not None and st.stats.shape == (N, out[0, 0].numel() // 128, Cout, 2)
+    s1, h1 = ops.groupnorm_affine(out, gamma.to(DEV), beta.to(DEV), stats=st)
+    s0, h0 = ops.groupnorm_affine(out, gamma.to(DEV), beta.to(DEV))
+    o = out.cpu()
+    ref = F.group_norm(o.double(), 32, gamma.double(), beta.double()).float()
+    bshape = (N, Cout) + (1,) * len(dims)
+    got = o * s1.cpu().view(bshape) + h1.cpu().view(bshape)
+    assert rel_err(got, ref) < 1e-5
+    assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item()
+    assert (h1 - h0).abs().max().item() <= 2e-6 * max(h0.abs().max().item(), 1.0)
+    # the conv output itself is unchanged by asking for statistics
+    assert torch.equal(out, ops.conv_igemm(x.to(DEV), layer, res=r))
+
+
+def test_conv_epilogue_groupnorm_statistics_large_mean_is_stable():
+    """same stress as test_groupnorm_large_mean_is_stable, through the conv epilogue: outputs 1000 +- 0.01 (bias 1000).
+    The tile statistics are (mean, centred sum of squares), so nothing of the form E[x^2] - mean^2 is ever evaluated in fp32."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, 64, 64, generator=g)
+    w = torch.randn(32, 16, 3, 3, generator=g) * (0.01 / 12.0)
+    b = torch.full((32,), 1000.0)
+    layer = pack.PackedConv("test", w, b, DEV, cfg=2)
+    out, st = ops.conv_igemm(x.to(DEV), layer, want_stats=True)
+    s, h = ops.groupnorm_affine(out, stats=st)
+    o = out.cpu()
+    got = o * s.cpu().view(1, 32, 1, 1) + h.cpu().view(1, 32, 1, 1)
+    ref = F.group_norm(o.double(), 32).float()
+    assert o.std().item() < 0.05 and abs(o.mean().item() - 1000.0) < 0.1
+    assert (got - ref).abs().max().item() < 0.05   # fp32 x*scale+shift cancellation bound at |x|=1e3, rstd~1e2
+
+
+def test_conv_statistics_are_refused_where_they_cannot_be_produced():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 64, 16, 16, generator=g).to(DEV)
+    layer = pack.PackedConv("test", torch.randn(64, 64, 3, 3, generator=g), None, DEV, cfg=0)
+    out, st = ops.conv_igemm(x, layer, ksplit=4, want_stats=True)      # K-split launch: no tile statistics, caller falls back
+    assert st is None
+    ref = ops.conv_igemm(x, layer, ksplit=1)
+    assert rel_err(out, ref.cpu()) < 1e-5
+
+
+def test_upsampling_resblock_skip_commutes_with_nearest_upsampling():
+    """nets.ResBlock runs the 1x1 skip of an up-block on the pre-upsample tensor (conv1x1(up(x)) == up(conv1x1(x))
+    element for element) and lets conv2's epilogue read it at (y>>1, x>>1): bit-identical to the direct form"""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 32, 32, generator=g).to(DEV)
+    h = torch.randn(2, 96, 64, 64, generator=g).to(DEV)
+    skip = pack.PackedConv("skip", torch.randn(96, 64, 1, 1, generator=g) / 8, None, DEV)
+    conv2 = pack.PackedConv("conv2", torch.randn(96, 96, 3, 3, generator=g) / 30, None, DEV)
+    r_big = ops.conv_igemm(x, skip, ups=True, ksplit=1)
+    direct = ops.conv_igemm(h, conv2, res=r_big)
+    r_small = ops.conv_igemm(x, skip, ksplit=1)
+    commuted = ops.conv_igemm(h, conv2, res=r_small, res_ups=True)
+    assert torch.equal(F.interpolate(r_small, scale_factor=2, mode="nearest"), r_big)
+    assert torch.equal(direct, commuted)
+
+
 def test_adaptive_groupnorm_matches_reference_quirk():
     g = torch.Generator().manual_seed(6)
     N, C = 3, 64

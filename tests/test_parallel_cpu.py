@@ -38,12 +38,14 @@ def _worker(rank, world, port, q):
                       MASTER_PORT=str(port))
     r, w = parallel.init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
-    shapes = dict(canonical=(1, 4, 2, 3, 3), idt_embed=(1, 8, 4, 4), theta_src=(1, 4, 4))
+    # odd sizes on purpose: entries are padded to 16-byte boundaries inside the single flat broadcast
+    shapes = dict(canonical=(1, 4, 2, 3, 3), idt_embed=(1, 7, 3, 3), theta_src=(1, 4, 4))
     g = torch.Generator().manual_seed(5)
     full = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
     cache = full if rank == 0 else {k: None for k in shapes}
-    got = parallel.broadcast_source_cache(cache, shapes, src=0, world=w, rank=r)
-    ok = all(torch.equal(got[k], full[k]) for k in shapes)
+    # only the source rank knows (and checks) the shapes; receivers learn them from the broadcast header
+    got = parallel.broadcast_source_cache(cache, shapes if rank == 0 else None, src=0, world=w, rank=r, names=list(shapes))
+    ok = all(torch.equal(got[k], full[k]) and got[k].data_ptr() % 16 == 0 for k in shapes)
     # frame sharding: every rank processes its contiguous slice of 11 "frames"; union must be all frames
     lo, hi = parallel.shard_range(11, r, w)
     t = parallel.max_over_ranks(float(rank + 1))
