@@ -531,6 +531,138 @@ int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
+// v3: channel-group-per-XCD kernels (EMO_LAYOUT_CG8).  Layout [N][8][D][H][W][C/8]: the C channels are split into 8
+// groups and the group index is the SLOWEST dimension below the sample, so a group's sub-volume is one contiguous
+// C/8-channel NDHWC volume (3.1 MB for 96 x 16 x 64 x 64).  Block b samples channel group b % 8 -- the dispatcher places
+// block b on XCD b % 8 (MI355X_MICROARCH.md, speed only, never correctness) -- so each XCD's private 4 MiB L2 only ever
+// sees ITS eighth of the volume.  Measured reason (profiles/r2_pmc_sampler_*.json, rocprofv3 TCC counters of the v2
+// kernels at 16 frames): the shared-volume call issued 3.8 M fabric read requests = 0.49 GB against 38 MB of algorithmic
+// reads -- every XCD streams the whole 25 MB canonical volume through its L2 twice (each z-plane as the lower and, a whole
+// z-slice of output writes later, as the upper corner plane) -- on top of the 0.40 GB it writes: the kernel sat at
+// ~4.5 TB/s of fabric traffic while delivering 2.2 TB/s of algorithmic bytes.  With one group per XCD the sub-volume stays
+// L2-resident and the volume crosses the fabric once per launch.
+// A block: 256 voxels (4 x-rows at Wo = 64), taps once per voxel in LDS (as v2), then (voxel, quad) items: C/32 quads per
+// voxel, lanes of a voxel adjacent => each corner is one contiguous C/8*4-byte read and x-neighbours continue it.
+// Block order inside an XCD: z-slice major over the samples when the volume is shared (the two corner planes of a slice,
+// 0.4 MB per group, serve all samples back to back), sample major otherwise.
+// ------------------------------------------------------------------------------------------------------
+constexpr int CG8_VPB = 256;
+
+template <int PAD, int MODE, bool OUT_NCDHW>
+__global__ __launch_bounds__(256) void gs3d_cg8_kernel(
+    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
+    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+    float* __restrict__ out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int bps,
+    int slice_major) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  TapRec* recs = reinterpret_cast<TapRec*>(smem);                       // CG8_VPB * 80 B
+  float* tile = smem + CG8_VPB * (sizeof(TapRec) / 4);                  // OUT_NCDHW: [C/8][CG8_VPB + 1]
+  constexpr int LD = CG8_VPB + 1;
+  const int CG = C >> 3;                 // channels per group
+  const int QPV = CG >> 2;               // float4 quads per voxel
+  const int nvox = Do * Ho * Wo;
+  const int g = blockIdx.x & 7;          // channel group == XCD of this block
+  const int idx = blockIdx.x >> 3;
+  int n, blk;
+  if (slice_major) {                     // (z-slice, sample, block in slice); needs bps % Do == 0
+    const int bpz = bps / Do;
+    const int z = idx / (N * bpz);
+    const int rem = idx - z * (N * bpz);
+    n = rem / bpz;
+    blk = z * bpz + (rem - n * bpz);
+  } else {
+    n = idx / bps;
+    blk = idx - n * bps;
+  }
+  const int vox0 = blk * CG8_VPB;
+  stage_taps<PAD, MODE, CG8_VPB>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
+  __syncthreads();
+  const long gvol = (long)D * H * W * CG;                               // floats of one group's sub-volume
+  const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride + (long)g * gvol);
+  const unsigned row_bytes = (unsigned)CG * 4u;
+  const int nv = min(CG8_VPB, nvox - vox0);
+  const int nitems = nv * QPV;
+  float4* obase = reinterpret_cast<float4*>(out + (((long)n * 8 + g) * nvox + vox0) * CG);   // CG8 output
+  for (int item = threadIdx.x; item < nitems; item += 256) {
+    const int v = item / QPV;
+    const int q = item - v * QPV;
+    const TapRec r = recs[v];
+    const float4 acc = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
+    if (OUT_NCDHW) {
+      const int c = q * 4;
+      tile[(c + 0) * LD + v] = acc.x;
+      tile[(c + 1) * LD + v] = acc.y;
+      tile[(c + 2) * LD + v] = acc.z;
+      tile[(c + 3) * LD + v] = acc.w;
+    } else {
+      obase[item] = acc;
+    }
+  }
+  if (OUT_NCDHW) {
+    __syncthreads();
+    float* ob = out + ((long)n * C + (long)g * CG) * nvox + vox0;      // channel g*CG + c, voxels vox0 .. vox0 + nv
+    for (int i = threadIdx.x; i < CG * CG8_VPB; i += 256) {
+      const int c = i / CG8_VPB;
+      const int v = i - c * CG8_VPB;
+      if (v < nv) ob[(long)c * nvox + v] = tile[c * LD + v];
+    }
+  }
+}
+
+template <int PAD, int MODE>
+int launch_cg8(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
+               const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+               long vol_bstride, int out_layout, hipStream_t s) {
+  if (C % 32) return EMO_ERR_UNSUPPORTED;                               // 8 groups of whole float4 quads
+  if ((long)D * H * W * (C / 8) * 4 >= (1L << 32)) return EMO_ERR_UNSUPPORTED;   // 32-bit byte offsets inside a group
+  const int nvox = Do * Ho * Wo;
+  const int bps = emo_cdiv(nvox, CG8_VPB);
+  const long total = (long)bps * N * 8;
+  if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  const int slice_major = (vol_bstride == 0 && N > 1 && (nvox % CG8_VPB) == 0 && (bps % Do) == 0) ? 1 : 0;
+  if (out_layout == EMO_LAYOUT_CG8) {
+    const size_t lds = CG8_VPB * sizeof(TapRec);
+    hipLaunchKernelGGL((gs3d_cg8_kernel<PAD, MODE, false>), dim3((unsigned)total), dim3(256), lds, s, vol, grid, theta,
+                       lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride, bps, slice_major);
+  } else if (out_layout == EMO_LAYOUT_NCDHW) {
+    const size_t lds = CG8_VPB * sizeof(TapRec) + (size_t)(C / 8) * (CG8_VPB + 1) * sizeof(float);
+    if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((gs3d_cg8_kernel<PAD, MODE, true>), dim3((unsigned)total), dim3(256), lds, s, vol, grid, theta,
+                       lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride, bps, slice_major);
+  } else {
+    return EMO_ERR_UNSUPPORTED;
+  }
+  return emo_launch_status();
+}
+
+// layout repack NCDHW [N][C][S] -> CG8 [N][8][S][C/8] (and back): per group a [C/8][S] <-> [S][C/8] transpose
+__global__ __launch_bounds__(256) void repack_cg8_kernel(const float* __restrict__ in, float* __restrict__ out, int CG,
+                                                         int S, int to_cg8) {
+  // one block per (64 spatial positions, group, sample); CG <= 64
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, g = blockIdx.y, s0 = blockIdx.x * 64;
+  const long base = ((long)n * 8 + g) * CG * S;            // both layouts keep (sample, group) outermost
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (to_cg8) {
+    for (int c = ty; c < CG; c += 4)
+      if (s0 + tx < S) tile[c][tx] = in[base + (long)c * S + s0 + tx];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * CG; i += 256) {
+      const int sp = i / CG, c = i - sp * CG;
+      if (s0 + sp < S) out[base + (long)(s0 + sp) * CG + c] = tile[c][sp];
+    }
+  } else {
+    for (int i = threadIdx.x; i < 64 * CG; i += 256) {
+      const int sp = i / CG, c = i - sp * CG;
+      if (s0 + sp < S) tile[c][sp] = in[base + (long)(s0 + sp) * CG + c];
+    }
+    __syncthreads();
+    for (int c = ty; c < CG; c += 4)
+      if (s0 + tx < S) out[base + (long)c * S + s0 + tx] = tile[c][tx];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // layout repack [N][C][S] <-> [N][S][C] through a 64x64 LDS tile
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -674,6 +806,13 @@ extern "C" int emo_volume_repack_f32(const float* in, float* out, int N, int C, 
                                      void* stream) {
   if (!in || !out || N <= 0 || C <= 0 || DHW <= 0) return EMO_ERR_BAD_ARG;
   if (N > 65535) return EMO_ERR_UNSUPPORTED;
+  if (to_channels_last == 2 || to_channels_last == 3) {   // NCDHW <-> CG8
+    if (C % 32 || C / 8 > 64) return EMO_ERR_UNSUPPORTED;
+    dim3 g(emo_cdiv(DHW, 64), 8, N);
+    hipLaunchKernelGGL(repack_cg8_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, C / 8, DHW, to_channels_last == 2);
+    return emo_launch_status();
+  }
+  if (to_channels_last != 0 && to_channels_last != 1) return EMO_ERR_BAD_ARG;
   const int R = to_channels_last ? C : DHW;       // rows of the input matrix
   const int Ccols = to_channels_last ? DHW : C;   // columns of the input matrix
   dim3 g(emo_cdiv(Ccols, 64), emo_cdiv(R, 64), N);

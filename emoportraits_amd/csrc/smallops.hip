@@ -107,6 +107,20 @@ __global__ __launch_bounds__(256) void pack_rgb8_kernel(const float* __restrict_
   }
 }
 
+// the inverse direction, notebooks/infer.py:211-223 convert_to_tensor (ToTensor): [N,H,W,3] uint8 -> [N,3,H,W] fp32 = byte / 255
+// (an fp32 division like torch's, not a multiplication by the rounded reciprocal)
+__global__ __launch_bounds__(256) void unpack_rgb8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long N,
+                                                          long HW) {
+  const long total = N * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / HW, p = i - n * HW;
+    const uint8_t* src = in + i * 3;
+    float* dst = out + n * 3 * HW + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[c * HW] = __fdiv_rn((float)src[c], 255.0f);
+  }
+}
+
 // inverse of B 4x4 matrices (head-pose affines: notebooks/infer.py:443, expression_embedder.py:185-188 call
 // `theta.float().inverse()`): Gauss-Jordan with partial pivoting in double, one thread per matrix.
 __global__ __launch_bounds__(64) void mat4_inverse_kernel(const float* __restrict__ in, float* __restrict__ out, int B) {
@@ -200,6 +214,16 @@ extern "C" int emo_pack_rgb8(const float* img, uint8_t* out, int N, int H, int W
   long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(pack_rgb8_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, out, (long)N,
+                     (long)H * W);
+  return emo_launch_status();
+}
+
+extern "C" int emo_unpack_rgb8(const uint8_t* in, float* out, int N, int H, int W, void* stream) {
+  if (!in || !out || N <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
+  const long total = (long)N * H * W;
+  long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(unpack_rgb8_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, in, out, (long)N,
                      (long)H * W);
   return emo_launch_status();
 }

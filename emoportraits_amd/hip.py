@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMO_HIP_LIB") or os.path.join(_HERE, "lib", "libemoportraits_hip.so")
 
 PAD_MODES = {"zeros": 0, "border": 1, "reflection": 2}
-LAYOUT_NCDHW, LAYOUT_NDHWC = 0, 1
+LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_CG8 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 _c_int, _c_i64, _c_void, _c_float = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
@@ -50,6 +50,7 @@ SIGNATURES = {
     "emo_projector_finalize_f32": [_c_void] * 7 + [_c_int] * 3 + [_c_void],
     "emo_pose_theta_f32": [_c_void, _c_int, _c_void, _c_void, _c_void, _c_int, _c_void],
     "emo_pack_rgb8": [_c_void, _c_void, _c_int, _c_int, _c_int, _c_void],
+    "emo_unpack_rgb8": [_c_void, _c_void, _c_int, _c_int, _c_int, _c_void],
 }
 _RESTYPES = {"emo_build_info": ctypes.c_char_p, "emo_groupnorm_workspace_bytes": _c_i64}
 

@@ -388,7 +388,8 @@ class InferenceWrapper:
                 self.source_latent_volume = vol if c_source_latent_volume is None else \
                     c_source_latent_volume.to(self.device).float().contiguous()
                 inv = torch.linalg.inv(pred_source_theta.float().cpu()).to(self.device)                # infer.py:443
-                self.source_rotation_warp = inv
+                self._source_theta_inv = inv
+                self.source_rotation_warp = ops.affine_grid3d(inv, (d, s, s))                          # infer.py:441-444
                 self.source_xy_warp_resize = delta_xy
                 rot = ops.grid_sample3d(self.source_latent_volume, theta=inv, padding_mode=hp.pad)     # infer.py:499-500
                 tv = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=hp.pad)
@@ -459,6 +460,80 @@ class InferenceWrapper:
             theta = ops.pose_theta(*srt)
             img = self._drive(pose, theta)
             yield b0, (ops.pack_rgb8(img) if as_uint8 else img)
+
+    # ------------------------------------------------------------------------------------------------------
+    def animate_frames(self, frames, batch_size=16, windows=None, ring=3, to_host=True, smooth_pose=False):
+        """Video in -> video out, device resident (notebooks/infer.py:511-556, :562-601, :641-644 per
+        frame there).  frames: uint8 [N,H,W,3] tensor (host, ideally pinned, or device) or an iterable of such chunks --
+        decoded video frames, uploaded as BYTES.  Per batch, all on the device and without a host synchronisation:
+            byte -> fp32 CHW (emo_unpack_rgb8) -> crop window read in place + bicubic resize to image_size
+            (emo_resize2d_f32; `windows[i] = (x_lo, y_lo, side)` from the face detector + hostglue.crop_window, host
+            arithmetic; None = whole frame) -> HeadPoseRegressor -> ExpressionEmbed -> hot path -> uint8 HWC.
+        The driver-side matte (MODNet) of the reference is computed but unused with use_seg=False (infer.py:592-601): skipped.
+        to_host: results go D2H into a ring of `ring` pinned buffers on a copy stream; a batch is yielded once ITS copy
+        event has completed, i.e. the host only ever waits for a batch that is `ring - 1` batches behind the GPU.
+        Yields (first_frame_index, uint8 [b,S,S,3]) -- a pinned host tensor (valid until `ring - 1` more batches have been
+        yielded) or, with to_host=False, the device tensor.  Frames are sharded contiguously across ranks as in animate()."""
+        if self._canonical_cl is None:
+            raise RuntimeError("call forward with a source_image first")
+        S = self.cfg["image_size"]
+        chunks = [frames] if isinstance(frames, torch.Tensor) else frames
+        copy_stream = torch.cuda.Stream(device=self.device) if to_host else None
+        slots, pending = [], []          # pinned buffers; (first index, slot, n frames, event) in flight
+
+        def drain(keep):
+            while len(pending) > keep:
+                b0, slot, nb, ev = pending.pop(0)
+                ev.synchronize()
+                yield b0, slots[slot][:nb]
+
+        base, k = 0, 0
+        for chunk in chunks:
+            if chunk.dtype != torch.uint8 or chunk.dim() != 4 or chunk.shape[-1] != 3:
+                raise ValueError("frames must be uint8 [N,H,W,3]")
+            n = chunk.shape[0]
+            lo, hi = parallel.shard_range(n, self.rank, self.world)
+            for b0 in range(lo, hi, batch_size):
+                b1 = min(b0 + batch_size, hi)
+                u8 = chunk[b0:b1].to(self.device, non_blocking=True).contiguous()
+                x = ops.unpack_rgb8(u8)
+                if windows is not None:
+                    crops = torch.cat([ops.resize2d(x[i:i + 1], (S, S), "bicubic",
+                                                    window=(*windows[base + b0 + i][:2], windows[base + b0 + i][2],
+                                                            windows[base + b0 + i][2]), clamp01=True)
+                                       for i in range(b1 - b0)])
+                elif x.shape[-2:] != (S, S):
+                    crops = ops.resize2d(x, (S, S), "bicubic")
+                else:
+                    crops = x
+                theta, *_ = self._head_pose(crops)
+                if smooth_pose:                      # scan over frame order (infer.py:571-581): a per-rank host loop
+                    if self.theta is None:
+                        self.theta = theta[0].clone()
+                    sm = []
+                    for i in range(theta.shape[0]):
+                        self.theta = theta[i] * self.pose_momentum + self.theta * (1 - self.pose_momentum)
+                        sm.append(self.theta.clone())
+                    theta = torch.stack(sm)
+                pose, _ = self._expression(crops, theta, 'a driver call')
+                out = ops.pack_rgb8(self._drive(pose, theta.float().contiguous()))
+                if not to_host:
+                    yield base + b0, out
+                    continue
+                if len(slots) < ring:
+                    slots.append(torch.empty((batch_size, S, S, 3), dtype=torch.uint8, pin_memory=True))
+                slot = k % ring
+                k += 1
+                copy_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(copy_stream):
+                    slots[slot][:b1 - b0].copy_(out, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                out.record_stream(copy_stream)
+                pending.append((base + b0, slot, b1 - b0, ev))
+                yield from drain(ring - 1)
+            base += n
+        yield from drain(0)
 
     def share_source(self, src_rank=0):
         """RCCL broadcast of the per-identity cache computed on `src_rank`: canonical volume

@@ -77,7 +77,8 @@ class ResBlock:
         # so they are those of the small pre-upsample tensor
         need = not self.n1.bn
         s1, h1 = self.n1.affine(x, ada1, stats=x_stats)
-        h, hst = ops.conv_igemm(x, self.conv1, s1, h1, relu_in=True, ups=ups, want_stats=need)
+        h, hst = ops.conv_igemm(x, self.conv1, s1, h1, relu_in=True, ups=ups, want_stats=True) if need else \
+            (ops.conv_igemm(x, self.conv1, s1, h1, relu_in=True, ups=ups), None)
         s2, h2 = self.n2.affine(h, ada2, stats=hst)
         ws = want_stats and down is None and need
         if self.skip is not None and ups and (self.skip.kh, self.skip.kw, self.skip.kd) == (1, 1, 1):
@@ -290,6 +291,10 @@ class HotPath:
         self.pad = cfg["grid_sample_padding_mode"]
         self.c, self.d, self.s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
         self.with_source = with_source
+        # EMO_SAMPLER_LAYOUT=ndhwc selects the round-1 channels-last sampler kernels (A/B measurements)
+        import os
+        want = os.environ.get("EMO_SAMPLER_LAYOUT", "cg8")
+        self.sampler_layout = "cg8" if (want == "cg8" and self.c % 32 == 0) else "ndhwc"
         from .pack import conv_precision
         with conv_precision(precision):
             self.embed = WarpEmbed(sd, cfg, self.device)
@@ -306,10 +311,12 @@ class HotPath:
     def source_pass(self, source_img_masked, idt_embed, source_pose_embed, theta_src, keep=False):
         """-> canonical volume [1,c,d,s,s] (NCDHW, as the reference caches it in self.target_latent_volume)"""
         c, d, s = self.c, self.d, self.s
-        latents, lst = self.local_encoder(source_img_masked, want_stats=True)
+        latents = self.local_encoder(source_img_masked)
         emb = self.embed(source_pose_embed, idt_embed)
         delta_xy = self.xy_generator(emb)
-        vol = self.volume_source(latents.view(1, c, d, s, s), stats=lst)
+        # (the [1, c*d, s, s] -> [1, c, d, s, s] view regroups the channels: the 2-D tile statistics of `latents` do not
+        # describe the 3-D GroupNorm groups, so the first VPN norm reduces its own)
+        vol = self.volume_source(latents.view(1, c, d, s, s))
         inv = torch.linalg.inv(theta_src.float().cpu()).to(self.device)   # 4x4 inverse on the host (infer.py:443)
         rot = ops.grid_sample3d(vol, theta=inv, padding_mode=self.pad)
         pre = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=self.pad)
@@ -320,7 +327,10 @@ class HotPath:
         return canonical
 
     def prepare_canonical(self, canonical):
-        """channels-last copy of the cached canonical volume (done once per identity)"""
+        """sampler-layout copy of the cached canonical volume (done once per identity): 8 channel groups, one per XCD
+        (EMO_LAYOUT_CG8) when the channel count allows, else channels-last"""
+        if self.sampler_layout == "cg8":
+            return ops.volume_to_cg8(canonical)
         return ops.volume_to_channels_last(canonical)
 
     # ---- per driver batch ---------------------------------------------------------------------------
@@ -328,10 +338,9 @@ class HotPath:
         B = target_pose_embed.shape[0]
         emb = self.embed(target_pose_embed, idt_embed)
         delta_uv = self.uv_generator(emb)
-        warped = ops.grid_sample3d(canonical_cl, delta=delta_uv, padding_mode=self.pad, in_layout="ndhwc",
-                                   out_layout="ndhwc")
-        aligned = ops.grid_sample3d(warped, theta=theta_drv, padding_mode=self.pad, in_layout="ndhwc",
-                                    out_layout="ncdhw")
+        lay = "cg8" if canonical_cl.dim() == 6 else "ndhwc"
+        warped = ops.grid_sample3d(canonical_cl, delta=delta_uv, padding_mode=self.pad, in_layout=lay, out_layout=lay)
+        aligned = ops.grid_sample3d(warped, theta=theta_drv, padding_mode=self.pad, in_layout=lay, out_layout="ncdhw")
         feat = aligned.view(B, self.c * self.d, self.s, self.s)
         img, deep_f, img_f = self.decoder(feat)
         if keep:

@@ -22,7 +22,8 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
                   variant=0, out=None, delta=None):
     """5-D trilinear grid_sample, align_corners=False  (== F.grid_sample(vol, grid, padding_mode=...)).
 
-    vol    [Nv,C,D,H,W] ('ncdhw') or [Nv,D,H,W,C] ('ndhwc'); Nv == N or 1 (volume shared by all N samples).
+    vol    [Nv,C,D,H,W] ('ncdhw'), [Nv,D,H,W,C] ('ndhwc') or [Nv,8,D,H,W,C/8] ('cg8': 8 channel groups, one per XCD, see
+           include/emo_hip.h EMO_LAYOUT_CG8; out_layout 'cg8' or 'ncdhw'); Nv == N or 1 (volume shared by all N samples).
     grid   [N,Do,Ho,Wo,3]; or None with theta [N,3,4] / [N,4,4]: the sampling grid is then the head-pose affine of
            the identity lattice (notebooks/infer.py:583-588), generated inside the kernel, output size = D,H,W.
     delta  [N,3,Do,Ho,Wo] planar deltas: grid = identity lattice + delta (WarpGenerator output,
@@ -33,10 +34,16 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     if theta is not None:
         theta = theta.float().contiguous()      # e.g. torch.linalg.inv returns a column-major result
         hip.require_cuda_f32(theta)
-    cl_in = in_layout == "ndhwc"
-    cl_out = out_layout == "ndhwc"
-    if cl_in:
+    layouts = {"ncdhw": hip.LAYOUT_NCDHW, "ndhwc": hip.LAYOUT_NDHWC, "cg8": hip.LAYOUT_CG8}
+    if in_layout not in layouts or out_layout not in layouts:
+        raise ValueError("layouts are 'ncdhw', 'ndhwc' or 'cg8'")
+    if in_layout == "ndhwc":
         Nv, D, H, W, C = vol.shape
+    elif in_layout == "cg8":
+        Nv, G8, D, H, W, CG = vol.shape
+        if G8 != 8:
+            raise ValueError("a 'cg8' volume is [N, 8, D, H, W, C/8]")
+        C = 8 * CG
     else:
         Nv, C, D, H, W = vol.shape
     lx = ly = lz = None
@@ -66,7 +73,7 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     if Nv not in (1, N):
         raise ValueError(f"volume batch {Nv} does not match grid batch {N}")
     stride = 0 if (Nv == 1 and N > 1) else C * D * H * W
-    shape = (N, Do, Ho, Wo, C) if cl_out else (N, C, Do, Ho, Wo)
+    shape = {"ndhwc": (N, Do, Ho, Wo, C), "cg8": (N, 8, Do, Ho, Wo, C // 8), "ncdhw": (N, C, Do, Ho, Wo)}[out_layout]
     if out is None:
         out = torch.empty(shape, device=vol.device, dtype=torch.float32)
     else:
@@ -75,7 +82,7 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
             raise ValueError("bad out shape")
     rc = lib.emo_grid_sample3d_f32(hip.ptr(vol), hip.ptr(grid), hip.ptr(theta), hip.ptr(lx), hip.ptr(ly), hip.ptr(lz),
                                    hip.ptr(out), N, C, D, H, W, Do, Ho, Wo, stride, hip.PAD_MODES[padding_mode],
-                                   int(cl_in), int(cl_out), int(variant), grid_kind, hip.current_stream())
+                                   layouts[in_layout], layouts[out_layout], int(variant), grid_kind, hip.current_stream())
     hip.check(rc, "emo_grid_sample3d_f32")
     return out
 
@@ -105,6 +112,28 @@ def volume_to_channels_last(vol):
     N, C, D, H, W = vol.shape
     out = torch.empty((N, D, H, W, C), device=vol.device, dtype=torch.float32)
     hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, C, D * H * W, 1, hip.current_stream()),
+              "emo_volume_repack_f32")
+    return out
+
+
+def volume_to_cg8(vol):
+    """[N,C,D,H,W] -> [N,8,D,H,W,C/8]: 8 channel groups, each a channels-last sub-volume (EMO_LAYOUT_CG8)"""
+    lib = hip.load()
+    hip.require_cuda_f32(vol)
+    N, C, D, H, W = vol.shape
+    out = torch.empty((N, 8, D, H, W, C // 8), device=vol.device, dtype=torch.float32)
+    hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, C, D * H * W, 2, hip.current_stream()),
+              "emo_volume_repack_f32")
+    return out
+
+
+def volume_from_cg8(vol):
+    """[N,8,D,H,W,C/8] -> [N,C,D,H,W]"""
+    lib = hip.load()
+    hip.require_cuda_f32(vol)
+    N, G8, D, H, W, CG = vol.shape
+    out = torch.empty((N, 8 * CG, D, H, W), device=vol.device, dtype=torch.float32)
+    hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, 8 * CG, D * H * W, 3, hip.current_stream()),
               "emo_volume_repack_f32")
     return out
 
@@ -338,6 +367,19 @@ def pack_rgb8(img):
         raise ValueError("expected 3 channels")
     out = torch.empty((N, H, W, 3), device=img.device, dtype=torch.uint8)
     hip.check(lib.emo_pack_rgb8(hip.ptr(img), hip.ptr(out), N, H, W, hip.current_stream()), "emo_pack_rgb8")
+    return out
+
+
+def unpack_rgb8(frames_u8):
+    """[N,H,W,3] uint8 (decoded video frames) -> [N,3,H,W] fp32 in [0,1] = byte / 255 (notebooks/infer.py:211-223)"""
+    lib = hip.load()
+    if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8 or not frames_u8.is_contiguous():
+        raise RuntimeError("unpack_rgb8 expects a contiguous uint8 cuda tensor [N,H,W,3]")
+    N, H, W, C = frames_u8.shape
+    if C != 3:
+        raise ValueError("expected 3 channels")
+    out = torch.empty((N, 3, H, W), device=frames_u8.device, dtype=torch.float32)
+    hip.check(lib.emo_unpack_rgb8(hip.ptr(frames_u8), hip.ptr(out), N, H, W, hip.current_stream()), "emo_unpack_rgb8")
     return out
 
 

@@ -58,9 +58,9 @@ def pack_generic(w):
 
 
 def choose_cfg(cout):
-    """block config minimising padded output channels; ties go to the larger tile"""
+    """block config minimising padded output channels; ties go to the 64-row tile (see _CFG_EFF), then the 128-row one"""
     best = None
-    for cfg in (CFG_A, CFG_B, CFG_C):
+    for cfg in (CFG_B, CFG_A, CFG_C):
         bm = _BM[cfg]
         padded = -(-cout // bm) * bm
         if best is None or padded < best[0]:
@@ -114,9 +114,11 @@ def pack_weight(w, cfg):
     return wp.view(-1)
 
 
-# relative MFMA efficiency of the block configs measured on MI355X (profiles/r1_conv_microbench.jsonl):
-# the 32-row tile re-stages the same input patch for a quarter of the work
-_CFG_EFF = {CFG_A: 1.0, CFG_B: 0.97, CFG_C: 0.88}
+# relative MFMA efficiency of the block configs measured on MI355X at 16 frames (profiles/r2_conv_microbench.jsonl):
+# the 64-row tile (15 KB stage buffers -> 5 blocks per CU) beats the 128-row one (25 KB -> 3 blocks) on the 64^2 .. 256^2
+# layers (133 vs 124 TF on 512->512 @64^2) and ties it at 512^2 (132-135); the 32-row tile re-stages the same input patch
+# for a quarter of the work
+_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88}
 _FILL_BLOCKS = 512   # 2 blocks per CU on 256 CUs
 
 

@@ -193,7 +193,7 @@ class DecoderStage2:
     def __call__(self, feat_2d):
         # GroupNorm variant: the tile statistics of every conv output travel with the tensor (nets.ResBlock); the BatchNorm
         # default has static affines and asks for none
-        x, st = ops.conv_igemm(feat_2d, self.first, want_stats=not self.nh.bn)
+        x, st = (ops.conv_igemm(feat_2d, self.first), None) if self.nh.bn else ops.conv_igemm(feat_2d, self.first, want_stats=True)
         for b in self.trunk:
             x, st = b(x, x_stats=st, want_stats=True)
         for b in self.up:

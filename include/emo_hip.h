@@ -40,6 +40,9 @@ extern "C" {
 /* memory layout of a 5-D volume */
 #define EMO_LAYOUT_NCDHW 0         /* the reference's layout                                    */
 #define EMO_LAYOUT_NDHWC 1         /* channels-last, internal fast path (gathers read C contiguous floats) */
+#define EMO_LAYOUT_CG8 2           /* [N][8][D][H][W][C/8]: 8 channel groups, each a channels-last sub-volume; the sampler
+                                      runs group g on XCD g so that a group's sub-volume (3.1 MB for the released 96 x 16 x 64 x 64
+                                      canonical volume) stays resident in that XCD's private 4 MiB L2.  Needs C % 32 == 0.  */
 
 /* activation applied in a kernel epilogue */
 #define EMO_ACT_NONE 0
@@ -72,7 +75,7 @@ const char* emo_build_info(void);
  *   variant    0 = default kernels; other values select alternative tunings (kept for A/B measurements).
  *   out   [N, C, Do, Ho, Wo] or [N, Do, Ho, Wo, C] according to out_layout.
  *   vol_batch_stride  elements between consecutive volumes (0 = shared volume).
- * NDHWC paths require C % 4 == 0.
+ * NDHWC paths require C % 4 == 0.  in_layout EMO_LAYOUT_CG8 (C % 32 == 0) supports out_layout CG8 and NCDHW.
  */
 int emo_grid_sample3d_f32(const float* vol, const float* grid, const float* theta,
                           const float* lin_x, const float* lin_y, const float* lin_z,
@@ -88,8 +91,8 @@ int emo_grid_sample3d_f32(const float* vol, const float* grid, const float* thet
 int emo_affine_grid3d_f32(const float* theta, const float* lin_x, const float* lin_y, const float* lin_z,
                           float* grid, int N, int Do, int Ho, int Wo, void* stream);
 
-/* NCDHW <-> NDHWC repack of a 5-D volume (used once per identity on the cached canonical volume,
- * notebooks/infer.py:507 `self.target_latent_volume`).  to_channels_last != 0: NCDHW -> NDHWC. */
+/* Layout repack of a 5-D volume (used once per identity on the cached canonical volume, notebooks/infer.py:507
+ * `self.target_latent_volume`).  to_channels_last: 0 NDHWC -> NCDHW, 1 NCDHW -> NDHWC, 2 NCDHW -> CG8, 3 CG8 -> NCDHW. */
 int emo_volume_repack_f32(const float* in, float* out, int N, int C, int DHW, int to_channels_last, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -230,6 +233,8 @@ int emo_stage2_compose_f32(const float* img, const float* add, const float* mask
  *       T [B, R, E], V [n_norms, E, 2], norm_of_row [R] int32, gamma/beta [R] -> ada_gamma/ada_beta [B, R].
  *   emo_pose_theta_f32: utils/point_transforms.py:188-242 get_transform_matrix -> theta [B,4,4]; scale [B,scale_cols].
  *   emo_pack_rgb8: notebooks/infer.py:641-644 clamp(0,1) + ToPILImage: [N,3,H,W] fp32 -> [N,H,W,3] uint8.
+ *   emo_unpack_rgb8: notebooks/infer.py:211-223 convert_to_tensor (ToTensor) of decoded video frames:
+ *       [N,H,W,3] uint8 -> [N,3,H,W] fp32 = byte / 255, on the device (frames are uploaded as bytes: 4x less PCIe).
  */
 int emo_small_gemm_f32(const float* A, const float* B, float* C, int M, int K, int NN, int batch,
                        int64_t b_stride, int64_t c_stride, void* stream);
@@ -240,6 +245,7 @@ int emo_pose_theta_f32(const float* scale, int scale_cols, const float* rotation
 /* inverse of B row-major 4x4 matrices (`theta.float().inverse()`: notebooks/infer.py:443, expression_embedder.py:185-188) */
 int emo_mat4_inverse_f32(const float* in, float* out, int B, void* stream);
 int emo_pack_rgb8(const float* img, uint8_t* out, int N, int H, int W, void* stream);
+int emo_unpack_rgb8(const uint8_t* in, float* out, int N, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

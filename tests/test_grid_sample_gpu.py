@@ -46,6 +46,15 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
         ocl1 = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=1)
         res["cl_v1"] = ocl1.cpu().permute(0, 4, 1, 2, 3).contiguous()
         res["cl2ncdhw_v1"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw", variant=1).cpu()
+    if vol.shape[1] % 32 == 0:
+        # channel-group-per-XCD layout [N, 8, D, H, W, C/8]
+        vcg = ops.volume_to_cg8(vol)
+        N_, C_, D_, H_, W_ = vol_cpu.shape
+        assert torch.equal(vcg.cpu(), vol_cpu.view(N_, 8, C_ // 8, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
+        assert torch.equal(ops.volume_from_cg8(vcg).cpu(), vol_cpu)
+        ocg = ops.grid_sample3d(vcg, grid, theta, pm, in_layout="cg8", out_layout="cg8")
+        res["cg8"] = ops.volume_from_cg8(ocg).cpu()
+        res["cg8_to_ncdhw"] = ops.grid_sample3d(vcg, grid, theta, pm, in_layout="cg8", out_layout="ncdhw").cpu()
     return res
 
 
@@ -175,6 +184,39 @@ def test_delta_grid_mode_equals_materialised_warp(pm):
     assert torch.equal(ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw").cpu(), ref)
     o = ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ndhwc")
     assert torch.equal(o.cpu().permute(0, 4, 1, 2, 3), ref)
+
+
+@pytest.mark.parametrize("pm", PADS)
+def test_channel_group_layout_driver_pair_bit_exact(pm):
+    """the two sampler calls of the driver pass in the channel-group-per-XCD layout (EMO_LAYOUT_CG8): shared canonical
+    volume + planar deltas -> CG8 intermediate -> analytic theta -> NCDHW, against torch CPU on the materialised grids;
+    N = 5 samples (not a multiple of 8), ragged last block (Do*Ho*Wo not a multiple of 256), 32 and 96 channels"""
+    for C, D, S, N in ((32, 3, 10, 5), (96, 16, 64, 2)):
+        g = torch.Generator().manual_seed(C)
+        vol = torch.randn(1, C, D, S, S, generator=g)
+        delta = torch.tanh(torch.randn(N, 3, D, S, S, generator=g)) * 0.1
+        theta = O.get_transform_matrix(1 + 0.05 * torch.randn(N, 3, generator=g), 0.3 * torch.randn(N, 3, generator=g),
+                                       0.05 * torch.randn(N, 3, generator=g))
+        ident = O.identity_grid_3d(D, S)[..., :3].view(1, D, S, S, 3).permute(0, 4, 1, 2, 3)
+        warp = (ident + delta).permute(0, 2, 3, 4, 1)
+        ref1 = F.grid_sample(vol.expand(N, -1, -1, -1, -1), warp, padding_mode=pm, align_corners=False)
+        vcg = ops.volume_to_cg8(vol.to(DEV))
+        w = ops.grid_sample3d(vcg, delta=delta.to(DEV), padding_mode=pm, in_layout="cg8", out_layout="cg8")
+        assert w.shape == (N, 8, D, S, S, C // 8)
+        assert torch.equal(ops.volume_from_cg8(w).cpu(), ref1)
+        # second call on the per-sample intermediate: same coordinates as the channels-last kernel => identical output
+        a = ops.grid_sample3d(w, theta=theta.to(DEV), padding_mode=pm, in_layout="cg8", out_layout="ncdhw")
+        wcl = ops.volume_to_channels_last(ops.volume_from_cg8(w))
+        b = ops.grid_sample3d(wcl, theta=theta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw")
+        assert torch.equal(a, b)
+        grid2 = ops.affine_grid3d(theta.to(DEV), (D, S, S)).cpu()
+        assert torch.equal(a.cpu(), F.grid_sample(ref1, grid2, padding_mode=pm, align_corners=False))
+
+
+def test_channel_group_layout_needs_whole_quads_per_group():
+    vol = torch.randn(1, 8, 2, 2, 2, 3, device=DEV)          # C = 24: not a multiple of 32
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        ops.grid_sample3d(vol, torch.zeros(1, 2, 2, 2, 3, device=DEV), in_layout="cg8", out_layout="cg8")
 
 
 def test_empty_batch_is_rejected():

@@ -107,13 +107,14 @@ def test_pack_weight_layout(cfg_id, shape):
 
 
 def test_launch_config_heuristic():
-    assert pack.choose_cfg(512) == pack.CFG_A and pack.choose_cfg(320) == pack.CFG_B and pack.choose_cfg(3) == pack.CFG_C
+    assert pack.choose_cfg(512) == pack.CFG_B and pack.choose_cfg(320) == pack.CFG_B and pack.choose_cfg(3) == pack.CFG_C
     # few position tiles: prefer more (smaller) blocks; many: least padding wins
     assert pack.choose_cfg_for_launch(256, 16) == pack.CFG_C
     assert pack.choose_cfg_for_launch(320, 4096) == pack.CFG_B
-    assert pack.choose_cfg_for_launch(128, 32768) == pack.CFG_A
-    # K split: big launches stay single-pass; a 64x64 map at batch 1 (32 position tiles) keeps the large tile and splits
-    assert pack.plan_launch(128, 128, 1, 3, 3, 32768) == (pack.CFG_A, 1)
+    # equal padding: the 64-row tile (5 blocks per CU) is preferred to the 128-row one (3 per CU), measured faster or equal
+    assert pack.choose_cfg_for_launch(128, 32768) == pack.CFG_B
+    # K split: big launches stay single-pass; a 64x64 map at batch 1 (32 position tiles) splits
+    assert pack.plan_launch(128, 128, 1, 3, 3, 32768) == (pack.CFG_B, 1)
     cfg, ks = pack.plan_launch(512, 512, 1, 3, 3, 32)
     assert ks > 1 and (-(-512 // pack._BM[cfg])) * 32 * ks >= 512
     assert pack.plan_launch(256, 512, 3, 3, 3, 4)[1] > 1                 # 8^3 WarpGenerator layer, batch 1

@@ -252,3 +252,89 @@ def test_crop_true_and_mix_true_paths(project, tiny):
     full = torch.cat([mixed, torch.tensor([[[0.0, 0, 0, 1]]]).expand(2, -1, -1)], dim=1)
     _, explicit_img = w.forward(custome_target_theta_embed=full, **drv_kw)
     assert torch.equal(mixed_img, explicit_img)
+
+
+def _toy_embedders(tiny, device):
+    """stand-ins for the driver-side networks (the tiny fixture has no embedder weights): deterministic functions of the
+    crop, with the call signatures the wrapper uses for user-supplied callables"""
+    from emoportraits_amd import ops
+    E = tiny["cfg"]["lpe_output_channels_expression"]
+    g = torch.Generator().manual_seed(9)
+    proj = (torch.randn(3 * 16, E, generator=g) * 0.5).to(device)
+
+    def head_pose(crop, return_srt=False):
+        m = crop.mean(dim=(2, 3))                                             # [B,3]
+        scale, rot, trans = 1 + 0.1 * (m - 0.5), 0.6 * (m - 0.5), 0.1 * (m.flip(1) - 0.5)
+        theta = ops.pose_theta(scale.contiguous(), rot.contiguous(), trans.contiguous())
+        return (theta, scale, rot, trans) if return_srt else theta
+
+    def expression(crop, theta):
+        small = torch.nn.functional.adaptive_avg_pool2d(crop, 4).reshape(crop.shape[0], -1)
+        return small @ proj, crop[:, :, ::2, ::2].contiguous()                # (pose embedding, "aligned" crop)
+
+    return {"head_pose_regressor": head_pose, "expression_embedder": expression}
+
+
+def test_animate_frames_is_device_resident_and_equals_forward(project, tiny):
+    import numpy as np
+    w = _wrapper(project)
+    w.embedders.update(_toy_embedders(tiny, w.device))
+    S = tiny["cfg"]["image_size"]
+    w.forward(source_image=tiny["img"], crop=False, source_mask=torch.ones(1, 1, S, S),
+              custome_idt_embed=tiny["idt_embed"], custome_source_pose_embed=tiny["source_pose_embed"],
+              custome_source_theta_embed=tiny["theta_src"])
+    g = torch.Generator().manual_seed(3)
+    N = 8
+    frames = (torch.rand(N, S, S, 3, generator=g) * 255).to(torch.uint8)
+    got = {}
+    order = []
+    for b0, u8 in w.animate_frames(frames.pin_memory(), batch_size=3, ring=2):
+        assert not u8.is_cuda and u8.dtype == torch.uint8 and u8.shape[1:] == (S, S, 3)
+        order.append((b0, u8.shape[0]))
+        for j in range(u8.shape[0]):
+            got[b0 + j] = u8[j].clone()
+    assert order == [(0, 3), (3, 3), (6, 2)]
+    # the reference's per-call path on the same frames (float tensors in [0,1] = byte / 255)
+    imgs, _ = w.forward(driver_image=frames.permute(0, 3, 1, 2).float() / 255.0, crop=False)
+    assert w.target_img_align is not None and w.target_img_align.shape == (N, 3, S // 2, S // 2)    # infer.py:608
+    for i in range(N):
+        assert np.abs(np.asarray(imgs[i]).astype(int) - got[i].numpy().astype(int)).max() <= 1
+    # crop windows are read in place from larger frames and resized on the device
+    big = (torch.rand(2, 96, 128, 3, generator=g) * 255).to(torch.uint8)
+    wins = [(10, 5, 80), (40, 16, 64)]
+    dev_out = [u8 for _, u8 in w.animate_frames(big, batch_size=2, windows=wins, to_host=False)]
+    assert dev_out[0].is_cuda and dev_out[0].shape == (2, S, S, 3)
+    x = big.permute(0, 3, 1, 2).float() / 255.0
+    crops = torch.cat([torch.nn.functional.interpolate(x[i:i + 1, :, y:y + s, xx:xx + s], size=(S, S), mode="bicubic").clamp(0, 1)
+                       for i, (xx, y, s) in enumerate(wins)])
+    imgs, _ = w.forward(driver_image=crops, crop=False)
+    for i in range(2):
+        assert np.abs(np.asarray(imgs[i]).astype(int) - dev_out[0][i].cpu().numpy().astype(int)).max() <= 2
+
+
+def test_source_mask_semantics_follow_reference(project, tiny):
+    """notebooks/infer.py:408-420: the face-parsing mask (> 0.6) always multiplies the crop; source_mask only replaces
+    source_img_mask"""
+    w = _wrapper(project)
+    S = tiny["cfg"]["image_size"]
+    g = torch.Generator().manual_seed(4)
+    soft = torch.rand(1, 1, S, S, generator=g)
+    w.embedders["face_parsing"] = lambda crop: soft.to(crop.device)
+    matte = torch.rand(1, 1, S, S, generator=g)
+    w.forward(source_image=tiny["img"], crop=False, source_mask=matte, custome_idt_embed=tiny["idt_embed"],
+              custome_source_pose_embed=tiny["source_pose_embed"], custome_source_theta_embed=tiny["theta_src"])
+    hard = (soft > 0.6).float()
+    assert torch.equal(w.source_img_crop_m.cpu(), tiny["img"] * hard)
+    assert torch.equal(w.source_img_mask.cpu(), matte)
+    d, s = tiny["cfg"]["latent_volume_depth"], tiny["cfg"]["latent_volume_size"]
+    assert w.source_rotation_warp.shape == (1, d, s, s, 3)                  # the cached rotation warp is a grid (infer.py:441-444)
+
+
+def test_driver_call_without_a_frame_needs_the_theta_hook(project, tiny):
+    w = _wrapper(project)
+    S = tiny["cfg"]["image_size"]
+    w.forward(source_image=tiny["img"], crop=False, source_mask=torch.ones(1, 1, S, S),
+              custome_idt_embed=tiny["idt_embed"], custome_source_pose_embed=tiny["source_pose_embed"],
+              custome_source_theta_embed=tiny["theta_src"])
+    with pytest.raises(RuntimeError, match="custome_target_theta_embed"):
+        w.forward(driver_image=None, crop=False, custome_target_pose_embed=tiny["target_pose_embed"][:1])

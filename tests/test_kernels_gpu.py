@@ -268,7 +268,7 @@ def test_conv_epilogue_groupnorm_statistics(case):
     gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
     layer = pack.PackedConv("test", w, b, DEV, cfg=cfg)
     r = torch.randn(N, Cout, *dims, generator=g).to(DEV) if res else None
-    out, st = ops.conv_igemm(x.to(DEV), layer, res=r, want_stats=True)
+    out, st = ops.conv_igemm(x.to(DEV), layer, res=r, want_stats=True, ksplit=1)   # (small test launches would be K-split)
     assert st is not None and st.stats.shape == (N, out[0, 0].numel() // 128, Cout, 2)
     s1, h1 = ops.groupnorm_affine(out, gamma.to(DEV), beta.to(DEV), stats=st)
     s0, h0 = ops.groupnorm_affine(out, gamma.to(DEV), beta.to(DEV))
@@ -280,7 +280,7 @@ def test_conv_epilogue_groupnorm_statistics(case):
     assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item()
     assert (h1 - h0).abs().max().item() <= 2e-6 * max(h0.abs().max().item(), 1.0)
     # the conv output itself is unchanged by asking for statistics
-    assert torch.equal(out, ops.conv_igemm(x.to(DEV), layer, res=r))
+    assert torch.equal(out, ops.conv_igemm(x.to(DEV), layer, res=r, ksplit=1))
 
 
 def test_conv_epilogue_groupnorm_statistics_large_mean_is_stable():
@@ -291,7 +291,7 @@ def test_conv_epilogue_groupnorm_statistics_large_mean_is_stable():
     w = torch.randn(32, 16, 3, 3, generator=g) * (0.01 / 12.0)
     b = torch.full((32,), 1000.0)
     layer = pack.PackedConv("test", w, b, DEV, cfg=2)
-    out, st = ops.conv_igemm(x.to(DEV), layer, want_stats=True)
+    out, st = ops.conv_igemm(x.to(DEV), layer, want_stats=True, ksplit=1)
     s, h = ops.groupnorm_affine(out, stats=st)
     o = out.cpu()
     got = o * s.cpu().view(1, 32, 1, 1) + h.cpu().view(1, 32, 1, 1)

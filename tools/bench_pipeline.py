@@ -53,8 +53,27 @@ def main():
             for _ in range(iters):
                 imgs, _ = w.forward(driver_image=drv, crop=False)      # includes uint8 packing + D2H + PIL objects
             dt = (time.perf_counter() - t0) / iters
-            print(json.dumps(dict(S=S, B=B, graphs=use_graphs, ms_per_call=round(dt * 1e3, 3), fps=round(B / dt, 2),
-                                  first_source_call_ms=round(src_ms, 1))), flush=True)
+            print(json.dumps(dict(path="forward() per call (PIL out)", S=S, B=B, graphs=use_graphs, ms_per_call=round(dt * 1e3, 3),
+                                  fps=round(B / dt, 2), first_source_call_ms=round(src_ms, 1))), flush=True)
+            # device-resident frames path (InferenceWrapper.animate_frames): uint8 frames in pinned host memory -> uint8
+            # frames in pinned host memory, no .cpu() / host sync inside the loop (D2H ring)
+            n_frames = B * 12
+            frames = (torch.rand(n_frames, S, S, 3, generator=g) * 255).to(torch.uint8).pin_memory()
+            for _ in w.animate_frames(frames[:B * 3], batch_size=B):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = 0
+            lat = []
+            for first, out in w.animate_frames(frames, batch_size=B):
+                got += out.shape[0]
+                lat.append(time.perf_counter())
+            dt = time.perf_counter() - t0
+            assert got == n_frames
+            gaps = sorted(b - a for a, b in zip(lat[2:], lat[3:]))
+            print(json.dumps(dict(path="animate_frames (uint8 in -> uint8 out, pinned D2H ring)", S=S, B=B, graphs=use_graphs,
+                                  fps=round(n_frames / dt, 2), ms_per_batch=round(dt / (n_frames / B) * 1e3, 3),
+                                  median_gap_ms=round(gaps[len(gaps) // 2] * 1e3, 3) if gaps else None)), flush=True)
 
 
 if __name__ == "__main__":
