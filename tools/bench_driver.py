@@ -42,14 +42,15 @@ def main():
         theta = ops.pose_theta(*srt)
         emb = hp.embed(pose, idt)
         delta = hp.uv_generator(emb)
-        warped = ops.grid_sample3d(ccl, delta=delta, in_layout="ndhwc", out_layout="ndhwc")
-        aligned = ops.grid_sample3d(warped, theta=theta, in_layout="ndhwc", out_layout="ncdhw")
+        lay = "cg8" if ccl.dim() == 6 else "ndhwc"
+        warped = ops.grid_sample3d(ccl, delta=delta, in_layout=lay, out_layout=lay)
+        aligned = ops.grid_sample3d(warped, theta=theta, in_layout=lay, out_layout="ncdhw")
         feat = aligned.view(B, 96 * 16, 64, 64)
         rec = dict(S=S, B=B, conv_operands=precision)
         rec["embed_ms"] = timeit(lambda: hp.embed(pose, idt))
         rec["warpgen_ms"] = timeit(lambda: hp.uv_generator(emb))
-        rec["sampler_uv_ms"] = timeit(lambda: ops.grid_sample3d(ccl, delta=delta, in_layout="ndhwc", out_layout="ndhwc"))
-        rec["sampler_rot_ms"] = timeit(lambda: ops.grid_sample3d(warped, theta=theta, in_layout="ndhwc", out_layout="ncdhw"))
+        rec["sampler_uv_ms"] = timeit(lambda: ops.grid_sample3d(ccl, delta=delta, in_layout=lay, out_layout=lay))
+        rec["sampler_rot_ms"] = timeit(lambda: ops.grid_sample3d(warped, theta=theta, in_layout=lay, out_layout="ncdhw"))
         rec["decoder_ms"] = timeit(lambda: hp.decoder(feat))
         rec["total_ms"] = timeit(lambda: hp.driver_pass(ccl, idt, pose, theta))
         rec["fps"] = B / rec["total_ms"] * 1e3
