@@ -105,7 +105,9 @@ struct ConvCfg {
   // blocks per CU that LDS admits, capped: the register allocator must fit that many waves per SIMD (1 wave per block
   // and SIMD) -- without a floor it spends up to 256 VGPRs on epilogue ILP and silently halves the occupancy
   static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
-  static constexpr int OCC = BY_LDS < 2 ? 2 : (BY_LDS > EMO_CONV_MAX_WAVES ? EMO_CONV_MAX_WAVES : BY_LDS);
+  static constexpr int CAP = TM * TP >= 4 ? (EMO_CONV_MAX_WAVES < 4 ? EMO_CONV_MAX_WAVES : 4)   // 64 accumulator registers: 4 waves
+                                          : EMO_CONV_MAX_WAVES;                                   // per SIMD = 128 VGPRs at most
+  static constexpr int OCC = BY_LDS < 2 ? 2 : (BY_LDS > CAP ? CAP : BY_LDS);
 };
 
 __device__ __forceinline__ float emo_act(float v, int act) {

@@ -720,6 +720,9 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
       return dispatch_cl_v2<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
                                        vol_bstride, false, variant, s);
     }
+  } else if (in_layout == EMO_LAYOUT_CG8) {
+    return launch_cg8<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                 out_layout, s);
   } else {
     return EMO_ERR_UNSUPPORTED;
   }

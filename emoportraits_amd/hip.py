@@ -30,6 +30,7 @@ SIGNATURES = {
     "emo_groupnorm_affine_from_tiles_f32": [_c_void, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_float] + [_c_void] * 4
                                            + [_c_i64] + [_c_void] * 5,
     "emo_conv_pack_info": [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
+    "emo_conv_tile_positions": [_c_int],
     "emo_conv_igemm_f32": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void],
     "emo_conv_igemm_ksplit": [_c_int] * 11,
     "emo_conv_pack_info_f16": [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],

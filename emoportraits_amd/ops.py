@@ -9,6 +9,7 @@ import functools
 import torch
 
 from . import hip
+from . import pack as pack_mod
 
 
 @functools.lru_cache(maxsize=None)
@@ -251,7 +252,7 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
             raise ValueError("bad residual shape")
     positions = N * D * Hl * Wl
-    cfg, ks = layer.plan_for(max(1, -(-positions // 128)))
+    cfg, ks = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl)
     if ksplit is not None:
         ks = int(ksplit)
     ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None
@@ -262,8 +263,9 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
                                          layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
                                          hip.ptr(ws), hip.current_stream())
     else:
-        if want_stats and ks == 1 and (D * Hl * Wl) % 128 == 0:
-            stats = TileStats(torch.empty((N, D * Hl * Wl // 128, layer.cout, 2), device=x.device, dtype=torch.float32), 128)
+        bp = pack_mod._BP[cfg]
+        if want_stats and ks == 1 and (D * Hl * Wl) % bp == 0:
+            stats = TileStats(torch.empty((N, D * Hl * Wl // bp, layer.cout, 2), device=x.device, dtype=torch.float32), bp)
         rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
                                     hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
                                     layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,

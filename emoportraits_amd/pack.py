@@ -14,8 +14,10 @@ import torch
 
 from . import hip
 
-CFG_A, CFG_B, CFG_C = 0, 1, 2
-_BM = {CFG_A: 128, CFG_B: 64, CFG_C: 32}
+CFG_A, CFG_B, CFG_C, CFG_D = 0, 1, 2, 3
+_BM = {CFG_A: 128, CFG_B: 64, CFG_C: 32, CFG_D: 64}        # output channels per block
+_BP = {CFG_A: 128, CFG_B: 128, CFG_C: 128, CFG_D: 256}     # output positions per block (emo_conv_tile_positions)
+_PACK_AS = {CFG_D: CFG_B}                                   # configs that share another config's weight layout
 
 
 def fold_sn(weight_orig, u, v):
@@ -118,8 +120,17 @@ def pack_weight(w, cfg):
 # the 64-row tile (15 KB stage buffers -> 5 blocks per CU) beats the 128-row one (25 KB -> 3 blocks) on the 64^2 .. 256^2
 # layers (133 vs 124 TF on 512->512 @64^2) and ties it at 512^2 (132-135); the 32-row tile re-stages the same input patch
 # for a quarter of the work
-_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88}
+_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 0.0}   # D (64 x 256): opt-in via EMO_CONV_CFG_D / pinned cfg only
+if __import__("os").environ.get("EMO_CONV_CFG_D") == "1":   # A/B switch for the 64 x 256 tile
+    _CFG_EFF[CFG_D] = 1.02
 _FILL_BLOCKS = 512   # 2 blocks per CU on 256 CUs
+
+
+def cfg_d_fits(kd, kh, kw, Hl, Wl, precision="f32"):
+    """the 64 x 256 tile exists for 2-D 3x3 fp32 layers whose output is tiled by 2x128 / 4x64 / 8x32 positions"""
+    if precision != "f32" or kd != 1 or (kh, kw) != (3, 3) or Hl is None:
+        return False
+    return (Wl % 128 == 0 and Hl % 2 == 0) or (Wl == 64 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0)
 
 
 def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
@@ -161,7 +172,7 @@ def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C
         nstages = -(-cin // _kc(kh, kw, cfg, precision)) * kd
         bm = _BM[cfg]
         cot = -(-cout // bm)
-        blocks = cot * n_pos_tiles
+        blocks = cot * max(1, n_pos_tiles * 128 // _BP[cfg])
         ks = ksplit_for(blocks, nstages)
         score = min(blocks * ks, _FILL_BLOCKS) / _FILL_BLOCKS * (cout / (cot * bm)) * _CFG_EFF[cfg] * (0.97 if ks > 1 else 1.0)
         if best is None or score > best[0] + 1e-9:
@@ -221,6 +232,7 @@ class PackedConv:
         self.packed(first if first in self.allowed else CFG_B)
 
     def packed(self, cfg):
+        cfg = _PACK_AS.get(cfg, cfg)
         if cfg not in self._packed:
             fn = pack_weight_f16 if self.precision == "f16" else pack_weight
             self._packed[cfg] = fn(self._weight, cfg).to(self.device)
@@ -231,9 +243,11 @@ class PackedConv:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
-    def plan_for(self, n_pos_tiles):
-        """(cfg, ksplit) for a launch over n_pos_tiles 128-position tiles"""
+    def plan_for(self, n_pos_tiles, Hl=None, Wl=None):
+        """(cfg, ksplit) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output"""
         allowed = (self.pinned_cfg,) if self.pinned_cfg is not None else self.allowed
+        if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl, self.precision):
+            allowed = allowed + (CFG_D,)
         return plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, allowed, self.precision)
 
     @classmethod

@@ -114,7 +114,7 @@ int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S, int G, flo
                              void* workspace, int64_t workspace_bytes, void* stream);
 /* The same affine from the per-tile statistics emo_conv_igemm_f32 leaves in `gn_stats` (no pass over the activation):
  *   stats [N][T][C][2] = (mean, centred sum of squares) of `cnt` values each, T tiles per sample and channel
- *   (emo_conv_igemm_f32: T = D*Hl*Wl / 128, cnt = 128).  Combined per (sample, group) in fp64 with the equal-count
+ *   (emo_conv_igemm_f32: cnt = emo_conv_tile_positions(cfg), T = D*Hl*Wl / cnt).  Combined per (sample, group) in fp64 with the equal-count
  *   pairwise update (Chan et al.): no E[x^2] - mean^2 cancellation.  Other arguments as emo_groupnorm_affine_f32. */
 int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_t T, int cnt, int G, float eps,
                                         const float* gamma, const float* beta,
@@ -138,19 +138,21 @@ int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_
  *   res   residual added before `act` (ResBlock skip, utils.py:783); same shape as out, or the pre-upsample
  *         shape when res_ups != 0.  May alias `out`.
  *   act   EMO_ACT_* applied last (tanh head warp_generator_resnet.py:99-107; sigmoid head decoder.py:347-358).
- *   cfg   0: 128 output channels x 128 positions per block, 1: 64 x 128, 2: 32 x 128.
+ *   cfg   0: 128 output channels x 128 positions per block, 1: 64 x 128, 2: 32 x 128, 3: 64 x 256 (2-D 3x3 layers only;
+ *         weights packed as for cfg 1).  emo_conv_tile_positions(cfg) = positions per block.
  *   ksplit / workspace   ksplit > 1 divides the K loop (input-channel chunks x depth taps) of every output tile over
  *         ksplit blocks -- small launches (64x64 maps at batch 1, the 8^3 / 16^3 WarpGenerator layers) otherwise leave most
  *         of the 256 CUs idle; partial sums go to workspace [ksplit][N*Cout*D*Hl*Wl] floats and a second kernel adds them
  *         in fixed order and applies bias / residual / activation (deterministic; `out` may alias `res`).  ksplit = 1,
  *         workspace = NULL: single pass.  emo_conv_igemm_ksplit returns the split count the launch heuristic wants.
- *   gn_stats   NULL, or [N][D*Hl*Wl/128][Cout][2] floats (ksplit == 1 only): the epilogue also reduces, per sample,
- *         128-position tile and output channel, the mean and the centred sum of squares of the FINAL output values
+ *   gn_stats   NULL, or [N][D*Hl*Wl/P][Cout][2] floats, P = emo_conv_tile_positions(cfg) (ksplit == 1 only): the epilogue
+ *         also reduces, per sample, P-position tile and output channel, the mean and the centred sum of squares of the FINAL output values
  *         (after bias / residual / act) -- the statistics of the GroupNorm that follows in the next block
  *         (utils.py:711-731), consumed by emo_groupnorm_affine_from_tiles_f32 instead of a pass over `out`.
  * Supported output widths: multiples of 128, or 64 / 32 / 16 / 8 (with H resp. D divisible by the tile).
  */
 int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC);
+int emo_conv_tile_positions(int cfg);
 int emo_conv_igemm_f32(const float* x, const float* wpk, const float* bias,
                        const float* scale, const float* shift, const float* res, float* out,
                        int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,

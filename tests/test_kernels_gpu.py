@@ -77,6 +77,35 @@ def test_conv2d_3x3_all_tile_shapes(cfg, hw):
     assert e < 2e-5, e
 
 
+@pytest.mark.parametrize("hw", [32, 64, 128, 256])
+@pytest.mark.parametrize("mode", ["plain", "ups", "full"])
+def test_conv2d_3x3_config_D_64x256_tiles(hw, mode):
+    """block config 3: 64 output channels x 256 positions (2x128 / 4x64 / 8x32 position tiles)"""
+    if mode == "plain":
+        e, got, ref = run_conv(2, 12, 72, (hw, hw), 3, 3, seed=hw)
+    elif mode == "ups":
+        e, got, ref = run_conv(2, 12, 72, (hw // 2, hw // 2), 3, 3, ups=True, affine=True, relu_in=True, seed=hw + 1)
+    else:
+        e, got, ref = run_conv(1, 24, 130, (hw, hw), 3, 3, affine=True, relu_in=True, res=True, act="tanh", seed=hw + 2)
+    assert got.shape == ref.shape and e < 2e-5, e
+
+
+def test_conv_config_D_tile_statistics_and_unsupported_shapes():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 64, 64, generator=g)
+    w = torch.randn(64, 16, 3, 3, generator=g) / 12
+    layer = pack.PackedConv("d", w, None, DEV, cfg=3)
+    out, st = ops.conv_igemm(x.to(DEV), layer, want_stats=True, ksplit=1)
+    assert st.cnt == 256 and st.stats.shape == (2, 64 * 64 // 256, 64, 2)
+    s1, h1 = ops.groupnorm_affine(out, stats=st)
+    s0, h0 = ops.groupnorm_affine(out)
+    assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item() and (h1 - h0).abs().max().item() <= 2e-6
+    ref = F.conv2d(x, w, padding=1)
+    assert rel_err(out, ref) < 2e-5
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):       # 3-D layers have no 64 x 256 tile
+        ops.conv_igemm(torch.randn(1, 16, 8, 32, 32, device=DEV), pack.PackedConv("d3", torch.randn(64, 16, 3, 3, 3), None, DEV, cfg=3))
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2])
 @pytest.mark.parametrize("hw", [16, 64, 128])
 def test_conv2d_1x1(cfg, hw):
