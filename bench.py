@@ -75,7 +75,8 @@ class ConvMeter:
 
 
 class SamplerMeter:
-    def __init__(self):
+    def __init__(self, frames_per_step=None):
+        self.frames_per_step = frames_per_step
         self.events = []
         self.bytes = 0.0
         self._orig = None
@@ -92,7 +93,11 @@ class SamplerMeter:
             meter.events.append((e0, e1))
             delta = kw.get("delta")
             grid_bytes = (grid.numel() if grid is not None else 0) * 4 + (delta.numel() if delta is not None else 0) * 4
-            meter.bytes += vol.numel() * 4 + grid_bytes + out.numel() * 4   # shared volume counted once per launch
+            # a volume shared by the batch is read once per STEP (amortised over the samples that share it),
+            # however many launches the step's frames are split into
+            shared = vol.shape[0] == 1 and out.shape[0] > 1
+            vol_bytes = vol.numel() * 4 * (out.shape[0] / meter.frames_per_step if shared and meter.frames_per_step else 1.0)
+            meter.bytes += vol_bytes + grid_bytes + out.numel() * 4
             return out
 
         ops.grid_sample3d = wrapped
@@ -298,7 +303,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    conv_meter, samp_meter = ConvMeter(), SamplerMeter()
+    conv_meter, samp_meter = ConvMeter(), SamplerMeter(frames_per_step=B)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

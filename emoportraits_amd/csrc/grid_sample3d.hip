@@ -352,13 +352,23 @@ __device__ __forceinline__ void block_to_work(int b, int total, int bps, int nsl
   }
 }
 
-template <int PAD, int MODE, int VPB>
+// voxel i (0..63) of 4x4x4 brick `blk` of a Do x Ho x Wo output lattice (all three multiples of 4): bricks x-fastest
+__device__ __forceinline__ int brick_voxel(int blk, int i, int Ho, int Wo) {
+  const int bw = Wo >> 2, bh = Ho >> 2;
+  const int bx = blk % bw;
+  const int t = blk / bw;
+  const int by = t % bh, bz = t / bh;
+  return (((bz << 2) + (i >> 4)) * Ho + (by << 2) + ((i >> 2) & 3)) * Wo + (bx << 2) + (i & 3);
+}
+
+// BRICK: the block's voxels are a 4x4x4 brick (vox0 = brick index) instead of VPB consecutive voxels
+template <int PAD, int MODE, int VPB, bool BRICK = false>
 __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const float* __restrict__ grid,
                                            const float* __restrict__ theta, const float* __restrict__ lin_x,
                                            const float* __restrict__ lin_y, const float* __restrict__ lin_z, int n,
                                            int vox0, int nvox, int D, int H, int W, int Ho, int Wo) {
   for (int i = threadIdx.x; i < VPB; i += 256) {
-    const int vox = vox0 + i;
+    const int vox = BRICK ? brick_voxel(vox0, i, Ho, Wo) : vox0 + i;
     Taps t;
     if (vox < nvox) {
       float gx, gy, gz;
@@ -431,6 +441,35 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
     const int q = item - v * LPV;
     const TapRec r = recs[v];
     obase[item] = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
+  }
+}
+
+// NDHWC -> NDHWC with 4x4x4 output bricks per block: the 8 corners of a brick's 64 voxels fall into ~5x5x5 source voxels
+// (48 KB at C = 96) instead of the 2x2x65 of an x-row (100 KB): half the L1 fills per output voxel.  The samplers are
+// bound by the per-CU L1 path (64-byte granules per clock + outstanding-miss capacity), not by L2 or HBM
+// (profiles/r2_pmc_sampler_*.json), so fewer fills per voxel is the lever.  Needs Do, Ho, Wo multiples of 4.
+template <int PAD, int MODE, int ORDER>
+__global__ __launch_bounds__(256) void gs3d_cl_brick_kernel(
+    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
+    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int bps) {
+  __shared__ TapRec recs[64];
+  __shared__ int vox_of[64];
+  const int LPV = C >> 2;
+  const int nvox = Do * Ho * Wo;
+  int n, blk;
+  block_to_work<ORDER>(blockIdx.x, gridDim.x, bps, Do >> 2, n, blk);
+  stage_taps<PAD, MODE, 64, true>(recs, grid, theta, lin_x, lin_y, lin_z, n, blk, nvox, D, H, W, Ho, Wo);
+  if (threadIdx.x < 64) vox_of[threadIdx.x] = brick_voxel(blk, threadIdx.x, Ho, Wo);
+  __syncthreads();
+  const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
+  const unsigned row_bytes = (unsigned)C * 4u;
+  float4* obase = reinterpret_cast<float4*>(out) + (long)n * nvox * LPV;
+  for (int item = threadIdx.x; item < 64 * LPV; item += 256) {
+    const int v = item / LPV;
+    const int q = item - v * LPV;
+    const TapRec r = recs[v];
+    obase[(long)vox_of[v] * LPV + q] = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
   }
 }
 
@@ -525,6 +564,16 @@ int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, cons
     case 9: EMO_CLV2(64, 3);
     case 10: EMO_CLV2(64, 4);
     case 11: EMO_CLV2(64, 5);
+    case 12: {   // 4x4x4 output bricks (NDHWC output only), XCD-contiguous block order
+      if (!out_cl || (Do & 3) || (Ho & 3) || (Wo & 3)) return EMO_ERR_UNSUPPORTED;
+      const int nvox_ = Do * Ho * Wo;
+      const int bps_ = nvox_ >> 6;
+      const long total_ = (long)bps_ * N;
+      if (total_ > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((gs3d_cl_brick_kernel<PAD, MODE, 1>), dim3((unsigned)total_), dim3(256), 0, s, vol, grid, theta, lin_x,
+                         lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps_);
+      return emo_launch_status();
+    }
     default: return EMO_ERR_BAD_ARG;
   }
 #undef EMO_CLV2

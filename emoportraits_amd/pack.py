@@ -120,9 +120,11 @@ def pack_weight(w, cfg):
 # the 64-row tile (15 KB stage buffers -> 5 blocks per CU) beats the 128-row one (25 KB -> 3 blocks) on the 64^2 .. 256^2
 # layers (133 vs 124 TF on 512->512 @64^2) and ties it at 512^2 (132-135); the 32-row tile re-stages the same input patch
 # for a quarter of the work
-_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 0.0}   # D (64 x 256): opt-in via EMO_CONV_CFG_D / pinned cfg only
-if __import__("os").environ.get("EMO_CONV_CFG_D") == "1":   # A/B switch for the 64 x 256 tile
-    _CFG_EFF[CFG_D] = 1.02
+# the 64 x 256 tile (D) halves the weight-tile traffic per MFMA and stages 25-33 % less patch per position: 131-141 TF on
+# every 2-D 3x3 decoder layer (B: 126-135), bench 127.3 -> 132.0 frames/s (profiles/r2_conv_microbench.jsonl)
+_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 1.03}
+if __import__("os").environ.get("EMO_CONV_CFG_D") == "0":   # A/B switch: plan without the 64 x 256 tile
+    _CFG_EFF[CFG_D] = 0.0
 _FILL_BLOCKS = 512   # 2 blocks per CU on 256 CUs
 
 

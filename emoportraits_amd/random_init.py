@@ -23,7 +23,12 @@ def _kaiming(shape, g):
     return torch.randn(shape, generator=g) * math.sqrt(2.0 / max(fan_in, 1))
 
 
-def random_state_dict(cfg, seed=0, trained_like=True, with_source=True):
+def random_state_dict(cfg, seed=0, trained_like=True, with_source=True, image_head_gain=None):
+    """image_head_gain: scales the affine of the last GroupNorm of the image decoder (dec_img_head.0).  The head is a
+    weight-standardised 1x1 conv over 128 ReLU channels followed by a sigmoid: with unit norm weights its pre-activation has
+    a standard deviation of ~8, i.e. a random network paints saturated 0/1 images and every rounding difference that moves a
+    pre-activation across zero flips a pixel.  A trained decoder produces natural images: logits within a few units.  A gain
+    of ~0.2 gives the seeded checkpoint that statistic (pre-activation std ~1.5) without touching anything else."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     schema = hot_path_schema(cfg, with_source)
@@ -64,4 +69,7 @@ def random_state_dict(cfg, seed=0, trained_like=True, with_source=True):
                     u = torch.mv(w, v)
                     u = u / u.norm().clamp_min(1e-12)
                 sd[p + ".weight_u"], sd[p + ".weight_v"] = u, v
+    if image_head_gain is not None:
+        for k in ("decoder_nw.img_decoder.dec_img_head.0.weight", "decoder_nw.img_decoder.dec_img_head.0.bias"):
+            sd[k] = sd[k] * float(image_head_gain)
     return sd

@@ -37,7 +37,9 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
         res["cl"] = ops.volume_to_channels_first(ocl).cpu()
         assert torch.equal(res["cl"], ocl.cpu().permute(0, 4, 1, 2, 3).contiguous())
         res["cl2ncdhw"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw").cpu()
-        for var in (3, 4, 5, 6, 7):   # block-order / voxels-per-block variants of the v2 kernels
+        Do_, Ho_, Wo_ = (grid_cpu.shape[1:4] if grid_cpu is not None else vol_cpu.shape[2:])
+        bricks = (12,) if (Do_ % 4 == 0 and Ho_ % 4 == 0 and Wo_ % 4 == 0) else ()     # 4x4x4 output bricks per block
+        for var in (3, 4, 5, 6, 7) + bricks:   # block-order / voxels-per-block variants of the v2 kernels
             o = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=var)
             res[f"cl_var{var}"] = o.cpu().permute(0, 4, 1, 2, 3).contiguous()
         for var in (3, 4, 5):

@@ -81,20 +81,23 @@ def main():
         delta = (warp - ident().to(DEV)).permute(0, 4, 1, 2, 3).contiguous()
         cases.append(("uv/cg8", lambda: ops.grid_sample3d(vcg, warp, in_layout="cg8", out_layout="cg8", out=out_cg), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("uv_delta/cg8", lambda: ops.grid_sample3d(vcg, delta=delta, in_layout="cg8", out_layout="cg8", out=out_cg), vol_bytes / N + grid_bytes + vol_bytes))
+        cases.append(("uv_delta/cl_brick", lambda: ops.grid_sample3d(vcl, delta=delta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=12), vol_bytes / N + grid_bytes + vol_bytes))
+        cases.append(("uv_unshared_delta/cl_brick", lambda: ops.grid_sample3d(inN_cl, delta=delta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=12), 2 * vol_bytes + grid_bytes))
         cases.append(("uv_delta/cl", lambda: ops.grid_sample3d(vcl, delta=delta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), vol_bytes / N + grid_bytes + vol_bytes))
         cases.append(("rot_theta_unshared/cg8_to_ncdhw", lambda: ops.grid_sample3d(inN_cg, theta=theta, in_layout="cg8", out_layout="ncdhw", out=out_nc), 2 * vol_bytes))
         pair_bytes = vol_bytes / N + grid_bytes + vol_bytes + 2 * vol_bytes
 
-        def pair(lay, vshared, mid, chunk):
+        def pair(lay, vshared, mid, chunk, uv_variant=0):
             def run():
                 for a in range(0, N, chunk):
                     b = min(N, a + chunk)
-                    ops.grid_sample3d(vshared, delta=delta[a:b], in_layout=lay, out_layout=lay, out=mid[a:b])
+                    ops.grid_sample3d(vshared, delta=delta[a:b], in_layout=lay, out_layout=lay, out=mid[a:b], variant=uv_variant)
                     ops.grid_sample3d(mid[a:b], theta=theta[a:b], in_layout=lay, out_layout="ncdhw", out=out_nc[a:b])
             return run
-        for chunk in sorted({N, min(N, 8), min(N, 4)}, reverse=True):
+        for chunk in sorted({N, min(N, 8), min(N, 4), min(N, 2)}, reverse=True):
             cases.append((f"pair/cl/chunk{chunk}", pair("ndhwc", vcl, out_cl, chunk), pair_bytes))
             cases.append((f"pair/cg8/chunk{chunk}", pair("cg8", vcg, out_cg, chunk), pair_bytes))
+            cases.append((f"pair/cl_brick_uv/chunk{chunk}", pair("ndhwc", vcl, out_cl, chunk, 12), pair_bytes))
         cases.append(("torch/F.grid_sample(uv, expanded vol)", lambda: torch.nn.functional.grid_sample(inN_nc, warp, align_corners=False), 2 * vol_bytes + grid_bytes))
         cases.append(("copy/out_nc.copy_(inN_nc)", lambda: out_nc.copy_(inN_nc), 2 * vol_bytes))
         for name, fn, bytes_per_sample in cases:
