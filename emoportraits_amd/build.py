@@ -20,8 +20,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -ffp-contract=off: the sampler's index arithmetic must not be contracted into FMAs (bit-parity with ATen);
 # kernels that want FMAs ask for them explicitly (__fmaf_rn / MFMA).
+# -pragma-unroll-threshold: the conv kernels index their accumulator / staging register arrays with loop counters of
+# `#pragma unroll` loops; past LLVM's default size budget (16 K) a loop silently stays rolled, the indices become dynamic and
+# the arrays fall into scratch memory (seen on the 64 x 512 tile: 576 B of scratch inside the K loop).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-variable"]
+         "-Wno-unused-function", "-Wno-unused-variable", "-mllvm", "-pragma-unroll-threshold=100000"]
 
 
 def sources():

@@ -120,6 +120,15 @@ def validate(cfg):
         problems.append("latent_volume_channels != gen_latent_texture_channels")
     if cfg["warp_output_size"] != cfg["gen_latent_texture_size"]:
         problems.append("warp_output_size != gen_latent_texture_size (resize_warp) unsupported")
+    # every feature map on the path has width image_size / 2^k down to the latent size; the conv kernels tile output widths
+    # that are multiples of 128, or 64 / 32 / 16 / 8 (csrc/conv_api.hip shape_of_width) -- reject e.g. 384 or 768 here, not at
+    # the first convolution
+    S, L = cfg["image_size"], cfg["gen_latent_texture_size"]
+    if S < L or S % L or (S // L) & (S // L - 1):
+        problems.append(f"image_size={S} must be gen_latent_texture_size={L} times a power of two")
+    elif any(w % 128 and w not in (64, 32, 16, 8) for w in [S >> k for k in range((S // L).bit_length())]):
+        problems.append(f"image_size={S}: a feature-map width on the path is not tiled by the conv kernels "
+                        f"(multiples of 128, or 64 / 32 / 16 / 8)")
     if not (cfg["use_sn"] and cfg["use_ws"]):
         problems.append("use_sn and use_ws must both be True (released key layout)")
     if problems:

@@ -8,7 +8,8 @@ enum { SHAPE_W128 = 0, SHAPE_W64 = 1, SHAPE_W32 = 2, SHAPE_W16 = 3, SHAPE_W8 = 4
 // C = 32 co x 128 pos (waves 1x4, wave tile 32x32); D = 64 co x 256 pos (waves 1x4, wave tile 64x64): per MFMA half the
 // weight-tile traffic of A and B and 25-33 % less patch traffic (a 2x128 / 4x64 / 8x32 position tile has less halo per
 // position than 1x128 / 2x64 / 4x32); 2-D 3x3 layers only
-enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_D = 3, N_CFGS = 4 };
+// E = 64 co x 512 pos (waves 1x4, wave tile 64x128 = 8 accumulators): half of D's staging traffic per MFMA again, 2 waves / SIMD
+enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_D = 3, CFG_E = 4, N_CFGS = 5 };
 
 typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 
@@ -57,4 +58,12 @@ typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
                                    : &conv_igemm_launch<KH, KW, KC, 1, 4, 64, 2, 2, 1, 4, false>)              \
    : (shape) == SHAPE_W32 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 8, 32, 2, 2, 1, 4, true>                \
                                    : &conv_igemm_launch<KH, KW, KC, 1, 8, 32, 2, 2, 1, 4, false>)              \
+                          : (conv_launch_fn) nullptr)
+
+// 64 x 512 tiles (CFG_E): 2-D widths that are multiples of 128, or 64
+#define CONV_FOR_SHAPE_E(KH, KW, KC, shape, ups)                                                              \
+  ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 4, 128, 2, 4, 1, 4, true>                \
+                                  : &conv_igemm_launch<KH, KW, KC, 1, 4, 128, 2, 4, 1, 4, false>)              \
+   : (shape) == SHAPE_W64 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 8, 64, 2, 4, 1, 4, true>                \
+                                   : &conv_igemm_launch<KH, KW, KC, 1, 8, 64, 2, 4, 1, 4, false>)              \
                           : (conv_launch_fn) nullptr)

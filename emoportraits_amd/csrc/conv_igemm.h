@@ -99,14 +99,15 @@ struct ConvCfg {
   static_assert(TZ * TR * TW == BP, "position tile must equal BP");
   static_assert(KC % 2 == 0 && (KC % SW == 0 || SW % KC == 0), "whole channels per wave, or whole waves per channel");
   static_assert(ASZ % 4 == 0, "weight tile must be float4-copyable");
-  static_assert(TM * TP <= 4, "accumulator budget");
+  static_assert(TM * TP <= 8, "accumulator budget");
   static_assert(2 * BUF >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the stage buffers");
   static constexpr int LDS_BYTES = (2 * BUF + 256) * 4;             // two stage buffers + 64 float4 dump slots
   // blocks per CU that LDS admits, capped: the register allocator must fit that many waves per SIMD (1 wave per block
   // and SIMD) -- without a floor it spends up to 256 VGPRs on epilogue ILP and silently halves the occupancy
   static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
-  static constexpr int CAP = TM * TP >= 4 ? (EMO_CONV_MAX_WAVES < 4 ? EMO_CONV_MAX_WAVES : 4)   // 64 accumulator registers: 4 waves
-                                          : EMO_CONV_MAX_WAVES;                                   // per SIMD = 128 VGPRs at most
+  static constexpr int CAP = TM * TP >= 8 ? 2                                                    // 128 accumulator registers
+                             : TM * TP >= 4 ? (EMO_CONV_MAX_WAVES < 4 ? EMO_CONV_MAX_WAVES : 4)   // 64: 4 waves per SIMD = 128 VGPRs
+                                            : EMO_CONV_MAX_WAVES;
   static constexpr int OCC = BY_LDS < 2 ? 2 : (BY_LDS > CAP ? CAP : BY_LDS);
 };
 
@@ -356,13 +357,17 @@ void conv_igemm_kernel(const ConvArgs a) {
   }
   __syncthreads();
 
-  floatx16 acc[TM][TP];
+  // accumulators in two arrays of at most 64 floats each: one 128-float array (TM*TP = 8) is not scalarised by the
+  // compiler (it stays a scratch alloca that the K loop loads and stores around every MFMA)
+  constexpr int TPH = TP > 2 ? TP / 2 : TP;
+  floatx16 acc_lo[TM][TPH], acc_hi[TM][TPH];
+#define acc_at(i_, j_) ((j_) < TPH ? acc_lo[i_][(j_) < TPH ? (j_) : 0] : acc_hi[i_][(j_) >= TPH ? (j_) - TPH : 0])
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TP; ++j)
+    for (int j = 0; j < TPH; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
 
   // lane bases into the LDS tiles
   const int a_base = half * BM + m0 + l32;
@@ -406,7 +411,7 @@ void conv_igemm_kernel(const ConvArgs a) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc[i][j], 0, 0, 0);
+          acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc_at(i, j), 0, 0, 0);
     }
     if (!PINNED && EMO_CONV_ABLATE == 0) {
       // round-1 schedule: refill the registers with stage st+2 before the barrier
@@ -446,7 +451,7 @@ void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (co < a.Cout) a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc[i][j][r];
+          if (co < a.Cout) a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc_at(i, j)[r];
         }
       } else {
         float rv[16];
@@ -467,9 +472,9 @@ void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
-          const float v = emo_act(acc[i][j][r] + bv[r] + rv[r], a.act);
+          const float v = emo_act(acc_at(i, j)[r] + bv[r] + rv[r], a.act);
           if (co < a.Cout) op[(long)co * ovol] = v;
-          acc[i][j][r] = v;   // the stored value: what the next GroupNorm normalises
+          acc_at(i, j)[r] = v;   // the stored value: what the next GroupNorm normalises
         }
       }
     }
@@ -486,13 +491,13 @@ void conv_igemm_kernel(const ConvArgs a) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = acc[i][0][r];
+        float s = acc_at(i, 0)[r];
 #pragma unroll
-        for (int j = 1; j < TP; ++j) s += acc[i][j][r];
+        for (int j = 1; j < TP; ++j) s += acc_at(i, j)[r];
         const float mean = emo_sum32(s) * inv_cnt;
         float m2 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < TP; ++j) { const float d = acc[i][j][r] - mean; m2 = __fmaf_rn(d, d, m2); }
+        for (int j = 0; j < TP; ++j) { const float d = acc_at(i, j)[r] - mean; m2 = __fmaf_rn(d, d, m2); }
         m2 = emo_sum32(m2);
         if (l32 == 0) {
           const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -521,6 +526,7 @@ void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+#undef acc_at
 #undef EMO_ISSUE_PATCH
 #undef EMO_WAIT_PATCH
 #undef EMO_ISSUE_WEIGHTS

@@ -21,6 +21,11 @@ def test_released_config_matches_the_oracle_and_is_validated():
         config.hot_path_config(overrides={"use_back": True})
     with pytest.raises(ValueError, match="resize_warp"):
         config.hot_path_config(overrides={"warp_output_size": 128})
+    for bad in (384, 768, 96):          # widths the conv kernels do not tile: refused at configuration time
+        with pytest.raises(ValueError, match="image_size"):
+            config.hot_path_config(overrides={"image_size": bad})
+    for ok in (64, 128, 256, 512, 1024):
+        assert config.hot_path_config(overrides={"image_size": ok})["image_size"] == ok
 
 
 def test_args_txt_both_formats(tmp_path):

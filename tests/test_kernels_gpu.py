@@ -90,6 +90,19 @@ def test_conv2d_3x3_config_D_64x256_tiles(hw, mode):
     assert got.shape == ref.shape and e < 2e-5, e
 
 
+@pytest.mark.parametrize("hw", [64, 128, 256])
+@pytest.mark.parametrize("mode", ["plain", "ups", "full"])
+def test_conv2d_3x3_config_E_64x512_tiles(hw, mode):
+    """block config 4: 64 output channels x 512 positions (4x128 / 8x64 position tiles, 8 accumulator tiles per wave)"""
+    if mode == "plain":
+        e, got, ref = run_conv(2, 12, 72, (hw, hw), 3, 4, seed=hw)
+    elif mode == "ups":
+        e, got, ref = run_conv(2, 12, 72, (hw // 2, hw // 2), 3, 4, ups=True, affine=True, relu_in=True, seed=hw + 1)
+    else:
+        e, got, ref = run_conv(1, 24, 130, (hw, hw), 3, 4, affine=True, relu_in=True, res=True, act="tanh", seed=hw + 2)
+    assert got.shape == ref.shape and e < 2e-5, e
+
+
 def test_conv_config_D_tile_statistics_and_unsupported_shapes():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 16, 64, 64, generator=g)
