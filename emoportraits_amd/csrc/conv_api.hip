@@ -6,6 +6,7 @@ conv_launch_fn conv_lookup_3x3_B(int, int);
 conv_launch_fn conv_lookup_3x3_C(int, int);
 conv_launch_fn conv_lookup_3x3_D(int, int);
 conv_launch_fn conv_lookup_3x3_E(int, int);
+conv_launch_fn conv_lookup_3x3_F(int, int);
 conv_launch_fn conv_lookup_1x1_A(int, int);
 conv_launch_fn conv_lookup_1x1_B(int, int);
 conv_launch_fn conv_lookup_1x1_C(int, int);
@@ -33,7 +34,7 @@ static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
     return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : (KH == 1 && KW == 1) ? EMO_CONV_KC_F16_1X1 : 0;
   }
   if (KH == 3 && KW == 3) return cfg == CFG_A ? EMO_CONV_KC_3X3_A : EMO_CONV_KC_3X3;
-  if (cfg == CFG_D || cfg == CFG_E) return 0;   // 3x3 only
+  if (cfg == CFG_D || cfg == CFG_E || cfg == CFG_F) return 0;   // 3x3 (x3) only
   if (KH == 1 && KW == 1) return EMO_CONV_KC_1X1;
   if (KH == 1 && KW == 7) return EMO_CONV_KC_1X7;
   return 0;
@@ -41,7 +42,7 @@ static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
 
 extern "C" int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC) {
   if (!BM || !KC) return EMO_ERR_BAD_ARG;
-  if (cfg == CFG_A) *BM = 128; else if (cfg == CFG_B || cfg == CFG_D || cfg == CFG_E) *BM = 64; else if (cfg == CFG_C) *BM = 32; else return EMO_ERR_BAD_ARG;
+  if (cfg == CFG_A) *BM = 128; else if (cfg == CFG_B || cfg == CFG_D || cfg == CFG_E) *BM = 64; else if (cfg == CFG_C || cfg == CFG_F) *BM = 32; else return EMO_ERR_BAD_ARG;
   *KC = kc_of(KH, KW, cfg);
   return *KC ? EMO_OK : EMO_ERR_UNSUPPORTED;
 }
@@ -49,7 +50,7 @@ extern "C" int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC) {
 // output positions per block of a config (the tile the GroupNorm statistics of gn_stats are reduced over)
 extern "C" int emo_conv_tile_positions(int cfg) {
   if (cfg == CFG_A || cfg == CFG_B || cfg == CFG_C) return 128;
-  if (cfg == CFG_D) return 256;
+  if (cfg == CFG_D || cfg == CFG_F) return 256;
   if (cfg == CFG_E) return 512;
   return EMO_ERR_BAD_ARG;
 }
@@ -95,7 +96,7 @@ extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int
   const int kc = kc_of(KH, KW, cfg);
   if (!kc || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 || cfg < 0 || cfg >= N_CFGS) return EMO_ERR_BAD_ARG;
   const int bm = cfg == CFG_A ? 128 : (cfg == CFG_B || cfg == CFG_D || cfg == CFG_E) ? 64 : 32;
-  const int bp = cfg == CFG_D ? 256 : cfg == CFG_E ? 512 : 128;
+  const int bp = (cfg == CFG_D || cfg == CFG_F) ? 256 : cfg == CFG_E ? 512 : 128;
   const long pos = (long)N * D * (ups ? 4 : 1) * H * W;
   const long blocks = ((pos + bp - 1) / bp) * ((Cout + bm - 1) / bm);
   const int nstages = ((Cin + kc - 1) / kc) * KD;
@@ -137,9 +138,10 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
     if (KH == 3 && KW == 3) fn = cfg == CFG_A ? conv_lookup_f16_3x3_A(shape, ups) : cfg == CFG_B ? conv_lookup_f16_3x3_B(shape, ups) : nullptr;
     else if (KH == 1 && KW == 1) fn = cfg == CFG_A ? conv_lookup_f16_1x1_A(shape, ups) : cfg == CFG_B ? conv_lookup_f16_1x1_B(shape, ups) : nullptr;
     else return EMO_ERR_UNSUPPORTED;
-  } else if (cfg == CFG_D || cfg == CFG_E) {
-    if (!(KH == 3 && KW == 3 && KD == 1)) return EMO_ERR_UNSUPPORTED;
-    fn = cfg == CFG_D ? conv_lookup_3x3_D(shape, ups) : conv_lookup_3x3_E(shape, ups);
+  } else if (cfg == CFG_D || cfg == CFG_E || cfg == CFG_F) {
+    // position tiles of one depth slice (TZ = 1): 2-D layers, and 3-D layers whose depth taps run as K stages
+    if (!(KH == 3 && KW == 3 && (KD == 1 || (KD == 3 && cfg != CFG_E)))) return EMO_ERR_UNSUPPORTED;
+    fn = cfg == CFG_D ? conv_lookup_3x3_D(shape, ups) : cfg == CFG_E ? conv_lookup_3x3_E(shape, ups) : conv_lookup_3x3_F(shape, ups);
   } else if (KH == 3 && KW == 3) {
     fn = cfg == CFG_A ? conv_lookup_3x3_A(shape, ups) : cfg == CFG_B ? conv_lookup_3x3_B(shape, ups) : conv_lookup_3x3_C(shape, ups);
   } else if (KH == 1 && KW == 1) {

@@ -9,7 +9,8 @@ enum { SHAPE_W128 = 0, SHAPE_W64 = 1, SHAPE_W32 = 2, SHAPE_W16 = 3, SHAPE_W8 = 4
 // weight-tile traffic of A and B and 25-33 % less patch traffic (a 2x128 / 4x64 / 8x32 position tile has less halo per
 // position than 1x128 / 2x64 / 4x32); 2-D 3x3 layers only
 // E = 64 co x 512 pos (waves 1x4, wave tile 64x128 = 8 accumulators): half of D's staging traffic per MFMA again, 2 waves / SIMD
-enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_D = 3, CFG_E = 4, N_CFGS = 5 };
+// F = 32 co x 256 pos (waves 1x4, wave tile 32x64): D for layers with 32 or fewer output channels
+enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_D = 3, CFG_E = 4, CFG_F = 5, N_CFGS = 6 };
 
 typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 
@@ -66,4 +67,13 @@ typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
                                   : &conv_igemm_launch<KH, KW, KC, 1, 4, 128, 2, 4, 1, 4, false>)              \
    : (shape) == SHAPE_W64 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 8, 64, 2, 4, 1, 4, true>                \
                                    : &conv_igemm_launch<KH, KW, KC, 1, 8, 64, 2, 4, 1, 4, false>)              \
+                          : (conv_launch_fn) nullptr)
+
+// 32 x 256 tiles (CFG_F): widths that are multiples of 128, or 64 / 32
+#define CONV_FOR_SHAPE_F(KH, KW, KC, shape, ups)                                                              \
+  ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_launch<KH, KW, KC, 1, 2, 128, 1, 2, 1, 4, true>                \
+                                  : &conv_igemm_launch<KH, KW, KC, 1, 2, 128, 1, 2, 1, 4, false>)              \
+   : (ups)               ? (conv_launch_fn) nullptr                                                            \
+   : (shape) == SHAPE_W64 ? &conv_igemm_launch<KH, KW, KC, 1, 4, 64, 1, 2, 1, 4, false>                        \
+   : (shape) == SHAPE_W32 ? &conv_igemm_launch<KH, KW, KC, 1, 8, 32, 1, 2, 1, 4, false>                        \
                           : (conv_launch_fn) nullptr)

@@ -14,10 +14,10 @@ import torch
 
 from . import hip
 
-CFG_A, CFG_B, CFG_C, CFG_D, CFG_E = 0, 1, 2, 3, 4
-_BM = {CFG_A: 128, CFG_B: 64, CFG_C: 32, CFG_D: 64, CFG_E: 64}          # output channels per block
-_BP = {CFG_A: 128, CFG_B: 128, CFG_C: 128, CFG_D: 256, CFG_E: 512}      # output positions per block (emo_conv_tile_positions)
-_PACK_AS = {CFG_D: CFG_B, CFG_E: CFG_B}                                  # configs that share another config's weight layout
+CFG_A, CFG_B, CFG_C, CFG_D, CFG_E, CFG_F = 0, 1, 2, 3, 4, 5
+_BM = {CFG_A: 128, CFG_B: 64, CFG_C: 32, CFG_D: 64, CFG_E: 64, CFG_F: 32}            # output channels per block
+_BP = {CFG_A: 128, CFG_B: 128, CFG_C: 128, CFG_D: 256, CFG_E: 512, CFG_F: 256}       # output positions per block
+_PACK_AS = {CFG_D: CFG_B, CFG_E: CFG_B, CFG_F: CFG_C}                                 # configs sharing another one's weight layout
 
 
 def fold_sn(weight_orig, u, v):
@@ -122,7 +122,7 @@ def pack_weight(w, cfg):
 # for a quarter of the work
 # the 64 x 256 tile (D) halves the weight-tile traffic per MFMA and stages 25-33 % less patch per position: 131-141 TF on
 # every 2-D 3x3 decoder layer (B: 126-135), bench 127.3 -> 132.0 frames/s (profiles/r2_conv_microbench.jsonl)
-_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 1.03, CFG_E: 0.0}
+_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 1.03, CFG_E: 0.0, CFG_F: 0.92}
 if __import__("os").environ.get("EMO_CONV_CFG_D") == "0":   # A/B switch: plan without the 64 x 256 tile
     _CFG_EFF[CFG_D] = 0.0
 if __import__("os").environ.get("EMO_CONV_CFG_E") == "1":   # A/B switch: plan with the 64 x 512 tile
@@ -131,8 +131,9 @@ _FILL_BLOCKS = 512   # 2 blocks per CU on 256 CUs
 
 
 def cfg_d_fits(kd, kh, kw, Hl, Wl, precision="f32"):
-    """the 64 x 256 tile exists for 2-D 3x3 fp32 layers whose output is tiled by 2x128 / 4x64 / 8x32 positions"""
-    if precision != "f32" or kd != 1 or (kh, kw) != (3, 3) or Hl is None:
+    """the 64 x 256 (and 32 x 256) tiles exist for 3x3 / 3x3x3 fp32 layers whose output planes are tiled by 2x128 / 4x64 /
+    8x32 positions (the depth taps of a 3-D layer run as K stages, one depth slice per tile)"""
+    if precision != "f32" or kd not in (1, 3) or (kh, kw) != (3, 3) or Hl is None:
         return False
     return (Wl % 128 == 0 and Hl % 2 == 0) or (Wl == 64 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0)
 
@@ -253,11 +254,13 @@ class PackedConv:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
-    def plan_for(self, n_pos_tiles, Hl=None, Wl=None):
+    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False):
         """(cfg, ksplit) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output"""
         allowed = (self.pinned_cfg,) if self.pinned_cfg is not None else self.allowed
         if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl, self.precision):
             allowed = allowed + (CFG_D,)
+            if _CFG_EFF[CFG_F] > 0 and (not ups or Wl % 128 == 0):
+                allowed = allowed + (CFG_F,)
         if self.pinned_cfg is None and _CFG_EFF[CFG_E] > 0 and cfg_e_fits(self.kd, self.kh, self.kw, Hl, Wl, self.precision):
             allowed = allowed + (CFG_E,)
         return plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, allowed, self.precision)

@@ -138,8 +138,8 @@ int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_
  *   res   residual added before `act` (ResBlock skip, utils.py:783); same shape as out, or the pre-upsample
  *         shape when res_ups != 0.  May alias `out`.
  *   act   EMO_ACT_* applied last (tanh head warp_generator_resnet.py:99-107; sigmoid head decoder.py:347-358).
- *   cfg   0: 128 output channels x 128 positions per block, 1: 64 x 128, 2: 32 x 128, 3: 64 x 256, 4: 64 x 512 (3 and 4: 2-D 3x3 layers only;
- *         weights packed as for cfg 1).  emo_conv_tile_positions(cfg) = positions per block.
+ *   cfg   0: 128 output channels x 128 positions per block, 1: 64 x 128, 2: 32 x 128, 3: 64 x 256, 4: 64 x 512, 5: 32 x 256 (3-5: 3x3 layers, 3 and 5
+ *         also 3x3x3; weights packed as for cfg 1 resp. 2).  emo_conv_tile_positions(cfg) = positions per block.
  *   ksplit / workspace   ksplit > 1 divides the K loop (input-channel chunks x depth taps) of every output tile over
  *         ksplit blocks -- small launches (64x64 maps at batch 1, the 8^3 / 16^3 WarpGenerator layers) otherwise leave most
  *         of the 256 CUs idle; partial sums go to workspace [ksplit][N*Cout*D*Hl*Wl] floats and a second kernel adds them

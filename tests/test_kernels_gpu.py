@@ -115,8 +115,16 @@ def test_conv_config_D_tile_statistics_and_unsupported_shapes():
     assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item() and (h1 - h0).abs().max().item() <= 2e-6
     ref = F.conv2d(x, w, padding=1)
     assert rel_err(out, ref) < 2e-5
-    with pytest.raises(RuntimeError, match="UNSUPPORTED"):       # 3-D layers have no 64 x 256 tile
-        ops.conv_igemm(torch.randn(1, 16, 8, 32, 32, device=DEV), pack.PackedConv("d3", torch.randn(64, 16, 3, 3, 3), None, DEV, cfg=3))
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):       # 16-wide outputs have no 64 x 256 tile
+        ops.conv_igemm(torch.randn(1, 16, 16, 16, device=DEV), pack.PackedConv("d3", torch.randn(64, 16, 3, 3), None, DEV, cfg=3))
+
+
+@pytest.mark.parametrize("cfg", [3, 5])
+@pytest.mark.parametrize("dims", [(8, 32, 32), (4, 64, 64), (2, 128, 128), (64, 64), (128, 128)])
+def test_conv_256_position_tiles_2d_and_3d(cfg, dims):
+    """block configs 3 (64 x 256) and 5 (32 x 256) on 2-D and 3-D layers (depth taps as K stages, one depth slice per tile)"""
+    e, got, ref = run_conv(1, 12, 40 if cfg == 3 else 24, dims, 3, cfg, affine=True, relu_in=True, res=True, seed=sum(dims) + cfg)
+    assert got.shape == ref.shape and e < 2e-5, e
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2])

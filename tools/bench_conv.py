@@ -57,11 +57,13 @@ def main():
         ms_t = 0.0 if quick else timeit(lambda: conv(xin, wd, padding=k // 2))
         rec = dict(B=B, cin=cin, cout=cout, dims=dims, k=k, ups=ups, torch_ms=round(ms_t, 3),
                    torch_tflops=round(flops / ms_t / 1e9, 1) if ms_t else None)
-        for cfg in (0, 1, 2, 3, 4):
-            bm = {0: 128, 1: 64, 2: 32, 3: 64, 4: 64}[cfg]
+        for cfg in (0, 1, 2, 3, 4, 5):
+            bm = {0: 128, 1: 64, 2: 32, 3: 64, 4: 64, 5: 32}[cfg]
             if cfg == 2 and cout > 96:
                 continue
-            if cfg in (3, 4) and (three_d or k != 3 or cout < 64):
+            if cfg in (3, 4, 5) and (k != 3 or dims[-1] < 32 or (three_d and cfg == 4)):
+                continue
+            if (cfg in (3, 4) and cout < 64) or (cfg == 5 and cout > 96):
                 continue
             if -(-cout // bm) * bm > 1.5 * cout and cfg != pack.choose_cfg(cout):
                 continue
