@@ -156,6 +156,17 @@ __device__ __forceinline__ float emo_sum32(float v) {
 #define EMO_CONV_STORE_EIGHTHS 5   /* the next stage's patch is transformed and written to LDS after this many eighths of the
                                       stage's MFMA steps (PIPE 1 used 4) */
 #endif
+#ifndef EMO_CONV_LDS_PREFETCH
+#define EMO_CONV_LDS_PREFETCH 0   /* 1: the LDS operands of MFMA step k+1 are read before the MFMAs of step k are issued.
+                                     Measured neutral (bench 132.0 vs 131.9 frames/s, profiles/r2_conv_mfma_stream_variants.jsonl):
+                                     with 4-5 waves per SIMD the operand latency is already covered by the other waves */
+#endif
+#ifndef EMO_CONV_SETPRIO
+#define EMO_CONV_SETPRIO 1   /* 1: s_setprio 1 while a wave is in its MFMA stream, 0 around the staging of the next stage: the
+                                blocks of a CU are at independent phases, so the arbiter prefers a wave that has MFMAs to issue over
+                                one that is transforming / storing its patch (cdna_hip_programming.md T5).  Measured +0.4 %
+                                (132.4 vs 131.8 frames/s, twice each) */
+#endif
 #ifndef EMO_CONV_ABLATE
 #define EMO_CONV_ABLATE 0   /* timing experiments only (results are WRONG for any value != 0): 1 = no global loads, no LDS-DMA and
                                no LDS stores in the loop; 5 = LDS stores of stale registers, no global loads, no LDS-DMA */
@@ -393,26 +404,39 @@ void conv_igemm_kernel(const ConvArgs a) {
       EMO_ISSUE_WEIGHTS(stn, nxt);
       if (PINNED) { EMO_ISSUE_PATCH(stn, true); }
     }
+    // one MFMA step = one channel pair x one tap: 1 A read + 1 B read per 32x32 tile, TM*TP MFMAs
+#define EMO_READ_OPERANDS(step_, av__, bv__)                                                          \
+    {                                                                                                 \
+      const int pair_ = (step_) / TAPS, tap_ = (step_) % TAPS;                                        \
+      const int r_ = tap_ / KW, s_ = tap_ % KW;                                                       \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) av__[i] = As[a_base + ((pair_ * TAPS + tap_) * 2) * BM + i * 32]; \
+      _Pragma("unroll") for (int j = 0; j < TP; ++j) bv__[j] = Ps[b_base[j] + (pair_ * 2) * CHS + r_ * PW + s_];       \
+    }
+    float av_[2][TM], bv_[2][TP];   // operand registers of the current and (EMO_CONV_LDS_PREFETCH) the next step
+    if (EMO_CONV_LDS_PREFETCH) { EMO_READ_OPERANDS(0, av_[0], bv_[0]); }
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int step = 0; step < NSTEPS; ++step) {
       if (step == STORE_STEP && (EMO_CONV_ABLATE == 0 || EMO_CONV_ABLATE == 5)) {
+        if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
         if (PINNED && EMO_CONV_ABLATE == 0) { EMO_WAIT_PATCH(); }
         EMO_STORE_STAGE(nxt);
+        if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
       }
-      // one MFMA step = one channel pair x one tap: 1 A read + 1 B read per 32x32 tile, TM*TP MFMAs
-      const int pair = step / TAPS, tap = step % TAPS;
-      const int r = tap / KW, s = tap % KW;
-      float av_[TM], bv_[TP];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av_[i] = As[a_base + ((pair * TAPS + tap) * 2) * BM + i * 32];
-#pragma unroll
-      for (int j = 0; j < TP; ++j) bv_[j] = Ps[b_base[j] + (pair * 2) * CHS + r * PW + s];
+      const int cur_ = EMO_CONV_LDS_PREFETCH ? (step & 1) : 0;
+      if (EMO_CONV_LDS_PREFETCH) {
+        if (step + 1 < NSTEPS) { EMO_READ_OPERANDS(step + 1, av_[cur_ ^ 1], bv_[cur_ ^ 1]); }
+      } else {
+        EMO_READ_OPERANDS(step, av_[0], bv_[0]);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j)
-          acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], acc_at(i, j), 0, 0, 0);
+          acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[cur_][i], bv_[cur_][j], acc_at(i, j), 0, 0, 0);
     }
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
+#undef EMO_READ_OPERANDS
     if (!PINNED && EMO_CONV_ABLATE == 0) {
       // round-1 schedule: refill the registers with stage st+2 before the barrier
       const int stn2 = (st + 2) < st_end ? (st + 2) : (st_end - 1);
