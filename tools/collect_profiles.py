@@ -14,7 +14,16 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_stage2.jsonl", f"{tag}_stage2_bench.jsonl"), (f"{tag}_sampler.jsonl", f"{tag}_sampler_microbench.jsonl"),
                  (f"{tag}_conv.jsonl", f"{tag}_conv_microbench.jsonl"), (f"{tag}_driver512.jsonl", f"{tag}_driver_breakdown_r512.jsonl"),
                  (f"{tag}_pipeline.jsonl", f"{tag}_pipeline_images_in_out.jsonl"), (f"{tag}_embedders.txt", f"{tag}_embedders.txt"),
-                 (f"{tag}_smoke.log", f"{tag}_smoke.txt")):
+                 (f"{tag}_smoke.log", f"{tag}_smoke.txt"),
+                 (f"{tag}_ndhwc_pmc_sampler.json", f"{tag}_pmc_sampler_ndhwc_warp0.05.json"),
+                 (f"{tag}_ndhwc_small_pmc_sampler.json", f"{tag}_pmc_sampler_ndhwc_warp0.02.json"),
+                 (f"{tag}_cg8_pmc_sampler.json", f"{tag}_pmc_sampler_cg8_warp0.05.json"),
+                 (f"{tag}_f16_kernel_stats.csv", f"{tag}_f16_stage2_kernel_stats.csv"),
+                 (f"{tag}_f16_pmc_mfma.json", f"{tag}_f16_stage2_pmc_mfma.json"),
+                 (f"{tag}_f16_pmc_fetch.json", f"{tag}_f16_stage2_pmc_fetch.json"),
+                 (f"{tag}_f16_pmc_write.json", f"{tag}_f16_stage2_pmc_write.json"),
+                 (f"{tag}_f16_conv.jsonl", f"{tag}_f16_conv_microbench.jsonl"),
+                 (f"{tag}_f16_driver512.jsonl", f"{tag}_f16_driver_breakdown_r512.jsonl")):
     if os.path.exists(g + src):
         shutil.copy(g + src, p + dst)
 if os.path.exists(g + f"{tag}_pytest.log"):

@@ -1,24 +1,27 @@
 #!/bin/bash
 # Full round-end validation on the GPU box (what the driver runs, plus the evidence kept under profiles/):
-#   all GPU parity tests, smoke(), the bench line (N=1; R512 and R256), a 2-rank run on one GPU (gloo, test hook),
-#   stage-2 throughput, sampler / conv microbenchmarks, images-in/images-out pipeline, embedder parity + timing,
-#   rocprofv3 kernel stats + PMC passes.
-# usage: gpurun -- 'bash tools/gpu_validate.sh r1'   then   python tools/collect_profiles.py r1
+#   all GPU parity tests, smoke(), the bench line (N=1; R512 and R256), `python bench.py --gpus 2` on one GPU (gloo, test hook),
+#   stage-2 throughput, sampler / conv microbenchmarks, driver-pass breakdown, images-in/images-out pipeline, embedder parity +
+#   timing, rocprofv3 kernel stats + PMC passes of the bench, sampler L1/L2 counters, fp16-mode evidence.
+# usage: gpurun -- 'bash tools/gpu_validate.sh r2'   then   python tools/collect_profiles.py r2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r1}
+TAG=${1:-r2}
 mkdir -p $R/gpurun_out; cd $R
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${TAG}_pytest_full.log
 grep -a "PARITY\|passed\|failed\|Error\|FAILED" gpurun_out/${TAG}_pytest_full.log > gpurun_out/${TAG}_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_smoke.log
 timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --image-size 256 --batch 32 --no-cpu-baseline > gpurun_out/${TAG}_bench256.json 2>> gpurun_out/${TAG}_bench.err
-EMO_DIST_BACKEND=gloo EMO_FORCE_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-   bench.py --gpus 2 --steps 2 --warmup 1 --batch 4 > gpurun_out/${TAG}_bench_2ranks_1gpu.json 2>> gpurun_out/${TAG}_bench.err
+EMO_DIST_BACKEND=gloo EMO_FORCE_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 --batch 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_2ranks_1gpu.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python tools/bench_stage2.py 8 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_stage2.jsonl
-timeout 300 python tools/bench_sampler.py 64 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_sampler.jsonl
-timeout 300 python tools/bench_conv.py 4 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_conv.jsonl
+timeout 300 python tools/bench_sampler.py 16 64 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_sampler.jsonl
+timeout 400 python tools/bench_conv.py 16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_conv.jsonl
 timeout 300 python tools/bench_driver.py 512 1 4 16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_driver512.jsonl
 timeout 300 python tools/bench_pipeline.py 512 1 16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pipeline.jsonl
 timeout 300 python tools/probe_embedders.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_embedders.txt
 bash tools/profile_bench.sh ${TAG}
+bash tools/pmc_sampler.sh ${TAG}_ndhwc 16 0.05 ndhwc > gpurun_out/${TAG}_pmc_sampler_ndhwc.log 2>&1
+bash tools/pmc_sampler.sh ${TAG}_ndhwc_small 16 0.02 ndhwc > gpurun_out/${TAG}_pmc_sampler_ndhwc_small.log 2>&1
+bash tools/pmc_sampler.sh ${TAG}_cg8 16 0.05 cg8 > gpurun_out/${TAG}_pmc_sampler_cg8.log 2>&1
+bash tools/profile_f16.sh ${TAG}
 tail -3 gpurun_out/${TAG}_pytest.log; tail -1 gpurun_out/${TAG}_smoke.log; cut -c1-200 gpurun_out/${TAG}_bench.json
