@@ -12,10 +12,8 @@ conv_launch_fn conv_lookup_1x1_B(int, int);
 conv_launch_fn conv_lookup_1x1_C(int, int);
 conv_launch_fn conv_lookup_1x7_A(int, int);
 conv_launch_fn conv_lookup_1x7_B(int, int);
-conv_launch_fn conv_lookup_f16_3x3_A(int, int);
-conv_launch_fn conv_lookup_f16_3x3_B(int, int);
-conv_launch_fn conv_lookup_f16_1x1_A(int, int);
-conv_launch_fn conv_lookup_f16_1x1_B(int, int);
+conv_launch_fn conv_lookup_f16_3x3_D(int, int);
+conv_launch_fn conv_lookup_f16_1x1_D(int, int);
 
 enum { PREC_F32 = 0, PREC_F16 = 1 };   // MFMA operand format (accumulation and all tensors in HBM are fp32 either way)
 
@@ -30,7 +28,7 @@ static int shape_of_width(int Wl) {
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
   if (prec == PREC_F16) {
-    if (cfg != CFG_A && cfg != CFG_B) return 0;
+    if (cfg != CFG_D) return 0;   // the fp16-operand kernels exist for the 64 x 256 tile only
     return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : (KH == 1 && KW == 1) ? EMO_CONV_KC_F16_1X1 : 0;
   }
   if (KH == 3 && KW == 3) return cfg == CFG_A ? EMO_CONV_KC_3X3_A : EMO_CONV_KC_3X3;
@@ -86,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* 
 // launch heuristic: split the K loop until the launch has >= 2 blocks per CU, keeping >= 8 stages per split
 extern "C" int emo_conv_pack_info_f16(int KH, int KW, int cfg, int* BM, int* KC) {
   if (!BM || !KC) return EMO_ERR_BAD_ARG;
-  if (cfg == CFG_A) *BM = 128; else if (cfg == CFG_B) *BM = 64; else return EMO_ERR_UNSUPPORTED;
+  if (cfg == CFG_D) *BM = 64; else return EMO_ERR_UNSUPPORTED;
   *KC = kc_of(KH, KW, cfg, PREC_F16);
   return *KC ? EMO_OK : EMO_ERR_UNSUPPORTED;
 }
@@ -111,7 +109,7 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
                                int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups, int cfg,
                                int ksplit, float* workspace, float* gn_stats, void* stream) {
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
-  if (gn_stats && (ksplit > 1 || prec != PREC_F32)) return EMO_ERR_UNSUPPORTED;   // tile statistics: single-pass fp32 kernel only
+  if (gn_stats && ksplit > 1) return EMO_ERR_UNSUPPORTED;   // tile statistics come from the single-pass epilogue
   if ((long)D * H * W >= (1L << 30)) return EMO_ERR_UNSUPPORTED;                 // 32-bit byte offsets inside one channel
   if (ksplit < 1 || (ksplit > 1 && !workspace)) return EMO_ERR_BAD_ARG;
   if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
@@ -135,8 +133,9 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   conv_launch_fn fn = nullptr;
   if (prec == PREC_F16) {
     if (KD != 1 && !(KD == 3 && KH == 3)) return EMO_ERR_UNSUPPORTED;
-    if (KH == 3 && KW == 3) fn = cfg == CFG_A ? conv_lookup_f16_3x3_A(shape, ups) : cfg == CFG_B ? conv_lookup_f16_3x3_B(shape, ups) : nullptr;
-    else if (KH == 1 && KW == 1) fn = cfg == CFG_A ? conv_lookup_f16_1x1_A(shape, ups) : cfg == CFG_B ? conv_lookup_f16_1x1_B(shape, ups) : nullptr;
+    if (cfg != CFG_D || Cin % 8) return EMO_ERR_UNSUPPORTED;
+    if (KH == 3 && KW == 3) fn = conv_lookup_f16_3x3_D(shape, ups);
+    else if (KH == 1 && KW == 1) fn = conv_lookup_f16_1x1_D(shape, ups);
     else return EMO_ERR_UNSUPPORTED;
   } else if (cfg == CFG_D || cfg == CFG_E || cfg == CFG_F) {
     // position tiles of one depth slice (TZ = 1): 2-D layers, and 3-D layers whose depth taps run as K stages
@@ -180,7 +179,7 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
 extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias, const float* scale,
                                        const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
                                        int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
-                                       int cfg, int ksplit, float* workspace, void* stream) {
+                                       int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
   return conv_igemm_dispatch(PREC_F16, x, wpk16, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
-                             relu_in, act, res_ups, cfg, ksplit, workspace, nullptr, stream);
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
 }

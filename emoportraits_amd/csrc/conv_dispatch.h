@@ -24,19 +24,17 @@ typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 #define EMO_CONV_KC_1X1 16   /* 32 measured slower (64 KiB+ LDS, 163 VGPR: 67 vs 73 TF on 1536->512 @64^2) */
 #define EMO_CONV_KC_1X7 4
 
-#define EMO_CONV_KC_F16_3X3 8    /* fp16-operand kernels (conv_igemm_f16.h): input channels per stage, a multiple of 8 */
+#define EMO_CONV_KC_F16_3X3 16   /* fp16-operand kernels (conv_igemm_f16.h): input channels per stage, a multiple of 16 */
 #define EMO_CONV_KC_F16_1X1 32
 
-#define CONV_FOR_SHAPE_F16(KH, KW, KC, TM, TP, WGM, WGP, shape, ups)                                            \
-  ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 1, 128, TM, TP, WGM, WGP, true>       \
-                                  : &conv_igemm_f16_launch<KH, KW, KC, 1, 1, 128, TM, TP, WGM, WGP, false>)     \
-   : (shape) == SHAPE_W64 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 2, 64, TM, TP, WGM, WGP, true>       \
-                                   : &conv_igemm_f16_launch<KH, KW, KC, 1, 2, 64, TM, TP, WGM, WGP, false>)     \
-   : (shape) == SHAPE_W32 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 4, 32, TM, TP, WGM, WGP, true>       \
-                                   : &conv_igemm_f16_launch<KH, KW, KC, 1, 4, 32, TM, TP, WGM, WGP, false>)     \
-   : (ups)               ? (conv_launch_fn) nullptr                                                             \
-   : (shape) == SHAPE_W16 ? &conv_igemm_f16_launch<KH, KW, KC, 1, 8, 16, TM, TP, WGM, WGP, false>              \
-   : (shape) == SHAPE_W8  ? &conv_igemm_f16_launch<KH, KW, KC, 2, 8, 8, TM, TP, WGM, WGP, false>               \
+// fp16-operand kernels (conv_igemm_f16.h): 64 x 256 tiles only (widths that are multiples of 128, or 64 / 32)
+#define CONV_FOR_SHAPE_F16(KH, KW, KC, shape, ups)                                                              \
+  ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 2, 128, 2, 2, 1, 4, true>              \
+                                  : &conv_igemm_f16_launch<KH, KW, KC, 1, 2, 128, 2, 2, 1, 4, false>)            \
+   : (shape) == SHAPE_W64 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 4, 64, 2, 2, 1, 4, true>              \
+                                   : &conv_igemm_f16_launch<KH, KW, KC, 1, 4, 64, 2, 2, 1, 4, false>)            \
+   : (shape) == SHAPE_W32 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 8, 32, 2, 2, 1, 4, true>              \
+                                   : &conv_igemm_f16_launch<KH, KW, KC, 1, 8, 32, 2, 2, 1, 4, false>)            \
                           : (conv_launch_fn) nullptr)
 
 #define CONV_FOR_SHAPE(KH, KW, KC, TM, TP, WGM, WGP, shape, ups)                                              \

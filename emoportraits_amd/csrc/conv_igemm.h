@@ -144,6 +144,122 @@ __device__ __forceinline__ float emo_sum32(float v) {
   return v;
 }
 
+#define acc_at(i_, j_) ((j_) < TPH ? acc_lo[i_][(j_) < TPH ? (j_) : 0] : acc_hi[i_][(j_) >= TPH ? (j_) - TPH : 0])
+
+// Epilogue shared by the fp32 and the fp16-operand kernels (both accumulate in fp32 with the same C/D layout).
+// The accumulators live in two arrays of at most 64 floats each (see the kernel).
+template <int TZ, int TR, int TW, int TM, int TP, int WGP, int BM>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, floatx16 (&acc_lo)[TM][TP > 2 ? TP / 2 : TP],
+                                              floatx16 (&acc_hi)[TM][TP > 2 ? TP / 2 : TP], float* smem, int n, int cotile,
+                                              int ptile, int ks, int x0, int y0, int z0, int m0, int p0, int wp, int half,
+                                              int l32, int tid) {
+  constexpr int TPH = TP > 2 ? TP / 2 : TP;
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  //      Bias and residual are fetched in batches of 16 under wave-uniform branches (a per-element `if (a.res) v += ...`
+  //      makes the compiler wait vmcnt(0) behind every single load: 128 dependent round trips per lane). ----
+  const long plane = (long)a.Hl * a.Wl;
+  const long ovol = (long)a.Dl * plane;
+  const bool to_partial = a.partial != nullptr;
+  const bool has_bias = a.bias != nullptr && !to_partial;
+  const bool has_res = a.res != nullptr && !to_partial;
+  const int co_base = cotile * BM + m0 + 4 * half;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
+    if (has_bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = a.bias[min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      const int p = p0 + j * 32 + l32;
+      const int col = p % TW;
+      const int row = (p / TW) % TR;
+      const int pz = p / (TW * TR);
+      const int z = z0 + pz, y = y0 + row, x = x0 + col;
+      const long sp = (long)z * plane + (long)y * a.Wl + x;
+      if (to_partial) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (co < a.Cout) a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc_at(i, j)[r];
+        }
+      } else {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.0f;
+        if (has_res) {
+          long rsp = sp, rvol = ovol;
+          if (a.res_ups) {
+            const int Wr = a.Wl >> 1, Hr = a.Hl >> 1;
+            rsp = ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
+            rvol = (long)a.Dl * Hr * Wr;
+          }
+          const float* rp = a.res + (long)n * a.Cout * rvol + rsp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = rp[(long)min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1) * rvol];
+        }
+        float* op = a.out + (long)n * a.Cout * ovol + sp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
+          const float v = emo_act(acc_at(i, j)[r] + bv[r] + rv[r], a.act);
+          if (co < a.Cout) op[(long)co * ovol] = v;
+          acc_at(i, j)[r] = v;   // the stored value: what the next GroupNorm normalises
+        }
+      }
+    }
+  }
+
+  // ---- GroupNorm statistics of the output tile (wave-uniform branch).  Per channel row of this wave: mean over its
+  //      TP*32 positions (DPP butterfly over the 32 lanes that hold the row), then the sum of squares centred at that mean --
+  //      a two-pass variance on values that are still in registers.  The WGP waves that share the row combine their
+  //      (mean, M2) through LDS with the pairwise update of Chan et al. (equal counts).  No E[x^2] - mean^2 anywhere. ----
+  if (a.gn_stats != nullptr && !to_partial) {
+    float* st_lds = smem;   // [WGP][BM][2]: the stage buffers are idle (the K loop ended with a barrier)
+    constexpr float inv_cnt = 1.0f / (float)(TP * 32);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = acc_at(i, 0)[r];
+#pragma unroll
+        for (int j = 1; j < TP; ++j) s += acc_at(i, j)[r];
+        const float mean = emo_sum32(s) * inv_cnt;
+        float m2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) { const float d = acc_at(i, j)[r] - mean; m2 = __fmaf_rn(d, d, m2); }
+        m2 = emo_sum32(m2);
+        if (l32 == 0) {
+          const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          *reinterpret_cast<float2*>(st_lds + (wp * BM + m) * 2) = make_float2(mean, m2);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cotile * BM + tid;
+      if (co < a.Cout) {
+        float mean = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WGP; ++w) mean += st_lds[(w * BM + tid) * 2 + 0];
+        mean *= 1.0f / (float)WGP;
+#pragma unroll
+        for (int w = 0; w < WGP; ++w) {
+          const float d = st_lds[(w * BM + tid) * 2 + 0] - mean;
+          m2 += st_lds[(w * BM + tid) * 2 + 1] + (float)(TP * 32) * d * d;
+        }
+        const long nptiles = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+        float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)n * nptiles + ptile) * a.Cout + co;
+        *dst = make_float2(mean, m2);
+      }
+    }
+  }
+}
+#undef acc_at
+
 #ifndef EMO_CONV_XCD_ORDER
 #define EMO_CONV_XCD_ORDER 1   /* 1: 1-D grid, XCD-contiguous, output-channel tile fastest (see below); 0: (ptile, cotile, n) grid */
 #endif
@@ -445,109 +561,7 @@ void conv_igemm_kernel(const ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  //      Bias and residual are fetched in batches of 16 under wave-uniform branches (a per-element `if (a.res) v += ...`
-  //      makes the compiler wait vmcnt(0) behind every single load: 128 dependent round trips per lane). ----
-  const long plane = (long)a.Hl * a.Wl;
-  const long ovol = (long)a.Dl * plane;
-  const bool to_partial = a.partial != nullptr;
-  const bool has_bias = a.bias != nullptr && !to_partial;
-  const bool has_res = a.res != nullptr && !to_partial;
-  const int co_base = cotile * BM + m0 + 4 * half;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
-    if (has_bias) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bv[r] = a.bias[min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
-    }
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-      const int p = p0 + j * 32 + l32;
-      const int col = p % TW;
-      const int row = (p / TW) % TR;
-      const int pz = p / (TW * TR);
-      const int z = z0 + pz, y = y0 + row, x = x0 + col;
-      const long sp = (long)z * plane + (long)y * a.Wl + x;
-      if (to_partial) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (co < a.Cout) a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc_at(i, j)[r];
-        }
-      } else {
-        float rv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = 0.0f;
-        if (has_res) {
-          long rsp = sp, rvol = ovol;
-          if (a.res_ups) {
-            const int Wr = a.Wl >> 1, Hr = a.Hl >> 1;
-            rsp = ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
-            rvol = (long)a.Dl * Hr * Wr;
-          }
-          const float* rp = a.res + (long)n * a.Cout * rvol + rsp;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = rp[(long)min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1) * rvol];
-        }
-        float* op = a.out + (long)n * a.Cout * ovol + sp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
-          const float v = emo_act(acc_at(i, j)[r] + bv[r] + rv[r], a.act);
-          if (co < a.Cout) op[(long)co * ovol] = v;
-          acc_at(i, j)[r] = v;   // the stored value: what the next GroupNorm normalises
-        }
-      }
-    }
-  }
-
-  // ---- GroupNorm statistics of the output tile (wave-uniform branch).  Per channel row of this wave: mean over its
-  //      TP*32 positions (DPP butterfly over the 32 lanes that hold the row), then the sum of squares centred at that mean --
-  //      a two-pass variance on values that are still in registers.  The WGP waves that share the row combine their
-  //      (mean, M2) through LDS with the pairwise update of Chan et al. (equal counts).  No E[x^2] - mean^2 anywhere. ----
-  if (a.gn_stats != nullptr && !to_partial) {
-    float* st_lds = smem;   // [WGP][BM][2]: the stage buffers are idle (the K loop ended with a barrier)
-    constexpr float inv_cnt = 1.0f / (float)(TP * 32);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = acc_at(i, 0)[r];
-#pragma unroll
-        for (int j = 1; j < TP; ++j) s += acc_at(i, j)[r];
-        const float mean = emo_sum32(s) * inv_cnt;
-        float m2 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < TP; ++j) { const float d = acc_at(i, j)[r] - mean; m2 = __fmaf_rn(d, d, m2); }
-        m2 = emo_sum32(m2);
-        if (l32 == 0) {
-          const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          *reinterpret_cast<float2*>(st_lds + (wp * BM + m) * 2) = make_float2(mean, m2);
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < BM) {
-      const int co = cotile * BM + tid;
-      if (co < a.Cout) {
-        float mean = 0.0f, m2 = 0.0f;
-#pragma unroll
-        for (int w = 0; w < WGP; ++w) mean += st_lds[(w * BM + tid) * 2 + 0];
-        mean *= 1.0f / (float)WGP;
-#pragma unroll
-        for (int w = 0; w < WGP; ++w) {
-          const float d = st_lds[(w * BM + tid) * 2 + 0] - mean;
-          m2 += st_lds[(w * BM + tid) * 2 + 1] + (float)(TP * 32) * d * d;
-        }
-        const long nptiles = (long)a.tiles_x * a.tiles_y * a.tiles_z;
-        float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)n * nptiles + ptile) * a.Cout + co;
-        *dst = make_float2(mean, m2);
-      }
-    }
-  }
+  conv_epilogue<TZ, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
 }
 
 #undef acc_at

@@ -2,21 +2,29 @@
 // BASELINE.json configs[4] ("stage_2 refinement ... fp16 MFMA convs").  Opt-in per layer (PackedConv(precision="f16"));
 // the exact-fp32 kernel of conv_igemm.h stays the default everywhere and is what bench.py measures.
 //
-// Same tiling, staging map, block order, K split and epilogue as conv_igemm.h; what changes is the operand format:
-//   * activations stay fp32 NC(D)HW in HBM; the staging applies the producer's norm + ReLU in fp32 exactly as before and
-//     converts to fp16 (round-to-nearest-even) on the way into LDS;
-//   * v_mfma_f32_32x32x8_f16: the 8 k-values of one MFMA are 8 input CHANNELS at one tap; lane (l&31, l>>5) holds the four
-//     consecutive channels 4*(l>>5) .. +3 of its row / column, so both operands are one aligned 8-byte LDS read:
-//       patch   Ph[channel group of 4][patch element][4]   (wave w writes channel 4g + w: ds_write_b16)
-//       weights Ah[k-group of 8][tap][half][BM][4]          (packed like that on the host, copied by LDS-DMA)
-//   * a stage is KC = 8 (3x3) or 32 (1x1) channels: per wave 18 / 36 MFMAs of 32 cycles instead of 36 / 72 of 64.
-// Rounding: operands carry 11 significand bits (activations saturate at +-65504 instead of overflowing to inf), products
-// and sums are exact fp32 MFMA accumulation; measured error on the decoder layer shapes ~3e-4 of max|out|
-// (tests/test_kernels_gpu.py).
+// Round-2 kernel.  Same GEMM view, block order, K split and epilogue (shared: conv_epilogue, incl. the GroupNorm tile
+// statistics) as conv_igemm.h; what differs is the operand path:
+//   * v_mfma_f32_32x32x16_f16 (the gfx950 2xK form; the round-1 kernel used 32x32x8 = half the rate): the 16 k-values of one
+//     MFMA are 16 input CHANNELS at one tap, lane (l&31, l>>5) holds the 8 consecutive channels 8*(l>>5) .. +7 of its row /
+//     column, so both operands are one aligned 16-byte LDS read (ds_read_b128, consecutive lanes = consecutive 16 bytes):
+//       weights Ah[q][tap][half][BM][8]     packed like that on the host, copied by LDS-DMA
+//       patch   Ph[group = 2q + half][patch position][8]
+//   * activations stay fp32 NC(D)HW in HBM.  Staging is by (position, 8-channel group) ITEMS, a lane owning the 8 channels
+//     of one position: 8 coalesced global dword loads (one per channel plane), the producer's GroupNorm affine + ReLU in
+//     fp32, zero padding, saturation to +-65504, round-to-nearest-even to fp16 and ONE 16-byte ds_write -- the round-1
+//     kernel staged channel planes per wave and paid one ds_write_b16 per element, which (not the matrix pipe) bounded it at
+//     0.16-0.22 of the fp16 peak.  The 8 + 8 scale / shift values of an item are wave-uniform: one vector load per stage,
+//     broadcast with v_readlane.
+//   * a stage is KC = 16 channels (3x3: 9 MFMA steps of K = 16) or 32 (1x1: 2 steps); tile 64 output channels x 256
+//     positions (the fp32 kernel's config D), 2 blocks per CU (LDS: 18 KB weights + 16 KB patch per stage, double-buffered).
+//   * same software pipeline as the fp32 kernel: LDS-DMA of the weights and pinned-asm loads of the patch of stage s+1 at
+//     the top of stage s, transform + ds_write after 5/8 of the MFMAs, one barrier per stage.
+// Needs Cin % 8 == 0 (whole channel groups).  Rounding: operands carry 11 significand bits, products and sums are exact
+// fp32 MFMA accumulation.
 #pragma once
 #include "conv_igemm.h"
 
-typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
 struct ConvCfgH {
@@ -25,28 +33,37 @@ struct ConvCfgH {
   static constexpr int TAPS = KH * KW;
   static constexpr int PR = TR + KH - 1;
   static constexpr int PW = TW + KW - 1;
-  static constexpr int CHS = TZ * PR * PW;               // patch elements per input channel
-  static constexpr int KG = KC / 8;                      // k-groups (one MFMA per k-group, tap and 32x32 tile)
-  static constexpr int CPW = KC / 4;                     // channels staged per wave: c = 4 g + wave
-  static constexpr int EPC = (CHS + 63) / 64;
-  static constexpr int NPE = CPW * EPC;
+  static constexpr int CHS = TZ * PR * PW;               // patch positions
+  static constexpr int KQ = KC / 16;                     // MFMA k-steps (16 channels each) per tap and stage
+  static constexpr int NG = KC / 8;                      // 8-channel groups per stage: group = 2 q + half
+  static constexpr int CPG = (CHS + 63) / 64;            // 64-position chunks per group
+  static constexpr int WIT = NG * CPG;                   // wave-items (64 positions x 8 channels) per stage
+  static constexpr int IPW = (WIT + 3) / 4;              // items per wave: waves w, w + 4, ...
+  static constexpr int NSTEPS = KQ * TAPS;
   static constexpr int ASZ_H = KC * TAPS * BM;           // halfs of one stage's weight tile
-  static constexpr int PATCH_H = KC * CHS;               // halfs of one stage's patch
+  static constexpr int PSZ_H = NG * CHS * 8;             // halfs of one stage's patch
   static constexpr int ASZ = ASZ_H / 2;                  // in floats
-  static constexpr int BUF = ASZ + (((PATCH_H + 1) / 2 + 3) & ~3);
+  static constexpr int BUF = ASZ + ((PSZ_H / 2 + 3) & ~3);
+  static constexpr int LDS_BYTES = (2 * BUF + 256) * 4;  // two stage buffers + 64 16-byte dump slots
+  static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
+  static constexpr int OCC = BY_LDS < 1 ? 1 : (BY_LDS > 3 ? 3 : BY_LDS);
   static_assert(WGM * WGP == 4, "4 waves per block");
   static_assert(TZ * TR * TW == BP, "position tile must equal BP");
-  static_assert(KC % 8 == 0, "whole k-groups of 8 channels");
-  static_assert(ASZ_H % 8 == 0, "weight tile must be 16-byte copyable");
+  static_assert(KC % 16 == 0, "whole 16-channel MFMA steps");
+  static_assert((ASZ_H * 2) % 16 == 0, "weight tile must be 16-byte copyable");
   static_assert(TM * TP <= 4, "accumulator budget");
+  static_assert(2 * BUF >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the stage buffers");
 };
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(ConvCfgH<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>::OCC,
+                                   ConvCfgH<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>::OCC)))
 void conv_igemm_f16_kernel(const ConvArgs a) {
   using Cfg = ConvCfgH<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
-  constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS, KG = Cfg::KG;
-  constexpr int ASZ = Cfg::ASZ, ASZ_H = Cfg::ASZ_H, BUF = Cfg::BUF, NPE = Cfg::NPE, CPW = Cfg::CPW, EPC = Cfg::EPC;
+  constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS;
+  constexpr int ASZ = Cfg::ASZ, ASZ_H = Cfg::ASZ_H, BUF = Cfg::BUF, CPG = Cfg::CPG, WIT = Cfg::WIT, IPW = Cfg::IPW;
+  constexpr int NSTEPS = Cfg::NSTEPS;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -72,6 +89,7 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   const int nptiles = a.tiles_x * a.tiles_y * a.tiles_z;
   const int n = rest / nptiles;
   int bx = rest - n * nptiles;
+  const int ptile = bx;
   const int tx = bx % a.tiles_x; bx /= a.tiles_x;
   const int ty = bx % a.tiles_y; bx /= a.tiles_y;
   const int tz = bx;
@@ -86,24 +104,29 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : a.x;
   const float relu_floor = a.relu_in ? 0.0f : -__builtin_huge_valf();
 
-  unsigned p_off[EPC];
-  int p_pz[EPC];
-  bool p_ok[EPC];
+  // ---- staging map: wave-item wi = wave + 4 k covers channel group wi / CPG and patch positions (wi % CPG) * 64 + lane.
+  //      The position part is the same in every stage: plane offset and validity once per thread. ----
+  unsigned p_off[IPW];
+  int p_pz[IPW];
+  bool p_ok[IPW];
+  int p_e[IPW];
 #pragma unroll
-  for (int i = 0; i < EPC; ++i) {
-    const int e = lane + i * 64;
+  for (int k = 0; k < IPW; ++k) {
+    const int wi = wave + 4 * k;
+    const int e = (wi % CPG) * 64 + lane;
     const int pz = e / (PR * PW);
     const int rem2 = e - pz * (PR * PW);
     const int pr = rem2 / PW;
     const int pc = rem2 - pr * PW;
     const int yl = y0 + pr - (KH >> 1);
     const int xl = x0 + pc - (KW >> 1);
-    const bool ok = (e < CHS) && ((unsigned)yl < (unsigned)a.Hl) && ((unsigned)xl < (unsigned)a.Wl);
+    const bool ok = (wi < WIT) && (e < CHS) && ((unsigned)yl < (unsigned)a.Hl) && ((unsigned)xl < (unsigned)a.Wl);
     const int ys = UPS ? (yl >> 1) : yl;
     const int xs = UPS ? (xl >> 1) : xl;
-    p_ok[i] = ok;
-    p_off[i] = ok ? (unsigned)(ys * a.W + xs) * 4u : 0u;
-    p_pz[i] = pz;
+    p_ok[k] = ok;
+    p_off[k] = ok ? (unsigned)(ys * a.W + xs) * 4u : 0u;
+    p_pz[k] = pz;
+    p_e[k] = e;
   }
 
   const int nstages_all = a.n_cchunks * a.KD;
@@ -111,40 +134,52 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   const int st_end = min(nstages_all, st_begin + a.stages_per_split);
   const char* wsrc = reinterpret_cast<const char*>(a.wpk) + ((long)cotile * nstages_all) * (ASZ_H * 2);
 
-  _Float16* const dumph = reinterpret_cast<_Float16*>(smem + 2 * BUF) + lane;   // per-lane dump slot (written, never read)
+  halfx8* const dump8 = reinterpret_cast<halfx8*>(smem + 2 * BUF) + lane;   // per-lane dump slot (written, never read)
 
-  float pv[NPE];
-  bool pvz[NPE];
-  bool sv[CPW];
-  float sc[CPW], sh[CPW];
+  float pv[IPW][8];   // raw patch values of the next stage (pinned asm loads)
+  bool pvz[IPW];      // depth slice of the item inside the volume
+  bool gv[IPW];       // wave-uniform: the item's channel group exists
+  float scv, shv;     // lane l (mod 32): scale / shift of channel ci0 + l of the next stage (broadcast with v_readlane)
 
 #define EMO_H_ISSUE_PATCH(stage_)                                                                     \
   {                                                                                                   \
     const int cc_ = (stage_) / a.KD;                                                                  \
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
     const int ci0_ = cc_ * KC;                                                                        \
-    _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
-      const int c_ = ci0_ + g * 4 + wave;                                                             \
-      const bool cv_ = c_ < a.Cin;                                                                    \
-      const int cs_ = cv_ ? c_ : 0;                                                                   \
-      const int zu_ = z0 + t_ - padD;                                                                 \
-      const bool zv_ = (unsigned)zu_ < (unsigned)a.D;                                                 \
-      const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;            \
-      sv[g] = cv_ && (TZ > 1 || zv_);                                                                 \
-      { const float s1_ = scale_n[cs_], s0_ = shift_n[cs_];                                           \
-        sc[g] = has_affine ? s1_ : 1.0f; sh[g] = has_affine ? s0_ : 0.0f; }                           \
-      _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
-        if (TZ == 1) {                                                                                \
-          pvz[g * EPC + i] = true;                                                                    \
-          pv[g * EPC + i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + p_off[i]); \
-        } else {                                                                                      \
-          const int zi = zu_ + p_pz[i];                                                               \
-          const bool zok = (unsigned)zi < (unsigned)a.D;                                              \
-          pvz[g * EPC + i] = zok;                                                                     \
-          pv[g * EPC + i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + (p_off[i] + (unsigned)((zok ? zi : 0) * HW) * 4u)); \
-        }                                                                                             \
-      }                                                                                               \
+    {                                                                                                 \
+      const int cl_ = min(ci0_ + (lane & 31), a.Cin - 1);                                             \
+      scv = emo_gload_pinned(scale_n, (unsigned)cl_ * 4u);                                            \
+      shv = emo_gload_pinned(shift_n, (unsigned)cl_ * 4u);                                            \
     }                                                                                                 \
+    const int zu_ = z0 + t_ - padD;                                                                   \
+    const bool zv_ = (unsigned)zu_ < (unsigned)a.D;                                                   \
+    _Pragma("unroll") for (int k = 0; k < IPW; ++k) {                                                 \
+      const int wi_ = wave + 4 * k;                                                                   \
+      const int g_ = wi_ / CPG;                                                                       \
+      const int c0_ = ci0_ + g_ * 8;                                                                  \
+      const bool cv_ = (wi_ < WIT) && (c0_ < a.Cin);                                                  \
+      const int cs_ = cv_ ? c0_ : 0;                                                                  \
+      gv[k] = cv_ && (TZ > 1 || zv_);                                                                 \
+      unsigned off_ = p_off[k];                                                                       \
+      if (TZ == 1) {                                                                                  \
+        pvz[k] = true;                                                                                \
+      } else {                                                                                        \
+        const int zi = zu_ + p_pz[k];                                                                 \
+        const bool zok = (unsigned)zi < (unsigned)a.D;                                                \
+        pvz[k] = zok;                                                                                 \
+        off_ += (unsigned)((zok ? zi : 0) * HW) * 4u;                                                 \
+      }                                                                                               \
+      const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;            \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) pv[k][u] = emo_gload_pinned(base_ + (long)u * DHW, off_); \
+    }                                                                                                 \
+  }
+
+#define EMO_H_WAIT_PATCH()                                                                            \
+  {                                                                                                   \
+    emo_wait_vmem0();                                                                                 \
+    emo_touch(scv); emo_touch(shv);                                                                   \
+    _Pragma("unroll") for (int k = 0; k < IPW; ++k)                                                   \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(pv[k][u]);                              \
   }
 
 // weight tile of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
@@ -161,40 +196,52 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
     }                                                                                                 \
   }
 
-// transform in fp32, round to fp16, one ds_write_b16 per element: Ph[(g * CHS + e) * 4 + wave]
+// transform in fp32 (affine of the producer's GroupNorm, ReLU, zero padding, saturation), round to fp16, ONE 16-byte
+// ds_write per item: Ph[(g * CHS + e) * 8 .. + 7]
 #define EMO_H_STORE_PATCH(buf_)                                                                       \
   {                                                                                                   \
-    _Float16* Ph_ = reinterpret_cast<_Float16*>((buf_) + ASZ);                                        \
-    _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
-      _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
-        const int e = lane + i * 64;                                                                  \
-        float v = fmaxf(__fmaf_rn(pv[g * EPC + i], sc[g], sh[g]), relu_floor);                        \
-        v = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                        \
+    halfx8* Ph_ = reinterpret_cast<halfx8*>((buf_) + ASZ);                                            \
+    const int scb_ = __builtin_bit_cast(int, scv), shb_ = __builtin_bit_cast(int, shv);               \
+    _Pragma("unroll") for (int k = 0; k < IPW; ++k) {                                                 \
+      const int wi_ = wave + 4 * k;                                                                   \
+      const int g_ = wi_ / CPG;                       /* wave-uniform */                             \
+      const bool keep_ = p_ok[k] && gv[k] && pvz[k];                                                  \
+      halfx8 h_;                                                                                      \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                 \
+        const int cl_ = (g_ * 8 + u) & 31;            /* channel within the stage: lane cl_ holds its scale / shift */ \
+        const float sc_ = has_affine ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(scb_, cl_)) : 1.0f;       \
+        const float sh_ = has_affine ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(shb_, cl_)) : 0.0f;       \
+        float v = fmaxf(__fmaf_rn(pv[k][u], sc_, sh_), relu_floor);                                   \
+        v = keep_ ? v : 0.0f;                         /* zero padding applies to the transformed tensor */ \
         v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);   /* saturate instead of overflowing to inf */ \
-        _Float16* d_ = ((i + 1) * 64 <= CHS || e < CHS) ? Ph_ + ((g * CHS + e) * 4 + wave) : dumph;   \
-        *d_ = (_Float16)v;                                                                            \
+        h_[u] = (_Float16)v;                                                                          \
       }                                                                                               \
+      halfx8* d_ = (wi_ < WIT && p_e[k] < CHS) ? Ph_ + (g_ * CHS + p_e[k]) : dump8;                   \
+      *d_ = h_;                                                                                       \
     }                                                                                                 \
   }
 
-  EMO_H_ISSUE_PATCH(st_begin);
+  constexpr int STORE_STEP = (NSTEPS * EMO_CONV_STORE_EIGHTHS) / 8;
+
+  // ---- prologue: stage st_begin into buffer 0 ----
   EMO_H_ISSUE_WEIGHTS(st_begin, smem);
+  EMO_H_ISSUE_PATCH(st_begin);
+  EMO_H_WAIT_PATCH();
   EMO_H_STORE_PATCH(smem);
-  {
-    const int st1_ = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
-    EMO_H_ISSUE_PATCH(st1_);
-  }
   __syncthreads();
 
-  floatx16 acc[TM][TP];
+  constexpr int TPH = TP > 2 ? TP / 2 : TP;
+  floatx16 acc_lo[TM][TPH], acc_hi[TM][TPH];
+#define acc_at(i_, j_) ((j_) < TPH ? acc_lo[i_][(j_) < TPH ? (j_) : 0] : acc_hi[i_][(j_) >= TPH ? (j_) - TPH : 0])
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TP; ++j)
+    for (int j = 0; j < TPH; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
 
-  const int a_base = half * BM + m0 + l32;   // in units of 4 halfs
+  // lane bases into the LDS tiles, in units of 8 halfs (16 bytes)
+  const int a_base = half * BM + m0 + l32;
   int b_base[TP];
 #pragma unroll
   for (int j = 0; j < TP; ++j) {
@@ -208,82 +255,50 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   for (int st = st_begin; st < st_end; ++st) {
     float* cur = smem + ((st - st_begin) & 1) * BUF;
     float* nxt = smem + ((st - st_begin + 1) & 1) * BUF;
-    const int stn = (st + 1) < st_end ? (st + 1) : st;
-    const halfx4* Ah = reinterpret_cast<const halfx4*>(cur);
-    const halfx4* Ph = reinterpret_cast<const halfx4*>(cur + ASZ);
+    const int stn = (st + 1) < st_end ? (st + 1) : st;   // clamped prefetch on the last stage: harmless re-stage
+    const halfx8* Ah = reinterpret_cast<const halfx8*>(cur);
+    const halfx8* Ph = reinterpret_cast<const halfx8*>(cur + ASZ);
     EMO_H_ISSUE_WEIGHTS(stn, nxt);
+    EMO_H_ISSUE_PATCH(stn);
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int q = 0; q < KG; ++q) {
-#pragma unroll
-      for (int r = 0; r < KH; ++r) {
-#pragma unroll
-        for (int s = 0; s < KW; ++s) {
-          const int tap = r * KW + s;
-          halfx4 av_[TM], bv_[TP];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) av_[i] = Ah[a_base + ((q * TAPS + tap) * 2) * BM + i * 32];
-#pragma unroll
-          for (int j = 0; j < TP; ++j) bv_[j] = Ph[b_base[j] + (q * 2) * CHS + r * PW + s];
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(av_[i], bv_[j], acc[i][j], 0, 0, 0);
-        }
+    for (int step = 0; step < NSTEPS; ++step) {
+      if (step == STORE_STEP) {
+        if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
+        EMO_H_WAIT_PATCH();
+        EMO_H_STORE_PATCH(nxt);
+        if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
       }
+      const int q = step / TAPS, tap = step % TAPS;
+      const int r = tap / KW, s = tap % KW;
+      halfx8 av_[TM], bv_[TP];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av_[i] = Ah[a_base + ((q * TAPS + tap) * 2) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TP; ++j) bv_[j] = Ph[b_base[j] + (q * 2) * CHS + r * PW + s];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+          acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x16_f16(av_[i], bv_[j], acc_at(i, j), 0, 0, 0);
     }
-    EMO_H_STORE_PATCH(nxt);   // stage st+1 (loaded during the previous stage)
-    {
-      const int stn2 = (st + 2) < st_end ? (st + 2) : (st_end - 1);
-      EMO_H_ISSUE_PATCH(stn2);
-    }
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 #undef EMO_H_ISSUE_PATCH
+#undef EMO_H_WAIT_PATCH
 #undef EMO_H_ISSUE_WEIGHTS
 #undef EMO_H_STORE_PATCH
+#undef acc_at
 
-  // ---- epilogue (same as conv_igemm.h): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
-  const long plane = (long)a.Hl * a.Wl;
-  const long ovol = (long)a.Dl * plane;
-#pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int p = p0 + j * 32 + l32;
-    const int col = p % TW;
-    const int row = (p / TW) % TR;
-    const int pz = p / (TW * TR);
-    const int z = z0 + pz, y = y0 + row, x = x0 + col;
-    const long sp = (long)z * plane + (long)y * a.Wl + x;
-    long rsp = sp;
-    long rvol = ovol;
-    if (a.res_ups) {
-      const int Wr = a.Wl >> 1, Hr = a.Hl >> 1;
-      rsp = ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
-      rvol = (long)a.Dl * Hr * Wr;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cotile * BM + m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a.Cout && a.partial) {
-          a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc[i][j][r];
-        } else if (co < a.Cout) {
-          float v = acc[i][j][r];
-          if (a.bias) v += a.bias[co];
-          if (a.res) v += a.res[((long)n * a.Cout + co) * rvol + rsp];
-          v = emo_act(v, a.act);
-          a.out[((long)n * a.Cout + co) * ovol + sp] = v;
-        }
-      }
-    }
-  }
+  conv_epilogue<TZ, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
 }
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
 int conv_igemm_f16_launch(ConvArgs a, hipStream_t s) {
   using Cfg = ConvCfgH<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   if (a.Wl % TW || a.Hl % TR || a.Dl % TZ) return EMO_ERR_UNSUPPORTED;
+  if (a.Cin % 8) return EMO_ERR_UNSUPPORTED;   // whole 8-channel groups
   a.tiles_x = a.Wl / TW;
   a.tiles_y = a.Hl / TR;
   a.tiles_z = a.Dl / TZ;
@@ -291,21 +306,17 @@ int conv_igemm_f16_launch(ConvArgs a, hipStream_t s) {
   const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
   if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
-  const size_t lds = (size_t)(2 * Cfg::BUF + 64) * sizeof(float);   // two stage buffers + 64 dump slots
+  const size_t lds = (size_t)Cfg::LDS_BYTES;
   if (lds > 160 * 1024) return EMO_ERR_UNSUPPORTED;
   auto kern = conv_igemm_f16_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   if (lds > 64 * 1024) {
-    static bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      raised = true;
-    }
+    const int rc = emo_raise_dynamic_lds(kern);
+    if (rc != EMO_OK) return rc;
   }
   a.n_cotiles = cot;
   if (a.ksplit < 1 || (a.ksplit > 1 && !a.partial)) return EMO_ERR_BAD_ARG;
   if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }
+  if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
   if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)(nt * cot * a.N * a.ksplit)), dim3(256), lds, s, a);
   return emo_launch_status();

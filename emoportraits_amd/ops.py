@@ -227,8 +227,8 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
                out=None, ksplit=None, want_stats=False):
     """layer: emoportraits_amd.pack.PackedConv.  x [N,Cin,H,W] or [N,Cin,D,H,W].
     ksplit: K-loop split of the launch (None: pack.plan_launch decides together with the block config).
-    want_stats: also return the TileStats of the output (None when this launch cannot produce them: K-split launches
-    and the fp16-operand kernel) -> (out, stats)."""
+    want_stats: also return the TileStats of the output (None when this launch cannot produce them: K-split launches)
+    -> (out, stats)."""
     lib = hip.load()
     hip.require_cuda_f32(x, scale, shift, res)
     three_d = x.dim() == 5
@@ -252,26 +252,20 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
             raise ValueError("bad residual shape")
     positions = N * D * Hl * Wl
-    cfg, ks = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl, ups)
+    cfg, ks, prec = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl, ups)
     if ksplit is not None:
         ks = int(ksplit)
     ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None
     stats = None
-    if layer.precision == "f16":
-        rc = lib.emo_conv_igemm_f16acc32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
-                                         hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
-                                         layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
-                                         hip.ptr(ws), hip.current_stream())
-    else:
-        bp = pack_mod._BP[cfg]
-        if want_stats and ks == 1 and (D * Hl * Wl) % bp == 0:
-            stats = TileStats(torch.empty((N, D * Hl * Wl // bp, layer.cout, 2), device=x.device, dtype=torch.float32), bp)
-        rc = lib.emo_conv_igemm_f32(hip.ptr(x), hip.ptr(layer.packed(cfg)), hip.ptr(layer.bias), hip.ptr(scale),
-                                    hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
-                                    layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
-                                    hip.ptr(ws), hip.ptr(stats.stats) if stats is not None else None,
-                                    hip.current_stream())
-    hip.check(rc, f"emo_conv_igemm_{layer.precision}[{layer.name}]")
+    bp = pack_mod._BP[cfg]
+    if want_stats and ks == 1 and (D * Hl * Wl) % bp == 0:
+        stats = TileStats(torch.empty((N, D * Hl * Wl // bp, layer.cout, 2), device=x.device, dtype=torch.float32), bp)
+    entry = lib.emo_conv_igemm_f16acc32 if prec == "f16" else lib.emo_conv_igemm_f32
+    rc = entry(hip.ptr(x), hip.ptr(layer.packed(cfg, prec)), hip.ptr(layer.bias), hip.ptr(scale),
+               hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
+               layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
+               hip.ptr(ws), hip.ptr(stats.stats) if stats is not None else None, hip.current_stream())
+    hip.check(rc, f"emo_conv_igemm_{prec}[{layer.name}]")
     return (out, stats) if want_stats else out
 
 

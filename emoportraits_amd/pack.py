@@ -85,8 +85,8 @@ def conv_pack_info_f16(kh, kw, cfg):
 
 
 def pack_weight_f16(w, cfg):
-    """fp16 operand layout of emo_conv_igemm_f16acc32: [co_tile][cin chunk][kd][k-group of 8][tap][half][BM][4] with
-    channel-in-chunk = 8*group + 4*half + 0..3  ->  flat fp16 tensor (round-to-nearest-even of the folded fp32 weight)"""
+    """fp16 operand layout of emo_conv_igemm_f16acc32: [co_tile][cin chunk][kd][q][tap][half][BM][8] with
+    channel-in-chunk = 16*q + 8*half + 0..7  ->  flat fp16 tensor (round-to-nearest-even of the folded fp32 weight)"""
     if w.dim() == 4:
         w = w.unsqueeze(2)
     cout, cin, kd, kh, kw = w.shape
@@ -95,8 +95,8 @@ def pack_weight_f16(w, cfg):
     n_cc = -(-cin // kc)
     wp = torch.zeros((n_cot * bm, n_cc * kc, kd, kh * kw), dtype=torch.float32)
     wp[:cout, :cin] = w.reshape(cout, cin, kd, kh * kw).float()
-    # [cot, BM, cc, group, half, k4, kd, tap] -> [cot, cc, kd, group, tap, half, BM, k4]
-    wp = wp.view(n_cot, bm, n_cc, kc // 8, 2, 4, kd, kh * kw).permute(0, 2, 6, 3, 7, 4, 1, 5).contiguous()
+    # [cot, BM, cc, q, half, k8, kd, tap] -> [cot, cc, kd, q, tap, half, BM, k8]
+    wp = wp.view(n_cot, bm, n_cc, kc // 16, 2, 8, kd, kh * kw).permute(0, 2, 6, 3, 7, 4, 1, 5).contiguous()
     return wp.view(-1).to(torch.float16)
 
 
@@ -130,16 +130,16 @@ if __import__("os").environ.get("EMO_CONV_CFG_E") == "1":   # A/B switch: plan w
 _FILL_BLOCKS = 512   # 2 blocks per CU on 256 CUs
 
 
-def cfg_d_fits(kd, kh, kw, Hl, Wl, precision="f32"):
+def cfg_d_fits(kd, kh, kw, Hl, Wl):
     """the 64 x 256 (and 32 x 256) tiles exist for 3x3 / 3x3x3 fp32 layers whose output planes are tiled by 2x128 / 4x64 /
     8x32 positions (the depth taps of a 3-D layer run as K stages, one depth slice per tile)"""
-    if precision != "f32" or kd not in (1, 3) or (kh, kw) != (3, 3) or Hl is None:
+    if kd not in (1, 3) or (kh, kw) != (3, 3) or Hl is None:
         return False
     return (Wl % 128 == 0 and Hl % 2 == 0) or (Wl == 64 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0)
 
 
-def cfg_e_fits(kd, kh, kw, Hl, Wl, precision="f32"):
-    if precision != "f32" or kd != 1 or (kh, kw) != (3, 3) or Hl is None:
+def cfg_e_fits(kd, kh, kw, Hl, Wl):
+    if kd != 1 or (kh, kw) != (3, 3) or Hl is None:
         return False
     return (Wl % 128 == 0 and Hl % 4 == 0) or (Wl == 64 and Hl % 8 == 0)
 
@@ -209,15 +209,25 @@ def conv_precision(precision):
         _build_precision = old
 
 
-def supports_f16(cout, kd, kh, kw):
-    return (kh, kw) in ((3, 3), (1, 1)) and kd in (1, 3) and cout >= 32
+def supports_f16(cout, cin, kd, kh, kw):
+    """layers the fp16-operand kernel can take at all (whether a given LAUNCH runs on it also depends on the output width:
+    PackedConv.plan_for)"""
+    return (kh, kw) in ((3, 3), (1, 1)) and kd in (1, 3) and not (kd == 3 and kh == 1) and cout >= 32 and cin % 8 == 0
+
+
+def f16_launch_fits(Hl, Wl):
+    """output planes tiled by the 64 x 256 tile of the fp16-operand kernel: 2x128 / 4x64 / 8x32 positions"""
+    if Hl is None:
+        return False
+    return (Wl % 128 == 0 and Hl % 2 == 0) or (Wl == 64 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0)
 
 
 class PackedConv:
     """One convolution of the hot path, ready for emo_conv_igemm_f32.  Weights are packed lazily per block config
     (the best config depends on the batch size of the call); `cfg` pins one config (tests / benchmarks).
-    precision="f16" (opt-in, BASELINE configs[4]): fp16 MFMA operands with fp32 accumulation, emo_conv_igemm_f16acc32;
-    available for 3x3 / 1x1 kernels on the 128- and 64-row configs, anything else raises."""
+    precision="f16" (opt-in, BASELINE configs[4]): fp16 MFMA operands with fp32 accumulation, emo_conv_igemm_f16acc32, on
+    every launch whose output planes the 64 x 256 tile covers (widths that are multiples of 128, or 64 / 32); other launches
+    of the layer (the 16- and 8-wide WarpGenerator maps) run the exact-fp32 kernel."""
 
     def __init__(self, name, weight, bias, device, cfg=None, precision="f32"):
         if weight.dim() == 4:
@@ -233,20 +243,27 @@ class PackedConv:
         self.pinned_cfg = cfg
         if precision not in ("f32", "f16"):
             raise ValueError("precision must be 'f32' or 'f16'")
-        if precision == "f16" and ((kh, kw) not in ((3, 3), (1, 1)) or kd not in (1, 3) or cfg == CFG_C):
-            raise ValueError(f"{name}: the fp16-operand kernel covers 3x3 / 1x1 convolutions on block configs 0 and 1")
+        if precision == "f16" and not supports_f16(cout, cin, kd, kh, kw):
+            raise ValueError(f"{name}: the fp16-operand kernel covers 3x3 / 3x3x3 / 1x1 convolutions with >= 32 output "
+                             f"channels and a multiple of 8 input channels")
         self.precision = precision
-        self.allowed = (CFG_A, CFG_B) if ((kh, kw) == (1, 7) or precision == "f16") else (CFG_A, CFG_B, CFG_C)
+        self.allowed = (CFG_A, CFG_B) if (kh, kw) == (1, 7) else (CFG_A, CFG_B, CFG_C)
         self.bias = None if bias is None else bias.float().contiguous().to(device)
         self.macs_per_position = cout * cin * kd * kh * kw
-        first = choose_cfg(cout) if cfg is None else cfg
-        self.packed(first if first in self.allowed else CFG_B)
+        if precision == "f32":
+            first = choose_cfg(cout) if cfg is None else cfg
+            self.packed(first if first in self.allowed else CFG_B)
 
-    def packed(self, cfg):
+    def packed(self, cfg, precision="f32"):
+        """packed weights for a block config: fp32 layout, or the fp16 operand layout (64 x 256 tile only)"""
+        if precision == "f16":
+            key = ("f16", CFG_D)
+            if key not in self._packed:
+                self._packed[key] = pack_weight_f16(self._weight, CFG_D).to(self.device)
+            return self._packed[key]
         cfg = _PACK_AS.get(cfg, cfg)
         if cfg not in self._packed:
-            fn = pack_weight_f16 if self.precision == "f16" else pack_weight
-            self._packed[cfg] = fn(self._weight, cfg).to(self.device)
+            self._packed[cfg] = pack_weight(self._weight, cfg).to(self.device)
         return self._packed[cfg]
 
     def cfg_for(self, n_pos_tiles):
@@ -255,15 +272,19 @@ class PackedConv:
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
     def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False):
-        """(cfg, ksplit) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output"""
+        """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output"""
+        if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D):
+            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), "f16")
+            return cfg, ks, "f16"
         allowed = (self.pinned_cfg,) if self.pinned_cfg is not None else self.allowed
-        if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl, self.precision):
+        if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl):
             allowed = allowed + (CFG_D,)
             if _CFG_EFF[CFG_F] > 0 and (not ups or Wl % 128 == 0):
                 allowed = allowed + (CFG_F,)
-        if self.pinned_cfg is None and _CFG_EFF[CFG_E] > 0 and cfg_e_fits(self.kd, self.kh, self.kw, Hl, Wl, self.precision):
+        if self.pinned_cfg is None and _CFG_EFF[CFG_E] > 0 and cfg_e_fits(self.kd, self.kh, self.kw, Hl, Wl):
             allowed = allowed + (CFG_E,)
-        return plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, allowed, self.precision)
+        cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, allowed, "f32")
+        return cfg, ks, "f32"
 
     @classmethod
     def from_state_dict(cls, sd, prefix, kind, device, cfg=None, precision=None):
@@ -271,5 +292,5 @@ class PackedConv:
         w, b = folded_conv(sd, prefix, kind)
         if precision is None:
             kd = w.shape[2] if w.dim() == 5 else 1
-            precision = _build_precision if supports_f16(w.shape[0], kd, w.shape[-2], w.shape[-1]) else "f32"
+            precision = _build_precision if supports_f16(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1]) else "f32"
         return cls(prefix, w, b, device, cfg, precision)

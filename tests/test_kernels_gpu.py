@@ -159,36 +159,58 @@ def test_conv_split_k_equals_single_pass(case, ksplit):
 
 
 @pytest.mark.parametrize("case", [
-    dict(N=2, Cin=40, Cout=72, dims=(64, 64), k=3, cfg=0, affine=True, relu_in=True, res=True),
-    dict(N=2, Cin=64, Cout=40, dims=(16, 16), k=3, cfg=1, ups=True, res=True, res_ups=True, act="tanh"),
-    dict(N=1, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=1, affine=True, relu_in=True),
-    dict(N=1, Cin=70, Cout=33, dims=(8, 8, 8), k=3, cfg=1, affine=True, relu_in=True, bias=False),
-    dict(N=1, Cin=200, Cout=48, dims=(32, 32), k=1, cfg=1, act="sigmoid"),
-    dict(N=2, Cin=96, Cout=130, dims=(64, 64), k=1, cfg=0, ups=True),
-    dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=0, affine=True, relu_in=True, ksplit=3),
+    dict(N=2, Cin=40, Cout=72, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),
+    dict(N=2, Cin=64, Cout=40, dims=(16, 16), k=3, cfg=3, ups=True, res=True, res_ups=True, act="tanh"),
+    dict(N=1, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=3, affine=True, relu_in=True),
+    dict(N=1, Cin=72, Cout=33, dims=(8, 32, 32), k=3, cfg=3, affine=True, relu_in=True, bias=False),
+    dict(N=1, Cin=200, Cout=48, dims=(32, 32), k=1, cfg=3, act="sigmoid"),
+    dict(N=2, Cin=96, Cout=130, dims=(64, 64), k=1, cfg=3, ups=True),
+    dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, ksplit=3),
+    dict(N=1, Cin=24, Cout=64, dims=(256, 256), k=3, cfg=3, affine=True, relu_in=True, res=True),
 ])
 def test_conv_fp16_operands(case):
-    """opt-in reduced-precision mode (BASELINE configs[4]): fp16 MFMA operands, fp32 accumulation.  Operand rounding is
-    2^-11 relative, so the output agrees with the fp32 reference to ~1e-3 of max|out| (bound 3e-3); same fused prologue /
-    epilogue, ragged channel chunks (Cin not a multiple of 8 / 32), up-sampling gather, 3-D taps and K split."""
+    """opt-in reduced-precision mode (BASELINE configs[4]): fp16 MFMA operands (32x32x16), fp32 accumulation, 64 x 256 tile.
+    Operand rounding is 2^-11 relative, so the output agrees with the fp32 reference to ~1e-3 of max|out| (bound 3e-3); same
+    fused prologue / epilogue, ragged channel chunks (Cin a multiple of 8 but not of 16 / 32), up-sampling gather, 3-D taps
+    and K split."""
     e, got, ref = run_conv(seed=11, precision="f16", **case)
     assert got.shape == ref.shape
     print("PARITY conv fp16 operands:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
     assert e < 3e-3, e
     with pytest.raises(ValueError):
         pack.PackedConv("bad", torch.zeros(8, 8, 7, 7), None, DEV, precision="f16")
+    with pytest.raises(ValueError):
+        pack.PackedConv("bad", torch.zeros(64, 12, 3, 3), None, DEV, precision="f16")     # Cin not a multiple of 8
+
+
+def test_conv_fp16_layer_falls_back_to_fp32_on_narrow_maps_and_writes_tile_statistics():
+    """a layer built with precision='f16' runs the fp16-operand kernel where its 64 x 256 tile fits and the exact-fp32 kernel on
+    the 16- / 8-wide maps (WarpGenerator); both produce the GroupNorm tile statistics"""
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17
+    layer = pack.PackedConv("l", w, None, DEV, precision="f16")
+    assert layer.plan_for(64, 64, 64)[2] == "f16" and layer.plan_for(2, 16, 16)[2] == "f32"
+    x16 = torch.randn(1, 32, 16, 16, generator=g)
+    assert rel_err(ops.conv_igemm(x16.to(DEV), layer), F.conv2d(x16, w, padding=1)) < 2e-5          # exact fp32 path
+    x64 = torch.randn(2, 32, 64, 64, generator=g)
+    out, st = ops.conv_igemm(x64.to(DEV), layer, want_stats=True, ksplit=1)
+    assert st is not None and st.cnt == 256
+    assert 1e-5 < rel_err(out, F.conv2d(x64, w, padding=1)) < 3e-3                                   # fp16 operands
+    s1, h1 = ops.groupnorm_affine(out, stats=st)
+    s0, h0 = ops.groupnorm_affine(out)
+    assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item()
 
 
 def test_conv_fp16_operands_saturate():
     """activations beyond the fp16 range are clamped to +-65504 on the way into LDS, not turned into inf / NaN"""
-    x = torch.full((1, 8, 16, 16), 1.0e6)
-    x[0, :, 8:] = -3.0e5
+    x = torch.full((1, 8, 32, 32), 1.0e6)
+    x[0, :, 16:] = -3.0e5
     w = torch.zeros(32, 8, 3, 3)
     w[:, 0, 1, 1] = 1.0
-    layer = pack.PackedConv("sat", w, None, DEV, cfg=1, precision="f16")
+    layer = pack.PackedConv("sat", w, None, DEV, cfg=3, precision="f16")
     out = ops.conv_igemm(x.to(DEV), layer).cpu()
     assert torch.isfinite(out).all()
-    assert out[0, 0, 2, 2].item() == 65504.0 and out[0, 0, 12, 2].item() == -65504.0
+    assert out[0, 0, 2, 2].item() == 65504.0 and out[0, 0, 24, 2].item() == -65504.0
 
 
 def test_conv3d_1x1x1():
