@@ -126,6 +126,13 @@ __device__ __forceinline__ float emo_gload_pinned(const float* sbase, unsigned v
   asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   return v;
 }
+// 16-byte form (e.g. four consecutive per-channel scale values through a wave-uniform address: every lane gets the same 4)
+__device__ __forceinline__ floatx4 emo_gload4_pinned(const float* sbase, unsigned voff) {
+  floatx4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
+__device__ __forceinline__ void emo_touch4(floatx4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void emo_wait_vmem0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // makes v opaque at this point: no consumer of v is scheduled above it (volatile asm statements keep their order, so
 // after emo_wait_vmem0() this pins every use behind the wait)

@@ -37,8 +37,8 @@ struct ConvCfgH {
   static constexpr int KQ = KC / 16;                     // MFMA k-steps (16 channels each) per tap and stage
   static constexpr int NG = KC / 8;                      // 8-channel groups per stage: group = 2 q + half
   static constexpr int CPG = (CHS + 63) / 64;            // 64-position chunks per group
-  static constexpr int WIT = NG * CPG;                   // wave-items (64 positions x 8 channels) per stage
-  static constexpr int IPW = (WIT + 3) / 4;              // items per wave: waves w, w + 4, ...
+  static constexpr int PPW = (CPG + 3) / 4;              // position chunks per wave: chunks w, w + 4, ...
+  static constexpr int IPW = PPW * NG;                   // items (64 positions x 8 channels) per wave and stage
   static constexpr int NSTEPS = KQ * TAPS;
   static constexpr int ASZ_H = KC * TAPS * BM;           // halfs of one stage's weight tile
   static constexpr int PSZ_H = NG * CHS * 8;             // halfs of one stage's patch
@@ -62,7 +62,7 @@ __attribute__((amdgpu_waves_per_eu(ConvCfgH<KH, KW, KC, TZ, TR, TW, TM, TP, WGM,
 void conv_igemm_f16_kernel(const ConvArgs a) {
   using Cfg = ConvCfgH<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS;
-  constexpr int ASZ = Cfg::ASZ, ASZ_H = Cfg::ASZ_H, BUF = Cfg::BUF, CPG = Cfg::CPG, WIT = Cfg::WIT, IPW = Cfg::IPW;
+  constexpr int ASZ = Cfg::ASZ, ASZ_H = Cfg::ASZ_H, BUF = Cfg::BUF, CPG = Cfg::CPG, PPW = Cfg::PPW, NG = Cfg::NG;
   constexpr int NSTEPS = Cfg::NSTEPS;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -102,25 +102,27 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   const int padD = a.KD >> 1;
   const float* scale_n = has_affine ? a.scale + (long)n * a.Cin : a.x;
   const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : a.x;
-  const float relu_floor = a.relu_in ? 0.0f : -__builtin_huge_valf();
+  const float clamp_lo = a.relu_in ? 0.0f : -65504.0f;   // lower bound of the staged value: ReLU, or the fp16 range
 
-  // ---- staging map: wave-item wi = wave + 4 k covers channel group wi / CPG and patch positions (wi % CPG) * 64 + lane.
-  //      The position part is the same in every stage: plane offset and validity once per thread. ----
-  unsigned p_off[IPW];
-  int p_pz[IPW];
-  bool p_ok[IPW];
-  int p_e[IPW];
+  // ---- staging map: wave w stages the 64-position chunks w, w + 4, ... of the patch, for every 8-channel group of the
+  //      stage (item = (chunk, group); the group index is a compile-time constant of the unrolled loops, so the
+  //      per-channel scale / shift registers are indexed statically).  The position part is the same in every stage:
+  //      plane offset and validity once per thread. ----
+  unsigned p_off[PPW];
+  int p_pz[PPW];
+  bool p_ok[PPW];
+  int p_e[PPW];
 #pragma unroll
-  for (int k = 0; k < IPW; ++k) {
-    const int wi = wave + 4 * k;
-    const int e = (wi % CPG) * 64 + lane;
+  for (int k = 0; k < PPW; ++k) {
+    const int chunk = wave + 4 * k;
+    const int e = chunk * 64 + lane;
     const int pz = e / (PR * PW);
     const int rem2 = e - pz * (PR * PW);
     const int pr = rem2 / PW;
     const int pc = rem2 - pr * PW;
     const int yl = y0 + pr - (KH >> 1);
     const int xl = x0 + pc - (KW >> 1);
-    const bool ok = (wi < WIT) && (e < CHS) && ((unsigned)yl < (unsigned)a.Hl) && ((unsigned)xl < (unsigned)a.Wl);
+    const bool ok = (e < CHS) && ((unsigned)yl < (unsigned)a.Hl) && ((unsigned)xl < (unsigned)a.Wl);
     const int ys = UPS ? (yl >> 1) : yl;
     const int xs = UPS ? (xl >> 1) : xl;
     p_ok[k] = ok;
@@ -136,30 +138,25 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
 
   halfx8* const dump8 = reinterpret_cast<halfx8*>(smem + 2 * BUF) + lane;   // per-lane dump slot (written, never read)
 
-  float pv[IPW][8];   // raw patch values of the next stage (pinned asm loads)
-  bool pvz[IPW];      // depth slice of the item inside the volume
-  bool gv[IPW];       // wave-uniform: the item's channel group exists
-  float scv, shv;     // lane l (mod 32): scale / shift of channel ci0 + l of the next stage (broadcast with v_readlane)
+  float pv[PPW][NG][8];   // raw patch values of the next stage (pinned asm loads)
+  bool pvz[PPW];          // depth slice of the chunk inside the volume
+  bool gv[NG];            // wave-uniform: the channel group exists (and, for TZ == 1, the depth slice is inside the volume)
+  floatx4 sc4[KC / 4], sh4[KC / 4];   // scale / shift of the KC channels of the next stage, the same value in every lane
+                                      // (loaded with a wave-uniform address: no broadcast instructions)
 
 #define EMO_H_ISSUE_PATCH(stage_)                                                                     \
   {                                                                                                   \
     const int cc_ = (stage_) / a.KD;                                                                  \
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
     const int ci0_ = cc_ * KC;                                                                        \
-    {                                                                                                 \
-      const int cl_ = min(ci0_ + (lane & 31), a.Cin - 1);                                             \
-      scv = emo_gload_pinned(scale_n, (unsigned)cl_ * 4u);                                            \
-      shv = emo_gload_pinned(shift_n, (unsigned)cl_ * 4u);                                            \
+    _Pragma("unroll") for (int j = 0; j < KC / 4; ++j) {                                              \
+      const int c4_ = (ci0_ + 4 * j) < a.Cin ? (ci0_ + 4 * j) : 0;   /* Cin % 8 == 0: whole quads exist or not */ \
+      sc4[j] = emo_gload4_pinned(scale_n + c4_, 0u);                                                  \
+      sh4[j] = emo_gload4_pinned(shift_n + c4_, 0u);                                                  \
     }                                                                                                 \
     const int zu_ = z0 + t_ - padD;                                                                   \
     const bool zv_ = (unsigned)zu_ < (unsigned)a.D;                                                   \
-    _Pragma("unroll") for (int k = 0; k < IPW; ++k) {                                                 \
-      const int wi_ = wave + 4 * k;                                                                   \
-      const int g_ = wi_ / CPG;                                                                       \
-      const int c0_ = ci0_ + g_ * 8;                                                                  \
-      const bool cv_ = (wi_ < WIT) && (c0_ < a.Cin);                                                  \
-      const int cs_ = cv_ ? c0_ : 0;                                                                  \
-      gv[k] = cv_ && (TZ > 1 || zv_);                                                                 \
+    _Pragma("unroll") for (int k = 0; k < PPW; ++k) {                                                 \
       unsigned off_ = p_off[k];                                                                       \
       if (TZ == 1) {                                                                                  \
         pvz[k] = true;                                                                                \
@@ -169,17 +166,27 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
         pvz[k] = zok;                                                                                 \
         off_ += (unsigned)((zok ? zi : 0) * HW) * 4u;                                                 \
       }                                                                                               \
-      const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;            \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) pv[k][u] = emo_gload_pinned(base_ + (long)u * DHW, off_); \
+      _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                \
+        const int c0_ = ci0_ + g * 8;                                                                 \
+        const bool cv_ = c0_ < a.Cin;                                                                 \
+        const int cs_ = cv_ ? c0_ : 0;                                                                \
+        gv[g] = cv_ && (TZ > 1 || zv_);                                                               \
+        const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;          \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) pv[k][g][u] = emo_gload_pinned(base_ + (long)u * DHW, off_); \
+      }                                                                                               \
     }                                                                                                 \
   }
 
 #define EMO_H_WAIT_PATCH()                                                                            \
   {                                                                                                   \
     emo_wait_vmem0();                                                                                 \
-    emo_touch(scv); emo_touch(shv);                                                                   \
-    _Pragma("unroll") for (int k = 0; k < IPW; ++k)                                                   \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(pv[k][u]);                              \
+    _Pragma("unroll") for (int j = 0; j < KC / 4; ++j) {                                              \
+      emo_touch4(sc4[j]); emo_touch4(sh4[j]);                                                         \
+      if (!has_affine) { sc4[j] = floatx4{1.0f, 1.0f, 1.0f, 1.0f}; sh4[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; } \
+    }                                                                                                 \
+    _Pragma("unroll") for (int k = 0; k < PPW; ++k)                                                   \
+      _Pragma("unroll") for (int g = 0; g < NG; ++g)                                                  \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(pv[k][g][u]);                         \
   }
 
 // weight tile of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
@@ -196,30 +203,28 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
     }                                                                                                 \
   }
 
-// transform in fp32 (affine of the producer's GroupNorm, ReLU, zero padding, saturation), round to fp16, ONE 16-byte
-// ds_write per item: Ph[(g * CHS + e) * 8 .. + 7]
+// transform in fp32 (affine of the producer's GroupNorm, ReLU + saturation in one v_med3, zero padding), round to fp16,
+// ONE 16-byte ds_write per item: Ph[(g * CHS + e) * 8 .. + 7]
 #define EMO_H_STORE_PATCH(buf_)                                                                       \
   {                                                                                                   \
     halfx8* Ph_ = reinterpret_cast<halfx8*>((buf_) + ASZ);                                            \
-    const int scb_ = __builtin_bit_cast(int, scv), shb_ = __builtin_bit_cast(int, shv);               \
-    _Pragma("unroll") for (int k = 0; k < IPW; ++k) {                                                 \
-      const int wi_ = wave + 4 * k;                                                                   \
-      const int g_ = wi_ / CPG;                       /* wave-uniform */                             \
-      const bool keep_ = p_ok[k] && gv[k] && pvz[k];                                                  \
-      halfx8 h_;                                                                                      \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                 \
-        const int cl_ = (g_ * 8 + u) & 31;            /* channel within the stage: lane cl_ holds its scale / shift */ \
-        const float sc_ = has_affine ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(scb_, cl_)) : 1.0f;       \
-        const float sh_ = has_affine ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(shb_, cl_)) : 0.0f;       \
-        float v = fmaxf(__fmaf_rn(pv[k][u], sc_, sh_), relu_floor);                                   \
-        v = keep_ ? v : 0.0f;                         /* zero padding applies to the transformed tensor */ \
-        v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);   /* saturate instead of overflowing to inf */ \
-        h_[u] = (_Float16)v;                                                                          \
+    _Pragma("unroll") for (int k = 0; k < PPW; ++k) {                                                 \
+      _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                \
+        const bool keep_ = p_ok[k] && gv[g] && pvz[k];                                                \
+        halfx8 h_;                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                               \
+          constexpr_int_c_(g * 8 + u)                                                                 \
+          float v = __fmaf_rn(pv[k][g][u], sc4[c_ / 4][c_ % 4], sh4[c_ / 4][c_ % 4]);                 \
+          v = __builtin_amdgcn_fmed3f(v, clamp_lo, 65504.0f);   /* ReLU (or -65504) and saturation instead of inf */ \
+          v = keep_ ? v : 0.0f;                       /* zero padding applies to the transformed tensor */ \
+          h_[u] = (_Float16)v;                                                                        \
+        }                                                                                             \
+        halfx8* d_ = (p_e[k] < CHS) ? Ph_ + (g * CHS + p_e[k]) : dump8;                               \
+        *d_ = h_;                                                                                     \
       }                                                                                               \
-      halfx8* d_ = (wi_ < WIT && p_e[k] < CHS) ? Ph_ + (g_ * CHS + p_e[k]) : dump8;                   \
-      *d_ = h_;                                                                                       \
     }                                                                                                 \
   }
+#define constexpr_int_c_(expr_) const int c_ = (expr_);
 
   constexpr int STORE_STEP = (NSTEPS * EMO_CONV_STORE_EIGHTHS) / 8;
 
@@ -289,6 +294,7 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
 #undef EMO_H_WAIT_PATCH
 #undef EMO_H_ISSUE_WEIGHTS
 #undef EMO_H_STORE_PATCH
+#undef constexpr_int_c_
 #undef acc_at
 
   conv_epilogue<TZ, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
