@@ -26,6 +26,13 @@
 
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
+// identity affine for convolutions without a fused GroupNorm: the staging always applies x * scale + shift, with the
+// 32 scale / shift values of a stage loaded through a wave-uniform address -- for scale == NULL that address points here
+#define EMO_ONES_8 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f
+static __device__ const float emo_identity_scale[32] = {EMO_ONES_8, EMO_ONES_8, EMO_ONES_8, EMO_ONES_8};
+static __device__ const float emo_identity_shift[32] = {};
+#undef EMO_ONES_8
+
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
 struct ConvCfgH {
   static constexpr int BM = WGM * TM * 32;
@@ -46,10 +53,12 @@ struct ConvCfgH {
   static constexpr int BUF = ASZ + ((PSZ_H / 2 + 3) & ~3);
   static constexpr int LDS_BYTES = (2 * BUF + 256) * 4;  // two stage buffers + 64 16-byte dump slots
   static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
-  static constexpr int OCC = BY_LDS < 1 ? 1 : (BY_LDS > 3 ? 3 : BY_LDS);
+  // 2 blocks per CU at most: 64 accumulator + 48-64 in-flight patch + 32-64 scale / shift registers per lane do not fit the
+  // 168-VGPR budget of 3 waves per SIMD (at 3 the compiler spilled in-flight load destinations: tools/kernel_resources.py --audit)
+  static constexpr int OCC = BY_LDS < 1 ? 1 : (BY_LDS > 2 ? 2 : BY_LDS);
   static_assert(WGM * WGP == 4, "4 waves per block");
   static_assert(TZ * TR * TW == BP, "position tile must equal BP");
-  static_assert(KC % 16 == 0, "whole 16-channel MFMA steps");
+  static_assert(KC % 16 == 0 && KC <= 32, "whole 16-channel MFMA steps; the identity-affine tables hold 32 entries");
   static_assert((ASZ_H * 2) % 16 == 0, "weight tile must be 16-byte copyable");
   static_assert(TM * TP <= 4, "accumulator budget");
   static_assert(2 * BUF >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the stage buffers");
@@ -100,8 +109,8 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   const float* xn = a.x + (long)n * a.Cin * DHW;
   const bool has_affine = a.scale != nullptr;
   const int padD = a.KD >> 1;
-  const float* scale_n = has_affine ? a.scale + (long)n * a.Cin : a.x;
-  const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : a.x;
+  const float* scale_n = has_affine ? a.scale + (long)n * a.Cin : emo_identity_scale;
+  const float* shift_n = has_affine ? a.shift + (long)n * a.Cin : emo_identity_shift;
   const float clamp_lo = a.relu_in ? 0.0f : -65504.0f;   // lower bound of the staged value: ReLU, or the fp16 range
 
   // ---- staging map: wave w stages the 64-position chunks w, w + 4, ... of the patch, for every 8-channel group of the
@@ -150,7 +159,8 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
     const int t_ = (stage_) - cc_ * a.KD;                                                             \
     const int ci0_ = cc_ * KC;                                                                        \
     _Pragma("unroll") for (int j = 0; j < KC / 4; ++j) {                                              \
-      const int c4_ = (ci0_ + 4 * j) < a.Cin ? (ci0_ + 4 * j) : 0;   /* Cin % 8 == 0: whole quads exist or not */ \
+      /* Cin % 8 == 0: whole quads exist or not; without an affine the 32-entry identity tables are indexed by j alone */ \
+      const int c4_ = !has_affine ? 4 * j : ((ci0_ + 4 * j) < a.Cin ? (ci0_ + 4 * j) : 0);            \
       sc4[j] = emo_gload4_pinned(scale_n + c4_, 0u);                                                  \
       sh4[j] = emo_gload4_pinned(shift_n + c4_, 0u);                                                  \
     }                                                                                                 \
@@ -182,7 +192,6 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
     emo_wait_vmem0();                                                                                 \
     _Pragma("unroll") for (int j = 0; j < KC / 4; ++j) {                                              \
       emo_touch4(sc4[j]); emo_touch4(sh4[j]);                                                         \
-      if (!has_affine) { sc4[j] = floatx4{1.0f, 1.0f, 1.0f, 1.0f}; sh4[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; } \
     }                                                                                                 \
     _Pragma("unroll") for (int k = 0; k < PPW; ++k)                                                   \
       _Pragma("unroll") for (int g = 0; g < NG; ++g)                                                  \
@@ -215,8 +224,8 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
         _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                               \
           constexpr_int_c_(g * 8 + u)                                                                 \
           float v = __fmaf_rn(pv[k][g][u], sc4[c_ / 4][c_ % 4], sh4[c_ / 4][c_ % 4]);                 \
-          v = __builtin_amdgcn_fmed3f(v, clamp_lo, 65504.0f);   /* ReLU (or -65504) and saturation instead of inf */ \
           v = keep_ ? v : 0.0f;                       /* zero padding applies to the transformed tensor */ \
+          v = __builtin_amdgcn_fmed3f(v, clamp_lo, 65504.0f);   /* ReLU (or -65504) and saturation instead of inf */ \
           h_[u] = (_Float16)v;                                                                        \
         }                                                                                             \
         halfx8* d_ = (p_e[k] < CHS) ? Ph_ + (g * CHS + p_e[k]) : dump8;                               \
