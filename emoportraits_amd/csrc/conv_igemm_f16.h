@@ -213,29 +213,33 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   }
 
 // transform in fp32 (affine of the producer's GroupNorm, ReLU + saturation in one v_med3, zero padding), round to fp16,
-// ONE 16-byte ds_write per item: Ph[(g * CHS + e) * 8 .. + 7]
-#define EMO_H_STORE_PATCH(buf_)                                                                       \
+// ONE 16-byte ds_write per item: Ph[(g * CHS + e) * 8 .. + 7].  One item (position chunk k_, channel group g_) at a time:
+// the items of a stage are spread over its MFMA steps, ~28 VALU instructions behind the 4 MFMAs of a step.
+#define EMO_H_STORE_ITEM(buf_, k_, g_)                                                                \
   {                                                                                                   \
     halfx8* Ph_ = reinterpret_cast<halfx8*>((buf_) + ASZ);                                            \
-    _Pragma("unroll") for (int k = 0; k < PPW; ++k) {                                                 \
-      _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                \
-        const bool keep_ = p_ok[k] && gv[g] && pvz[k];                                                \
-        halfx8 h_;                                                                                    \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                               \
-          constexpr_int_c_(g * 8 + u)                                                                 \
-          float v = __fmaf_rn(pv[k][g][u], sc4[c_ / 4][c_ % 4], sh4[c_ / 4][c_ % 4]);                 \
-          v = keep_ ? v : 0.0f;                       /* zero padding applies to the transformed tensor */ \
-          v = __builtin_amdgcn_fmed3f(v, clamp_lo, 65504.0f);   /* ReLU (or -65504) and saturation instead of inf */ \
-          h_[u] = (_Float16)v;                                                                        \
-        }                                                                                             \
-        halfx8* d_ = (p_e[k] < CHS) ? Ph_ + (g * CHS + p_e[k]) : dump8;                               \
-        *d_ = h_;                                                                                     \
-      }                                                                                               \
+    const bool keep_ = p_ok[k_] && gv[g_] && pvz[k_];                                                 \
+    halfx8 h_;                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                   \
+      constexpr_int_c_((g_) * 8 + u)                                                                  \
+      float v = __fmaf_rn(pv[k_][g_][u], sc4[c_ / 4][c_ % 4], sh4[c_ / 4][c_ % 4]);                   \
+      v = keep_ ? v : 0.0f;                           /* zero padding applies to the transformed tensor */ \
+      v = __builtin_amdgcn_fmed3f(v, clamp_lo, 65504.0f);   /* ReLU (or -65504) and saturation instead of inf */ \
+      h_[u] = (_Float16)v;                                                                            \
     }                                                                                                 \
+    halfx8* d_ = (p_e[k_] < CHS) ? Ph_ + ((g_) * CHS + p_e[k_]) : dump8;                              \
+    *d_ = h_;                                                                                         \
+  }
+#define EMO_H_STORE_PATCH(buf_)                                                                       \
+  {                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < PPW; ++k)                                                   \
+      _Pragma("unroll") for (int g = 0; g < NG; ++g) EMO_H_STORE_ITEM(buf_, k, g)                     \
   }
 #define constexpr_int_c_(expr_) const int c_ = (expr_);
 
-  constexpr int STORE_STEP = (NSTEPS * EMO_CONV_STORE_EIGHTHS) / 8;
+  // item i of the next stage is transformed and stored after MFMA step STORE_STEP0 + i * (NSTEPS - STORE_STEP0) / IPW
+  constexpr int IPW = PPW * NG;
+  constexpr int STORE_STEP0 = NSTEPS >= 3 ? NSTEPS / 3 : (NSTEPS > 1 ? 1 : 0);
 
   // ---- prologue: stage st_begin into buffer 0 ----
   EMO_H_ISSUE_WEIGHTS(st_begin, smem);
@@ -277,12 +281,10 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
     if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int step = 0; step < NSTEPS; ++step) {
-      if (step == STORE_STEP) {
-        if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
-        EMO_H_WAIT_PATCH();
-        EMO_H_STORE_PATCH(nxt);
-        if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
-      }
+      if (step == STORE_STEP0) { EMO_H_WAIT_PATCH(); }
+#pragma unroll
+      for (int it = 0; it < IPW; ++it)
+        if (STORE_STEP0 + (it * (NSTEPS - STORE_STEP0)) / IPW == step) { EMO_H_STORE_ITEM(nxt, it / NG, it % NG) }
       const int q = step / TAPS, tap = step % TAPS;
       const int r = tap / KW, s = tap % KW;
       halfx8 av_[TM], bv_[TP];
@@ -303,6 +305,7 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
 #undef EMO_H_WAIT_PATCH
 #undef EMO_H_ISSUE_WEIGHTS
 #undef EMO_H_STORE_PATCH
+#undef EMO_H_STORE_ITEM
 #undef constexpr_int_c_
 #undef acc_at
 

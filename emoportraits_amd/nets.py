@@ -16,6 +16,7 @@ implicit-GEMM kernel, and replays the module's forward as a sequence of kernel l
 There is no torch compute here: torch only owns the buffers.  Every op raises if the HIP library is missing.
 """
 import math
+import os
 
 import torch
 
@@ -294,7 +295,6 @@ class HotPath:
         # channels-last volumes for the samplers.  EMO_SAMPLER_LAYOUT=cg8 selects the channel-group-per-XCD kernels instead:
         # they cut the fabric reads of the shared-volume call 4x (rocprofv3 TCC counters, profiles/r2_pmc_sampler_*.json) but
         # are not faster -- the samplers are bound by the per-CU L1 path, not by L2 / HBM
-        import os
         want = os.environ.get("EMO_SAMPLER_LAYOUT", "ndhwc")
         self.sampler_layout = "cg8" if (want == "cg8" and self.c % 32 == 0) else "ndhwc"
         # frames per sampler launch pair: the warped intermediate of a chunk (25 MB per frame) is consumed by the second
@@ -302,12 +302,18 @@ class HotPath:
         self.sampler_chunk = int(os.environ.get("EMO_SAMPLER_CHUNK", "4"))
         self.sampler_uv_variant = int(os.environ.get("EMO_SAMPLER_UV_VARIANT", "0"))   # 12: 4x4x4 output bricks (A/B)
         from .pack import conv_precision
-        with conv_precision(precision):
-            self.embed = WarpEmbed(sd, cfg, self.device)
+        # fp16 mode: the WarpGenerators stay exact fp32 (EMO_WARP_PRECISION=f16 overrides) -- their output is GEOMETRY (where
+        # the volume is sampled): measured at R256, fp16 operands there put 2e-3 on the deltas and 2e-2 of max on the warped
+        # volume, 10x the 1-2e-3 the decoder's own fp16 rounding causes (tools/diag_f16.py), for 10 % of the time
+        wprec = os.environ.get("EMO_WARP_PRECISION", "f32") if precision == "f16" else precision
+        with conv_precision(wprec):
             self.uv_generator = WarpGenerator(sd, "uv_generator_nw", cfg, self.device)
-            self.decoder = Decoder(sd, "decoder_nw", cfg, self.device)
             if with_source:
                 self.xy_generator = WarpGenerator(sd, "xy_generator_nw", cfg, self.device)
+        with conv_precision(precision):
+            self.embed = WarpEmbed(sd, cfg, self.device)
+            self.decoder = Decoder(sd, "decoder_nw", cfg, self.device)
+            if with_source:
                 self.volume_source = VPNResBlocks(sd, "volume_source_nw", cfg, self.device)
                 self.volume_process = Unet3D(sd, "volume_process_nw", cfg, self.device)
                 from .encoder import LocalEncoder
