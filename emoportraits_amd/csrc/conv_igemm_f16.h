@@ -51,7 +51,9 @@ struct ConvCfgH {
   static constexpr int PSZ_H = NG * CHS * 8;             // halfs of one stage's patch
   static constexpr int ASZ = ASZ_H / 2;                  // in floats
   static constexpr int BUF = ASZ + ((PSZ_H / 2 + 3) & ~3);
-  static constexpr int LDS_BYTES = (2 * BUF + 256) * 4;  // two stage buffers + 64 16-byte dump slots
+  static constexpr int SCT = 1024;                       // entries of the per-sample scale / shift tables kept in LDS
+  static constexpr int LDS_BYTES = (2 * BUF + 256 + 2 * SCT) * 4;   // two stage buffers + 64 dump slots + scale / shift tables
+  static constexpr int NDMA_MIN = (ASZ_H * 2) / 4096;    // LDS-DMA instructions EVERY wave issues per stage (some issue one more)
   static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
   // 2 blocks per CU at most: 64 accumulator + 48-64 in-flight patch + 32-64 scale / shift registers per lane do not fit the
   // 168-VGPR budget of 3 waves per SIMD (at 3 the compiler spilled in-flight load destinations: tools/kernel_resources.py --audit)
@@ -63,6 +65,18 @@ struct ConvCfgH {
   static_assert(TM * TP <= 4, "accumulator budget");
   static_assert(2 * BUF >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the stage buffers");
 };
+
+#ifndef EMO_F16_ROLLING
+#define EMO_F16_ROLLING 1   /* 1: rolling prefetch (below); 0: the patch of stage s+1 is loaded at the top of stage s */
+#endif
+
+// LDS-DMA hidden from the compiler (asm): 16 bytes per lane from `gsrc` to the wave-uniform LDS byte address `lds_dst`
+// + lane * 16.  M0 is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void emo_dma16_pinned(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
 __global__ __launch_bounds__(256)
@@ -146,6 +160,206 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   const char* wsrc = reinterpret_cast<const char*>(a.wpk) + ((long)cotile * nstages_all) * (ASZ_H * 2);
 
   halfx8* const dump8 = reinterpret_cast<halfx8*>(smem + 2 * BUF) + lane;   // per-lane dump slot (written, never read)
+  constexpr int IPW = PPW * NG;   // staging items (position chunk, 8-channel group) per wave and stage
+
+  constexpr int TPH = TP > 2 ? TP / 2 : TP;
+  floatx16 acc_lo[TM][TPH], acc_hi[TM][TPH];
+#define acc_at(i_, j_) ((j_) < TPH ? acc_lo[i_][(j_) < TPH ? (j_) : 0] : acc_hi[i_][(j_) >= TPH ? (j_) - TPH : 0])
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TPH; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
+
+  // lane bases into the LDS tiles, in units of 8 halfs (16 bytes)
+  const int a_base = half * BM + m0 + l32;
+  int b_base[TP];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int p = p0 + j * 32 + l32;
+    const int col = p % TW;
+    const int row = (p / TW) % TR;
+    const int pz = p / (TW * TR);
+    b_base[j] = half * CHS + pz * (PR * PW) + row * PW + col;
+  }
+
+  // fragments of an MFMA step (TM weight and TP patch fragments, 16 bytes per lane each) in three rotating register sets:
+  // the reads of step s + 2 are issued before the MFMAs of step s, so their LDS latency hides behind a whole step of MFMAs
+  // even in the steps that carry no staging item
+  halfx8 fa_[3][TM], fb_[3][TP];
+#define EMO_H_LOAD_FRAGS(set_, step_)                                                                 \
+  {                                                                                                   \
+    const int q = (step_) / TAPS, tap = (step_) % TAPS;                                               \
+    const int r = tap / KW, s = tap % KW;                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa_[set_][i] = Ah[a_base + ((q * TAPS + tap) * 2) * BM + i * 32]; \
+    _Pragma("unroll") for (int j = 0; j < TP; ++j) fb_[set_][j] = Ph[b_base[j] + (q * 2) * CHS + r * PW + s]; \
+  }
+#define EMO_H_MFMAS(set_)                                                                             \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
+      _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                  \
+        acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[set_][i], fb_[set_][j], acc_at(i, j), 0, 0, 0); \
+  }
+#define EMO_H_MFMA_STEP(step_)                                                                        \
+  {                                                                                                   \
+    EMO_H_LOAD_FRAGS(0, step_)                                                                        \
+    EMO_H_MFMAS(0)                                                                                    \
+  }
+
+#if EMO_F16_ROLLING
+  // ---- rolling prefetch.  Every VMEM instruction of the loop is inline asm (patch loads AND the weight LDS-DMA), so the
+  //      compiler inserts no vmcnt waits of its own and the counts below are exact.  Per wave and stage s, in issue order:
+  //        [items i+1 .. IPW-1 of stage s+1]  [DMA of stage s+1]  [items 0 .. i-1 of stage s+2]
+  //      are newer than the loads of item i of stage s+1 when that item is converted during stage s: item i waits with
+  //      vmcnt((IPW-1)*8 + NDMA_MIN) and is re-issued for stage s+2 right after its conversion, so every patch load has
+  //      a whole stage of MFMA work to land (the non-rolling schedule gave it a third of a stage).  At the end of the stage
+  //      vmcnt(IPW*8) leaves exactly the re-issued items outstanding: the DMA of stage s+1 has landed before the barrier.
+  //      The per-sample scale / shift vectors live in LDS (two SCT-entry tables, identity when the layer has no affine).
+  static_assert((IPW - 1) * 8 + Cfg::NDMA_MIN <= 63 && IPW * 8 <= 63, "vmcnt is a 6-bit counter");
+  float* const sct = smem + 2 * BUF + 256;
+  for (int c = tid; c < Cfg::SCT; c += 256) {
+    const bool real = has_affine && c < a.Cin;
+    sct[c] = real ? a.scale[(long)n * a.Cin + c] : 1.0f;
+    sct[Cfg::SCT + c] = real ? a.shift[(long)n * a.Cin + c] : 0.0f;
+  }
+  const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem);
+
+  float pv[IPW][8];   // raw patch values of an item (pinned asm loads, in flight across the stage boundary)
+  bool pzi[IPW];      // the item's depth slice lies inside the volume (per lane)
+  bool gvi[IPW];      // wave-uniform: the item's channel group exists (and, for TZ == 1, the depth slice is inside)
+  int tix[IPW];       // wave-uniform: first channel of the item in the scale / shift tables
+  floatx4 sc_[2][2], sh_[2][2];   // scale / shift of the next two items (set = item & 1), read two items ahead of their use
+  static_assert(IPW % 2 == 0, "two table register sets alternate over the items");
+
+  int n_ci0, n_zu;    // stage being loaded: first input channel, first depth slice
+  bool n_zv;
+#define EMO_H_SET_STAGE(stage_)                                                                       \
+  {                                                                                                   \
+    const int cc_ = (stage_) / a.KD;                                                                  \
+    n_ci0 = cc_ * KC;                                                                                 \
+    n_zu = z0 + ((stage_) - cc_ * a.KD) - padD;                                                       \
+    n_zv = (unsigned)n_zu < (unsigned)a.D;                                                            \
+  }
+#define EMO_H_ISSUE_ITEM(it_)                                                                         \
+  {                                                                                                   \
+    const int k_ = (it_) / NG, g_ = (it_) % NG;                                                       \
+    unsigned off_ = p_off[k_];                                                                        \
+    bool zok_ = true;                                                                                 \
+    if (TZ > 1) {                                                                                     \
+      const int zi = n_zu + p_pz[k_];                                                                 \
+      zok_ = (unsigned)zi < (unsigned)a.D;                                                            \
+      off_ += (unsigned)((zok_ ? zi : 0) * HW) * 4u;                                                  \
+    }                                                                                                 \
+    pzi[it_] = zok_;                                                                                  \
+    const int c0_ = n_ci0 + g_ * 8;                                                                   \
+    const bool cv_ = c0_ < a.Cin;                                                                     \
+    const int cs_ = cv_ ? c0_ : 0;                                                                    \
+    gvi[it_] = cv_ && (TZ > 1 || n_zv);                                                               \
+    tix[it_] = has_affine ? cs_ : (cs_ & (Cfg::SCT - 1));                                             \
+    const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && n_zv) ? n_zu : 0) * HW;            \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) pv[it_][u] = emo_gload_pinned(base_ + (long)u * DHW, off_); \
+  }
+// transform in fp32 (affine of the producer's GroupNorm, ReLU + saturation in one v_med3, zero padding), round to fp16,
+// ONE 16-byte ds_write per item: Ph[(g * CHS + e) * 8 .. + 7]
+#define EMO_H_STORE_ITEM(buf_, it_)                                                                   \
+  {                                                                                                   \
+    const int k_ = (it_) / NG, g_ = (it_) % NG;                                                       \
+    halfx8* Ph_ = reinterpret_cast<halfx8*>((buf_) + ASZ);                                            \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(pv[it_][u]);                              \
+    const bool keep_ = p_ok[k_] && gvi[it_] && pzi[it_];                                              \
+    halfx8 h_;                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                   \
+      float v = __fmaf_rn(pv[it_][u], sc_[(it_) & 1][u / 4][u % 4], sh_[(it_) & 1][u / 4][u % 4]);      \
+      v = keep_ ? v : 0.0f;                           /* zero padding applies to the transformed tensor */ \
+      v = __builtin_amdgcn_fmed3f(v, clamp_lo, 65504.0f);   /* ReLU (or -65504) and saturation instead of inf */ \
+      h_[u] = (_Float16)v;                                                                            \
+    }                                                                                                 \
+    halfx8* d_ = (p_e[k_] < CHS) ? Ph_ + (g_ * CHS + p_e[k_]) : dump8;                                \
+    *d_ = h_;                                                                                         \
+  }
+// weight tile of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
+#define EMO_H_DMA_WEIGHTS(stage_, dst_lds_)                                                           \
+  {                                                                                                   \
+    const char* ws_ = wsrc + (long)(stage_) * (ASZ_H * 2);                                            \
+    constexpr int NGL = (ASZ_H * 2 + 4095) / 4096;                                                    \
+    _Pragma("unroll") for (int i = 0; i < NGL; ++i) {                                                 \
+      const int j = wave + 4 * i;                                                                     \
+      const int boff = j * 1024 + lane * 16;                                                          \
+      /* the first NDMA_MIN rounds are whole for every wave: unconditional, so that the vmcnt counts hold */ \
+      if (i < Cfg::NDMA_MIN || boff < ASZ_H * 2) emo_dma16_pinned(ws_ + boff, (dst_lds_) + (unsigned)(j * 1024)); \
+    }                                                                                                 \
+  }
+// scale / shift of the 8 channels of an item, read from the LDS tables one item ahead of their use
+#define EMO_H_LOAD_TABLE(it_)                                                                         \
+  {                                                                                                   \
+    const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + (tix[it_] >> 2);                     \
+    sc_[(it_) & 1][0] = t4_[0]; sc_[(it_) & 1][1] = t4_[1];                                           \
+    sh_[(it_) & 1][0] = t4_[Cfg::SCT / 4]; sh_[(it_) & 1][1] = t4_[Cfg::SCT / 4 + 1];                 \
+  }
+#define EMO_H_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define EMO_H_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
+
+  __syncthreads();   // scale / shift tables visible (no asm VMEM issued yet: the compiler's own waits are complete here)
+
+  // ---- prologue: stage st_begin into buffer 0, issue the items of stage st_begin + 1 ----
+  EMO_H_DMA_WEIGHTS(st_begin, smem_lds);
+  EMO_H_SET_STAGE(st_begin);
+#pragma unroll
+  for (int it = 0; it < IPW; ++it) EMO_H_ISSUE_ITEM(it)
+  EMO_H_WAIT(0);
+  {
+    const int st1 = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
+    EMO_H_SET_STAGE(st1);
+  }
+#pragma unroll
+  for (int it = 0; it < IPW; ++it) {
+    EMO_H_LOAD_TABLE(it)
+    EMO_H_STORE_ITEM(smem, it)
+    EMO_H_ISSUE_ITEM(it)
+  }
+  EMO_H_LOAD_TABLE(0)
+  EMO_H_LOAD_TABLE(1)
+  EMO_H_BARRIER(IPW * 8);
+
+  for (int st = st_begin; st < st_end; ++st) {
+    const int par = (st - st_begin) & 1;
+    float* cur = smem + par * BUF;
+    float* nxt = smem + (par ^ 1) * BUF;
+    const int stn = (st + 1) < st_end ? (st + 1) : st;     // clamped on the last stages: harmless re-stage
+    const int stn2 = (st + 2) < st_end ? (st + 2) : stn;
+    const halfx8* Ah = reinterpret_cast<const halfx8*>(cur);
+    const halfx8* Ph = reinterpret_cast<const halfx8*>(cur + ASZ);
+    EMO_H_LOAD_FRAGS(0, 0)
+    if (NSTEPS > 1) EMO_H_LOAD_FRAGS(1, 1)
+    EMO_H_DMA_WEIGHTS(stn, smem_lds + (unsigned)((par ^ 1) * BUF * 4));
+    EMO_H_SET_STAGE(stn2);
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int step = 0; step < NSTEPS; ++step) {
+#pragma unroll
+      for (int it = 0; it < IPW; ++it)
+        if ((it * NSTEPS) / IPW == step) {
+          EMO_H_WAIT((IPW - 1) * 8 + Cfg::NDMA_MIN);
+          EMO_H_STORE_ITEM(nxt, it)
+          EMO_H_ISSUE_ITEM(it)
+          EMO_H_LOAD_TABLE((it + 2) % IPW)   // the last two items prefetch for items 0, 1 of the next stage (tix already set)
+        }
+      if (step + 2 < NSTEPS) EMO_H_LOAD_FRAGS((step + 2) % 3, step + 2)
+      EMO_H_MFMAS(step % 3)
+    }
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    EMO_H_BARRIER(IPW * 8);
+  }
+  EMO_H_WAIT(0);   // the re-issued items of the clamped last stage are dead: drain them before their registers are reused
+#undef EMO_H_SET_STAGE
+#undef EMO_H_ISSUE_ITEM
+#undef EMO_H_STORE_ITEM
+#undef EMO_H_DMA_WEIGHTS
+#undef EMO_H_LOAD_TABLE
+#undef EMO_H_WAIT
+#undef EMO_H_BARRIER
+#else
 
   float pv[PPW][NG][8];   // raw patch values of the next stage (pinned asm loads)
   bool pvz[PPW];          // depth slice of the chunk inside the volume
@@ -238,7 +452,6 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
 #define constexpr_int_c_(expr_) const int c_ = (expr_);
 
   // item i of the next stage is transformed and stored after MFMA step STORE_STEP0 + i * (NSTEPS - STORE_STEP0) / IPW
-  constexpr int IPW = PPW * NG;
   constexpr int STORE_STEP0 = NSTEPS >= 3 ? NSTEPS / 3 : (NSTEPS > 1 ? 1 : 0);
 
   // ---- prologue: stage st_begin into buffer 0 ----
@@ -247,28 +460,6 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   EMO_H_WAIT_PATCH();
   EMO_H_STORE_PATCH(smem);
   __syncthreads();
-
-  constexpr int TPH = TP > 2 ? TP / 2 : TP;
-  floatx16 acc_lo[TM][TPH], acc_hi[TM][TPH];
-#define acc_at(i_, j_) ((j_) < TPH ? acc_lo[i_][(j_) < TPH ? (j_) : 0] : acc_hi[i_][(j_) >= TPH ? (j_) - TPH : 0])
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TPH; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
-
-  // lane bases into the LDS tiles, in units of 8 halfs (16 bytes)
-  const int a_base = half * BM + m0 + l32;
-  int b_base[TP];
-#pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int p = p0 + j * 32 + l32;
-    const int col = p % TW;
-    const int row = (p / TW) % TR;
-    const int pz = p / (TW * TR);
-    b_base[j] = half * CHS + pz * (PR * PW) + row * PW + col;
-  }
 
   for (int st = st_begin; st < st_end; ++st) {
     float* cur = smem + ((st - st_begin) & 1) * BUF;
@@ -285,18 +476,7 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
 #pragma unroll
       for (int it = 0; it < IPW; ++it)
         if (STORE_STEP0 + (it * (NSTEPS - STORE_STEP0)) / IPW == step) { EMO_H_STORE_ITEM(nxt, it / NG, it % NG) }
-      const int q = step / TAPS, tap = step % TAPS;
-      const int r = tap / KW, s = tap % KW;
-      halfx8 av_[TM], bv_[TP];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av_[i] = Ah[a_base + ((q * TAPS + tap) * 2) * BM + i * 32];
-#pragma unroll
-      for (int j = 0; j < TP; ++j) bv_[j] = Ph[b_base[j] + (q * 2) * CHS + r * PW + s];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j)
-          acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x16_f16(av_[i], bv_[j], acc_at(i, j), 0, 0, 0);
+      EMO_H_MFMA_STEP(step)
     }
     if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
@@ -307,6 +487,11 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
 #undef EMO_H_STORE_PATCH
 #undef EMO_H_STORE_ITEM
 #undef constexpr_int_c_
+
+#endif
+#undef EMO_H_MFMA_STEP
+#undef EMO_H_MFMAS
+#undef EMO_H_LOAD_FRAGS
 #undef acc_at
 
   conv_epilogue<TZ, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
@@ -317,6 +502,7 @@ int conv_igemm_f16_launch(ConvArgs a, hipStream_t s) {
   using Cfg = ConvCfgH<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
   if (a.Wl % TW || a.Hl % TR || a.Dl % TZ) return EMO_ERR_UNSUPPORTED;
   if (a.Cin % 8) return EMO_ERR_UNSUPPORTED;   // whole 8-channel groups
+  if (EMO_F16_ROLLING && a.scale && a.Cin > Cfg::SCT) return EMO_ERR_UNSUPPORTED;   // scale / shift tables in LDS
   a.tiles_x = a.Wl / TW;
   a.tiles_y = a.Hl / TR;
   a.tiles_z = a.Dl / TZ;

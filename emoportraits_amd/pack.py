@@ -215,6 +215,9 @@ def supports_f16(cout, cin, kd, kh, kw):
     return (kh, kw) in ((3, 3), (1, 1)) and kd in (1, 3) and not (kd == 3 and kh == 1) and cout >= 32 and cin % 8 == 0
 
 
+F16_AFFINE_MAX_CIN = 1024   # ConvCfgH::SCT (conv_igemm_f16.h)
+
+
 def f16_launch_fits(Hl, Wl):
     """output planes tiled by the 64 x 256 tile of the fp16-operand kernel: 2x128 / 4x64 / 8x32 positions"""
     if Hl is None:
@@ -271,9 +274,11 @@ class PackedConv:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
-    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False):
-        """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output"""
-        if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D):
+    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False):
+        """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output; `affine`: the
+        launch carries a per-sample input scale / shift (the fp16-operand kernel keeps those in a 1024-entry LDS table)"""
+        if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D) \
+                and not (affine and self.cin > F16_AFFINE_MAX_CIN):
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), "f16")
             return cfg, ks, "f16"
         allowed = (self.pinned_cfg,) if self.pinned_cfg is not None else self.allowed

@@ -1,6 +1,8 @@
 """CPU test (hipcc cross-compiles): the conv kernels hide their global loads in inline asm (conv_igemm.h, conv_igemm_f16.h), so
 a register the compiler spills while such a load is in flight would be silent corruption.  tools/kernel_resources.py --audit
-compiles every instantiation to ISA and checks that no scratch access lies between the first pinned load and the last MFMA."""
+compiles every instantiation to ISA and checks that no scratch access lies between the first pinned load and the last MFMA,
+and that no instruction touches the destination of a pinned load which the listing's hand-counted vmcnt waits have not
+covered yet (the fp16-operand kernel keeps loads in flight across the stage boundary)."""
 import os
 import subprocess
 import sys
@@ -16,3 +18,42 @@ def test_no_scratch_access_while_pinned_loads_are_in_flight():
                        text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 violations" in r.stdout
+
+
+LISTING = """
+\t#ASMSTART
+\tglobal_load_dword v10, v1, s[2:3]
+\t#ASMEND
+\t#ASMSTART
+\tglobal_load_dword v11, v1, s[4:5]
+\t#ASMEND
+.LBB0_1:
+\t#ASMSTART
+\ts_waitcnt vmcnt({first})
+\t#ASMEND
+\tv_fma_f32 v20, v10, v2, v3
+\t#ASMSTART
+\tglobal_load_dword v10, v1, s[2:3]
+\t#ASMEND
+\t#ASMSTART
+\ts_waitcnt vmcnt({second})
+\t#ASMEND
+\tv_fma_f32 v21, v11, v2, v3
+\t#ASMSTART
+\tglobal_load_dword v11, v1, s[4:5]
+\t#ASMEND
+\tv_mfma_f32_32x32x16_f16 v[30:45], v[4:7], v[8:9], v[30:45]
+\ts_cbranch_scc0 .LBB0_1
+"""
+
+
+def test_inflight_checker_on_a_synthetic_rolling_loop():
+    """two registers reloaded right after their use: each wait may leave exactly one (the other register's) load outstanding"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as K
+    ok = LISTING.format(first=1, second=1).split("\n")
+    assert K.inflight_reads(ok) == []
+    late = K.inflight_reads(LISTING.format(first=2, second=1).split("\n"))
+    assert late and late[0][2] == [10]
+    second_pass_only = K.inflight_reads(LISTING.format(first=1, second=2).split("\n"))
+    assert second_pass_only and second_pass_only[0][2] == [11]

@@ -209,10 +209,10 @@ def test_driver_pass_fp16_operand_mode_vs_oracle():
     e_img = (got["img"].cpu() - ref["img"]).abs().max().item()
     e_mean = (got["img"].cpu() - ref["img"]).abs().mean().item()
     print("PARITY driver pass R256 fp16 operands:", f"features {e_feat:.2e} of max, image {e_img:.2e} abs max, {e_mean:.2e} abs mean")
-    # seeded random weights are the worst case (see tests/test_stage2_gpu.py): measured 3.1e-2 of max on the decoder
-    # features, image 1.3e-2 mean / 0.31 worst pixel (the weight-standardised sigmoid head of a random network saturates a
-    # pixel here and there); the mean error is what the mode is characterised by
-    assert e_feat <= 1e-1 and e_mean <= 5e-2 and torch.isfinite(got["img"]).all()
+    # seeded random weights with a saturated sigmoid head (the worst case, see the trained-like test below).  Round-2 kernel
+    # (32x32x16 MFMA) with the WarpGenerators kept in fp32: measured features 1.8e-3 of max, image 7.6e-4 mean / 1.8e-2 worst
+    # pixel (round 1, everything in fp16: 3.1e-2 / 1.3e-2 / 0.31)
+    assert e_feat <= 1e-2 and e_mean <= 5e-3 and e_img <= 1e-1 and torch.isfinite(got["img"]).all()
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16"])
@@ -222,7 +222,8 @@ def test_driver_pass_with_trained_like_image_statistics(precision):
     makes single pixels flip.  The released checkpoint is not obtainable here; this test gives the seeded checkpoint the
     image statistics of a trained decoder instead (random_init.random_state_dict(image_head_gain=0.2): logits of a few
     units, images in mid-range) and states the tolerance on THAT: fp32 path 5e-4 worst pixel (measured 1.6e-4, mean 1.1e-5);
-    fp16-operand mode (BASELINE configs[4], opt-in) 8e-3 mean / 1e-1 worst pixel (measured 5.5e-3 / 7.6e-2)."""
+    fp16-operand mode (BASELINE configs[4], opt-in; decoder in fp16 operands, WarpGenerator fp32) 2e-3 mean / 2e-2 worst pixel
+    (measured 3.9e-4 / 4.6e-3; with the WarpGenerator in fp16 as well: 3.2e-3 / 5.3e-2)."""
     S, B = 256, 2
     cfg = config.hot_path_config(overrides={"image_size": S})
     sd = random_init.random_state_dict(cfg, seed=31, image_head_gain=0.2)
@@ -243,4 +244,4 @@ def test_driver_pass_with_trained_like_image_statistics(precision):
     if precision == "f32":
         assert e_max <= 5e-4 and e_feat <= 1e-3
     else:
-        assert e_mean <= 8e-3 and e_max <= 1e-1
+        assert e_mean <= 2e-3 and e_max <= 2e-2

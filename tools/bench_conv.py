@@ -30,7 +30,8 @@ def timeit(fn, iters=10, warmup=2):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     quick = "--quick" in sys.argv
-    f16 = "--f16" in sys.argv     # also time the opt-in fp16-operand kernels (emo_conv_igemm_f16acc32)
+    f16 = "--f16" in sys.argv or "--f16-only" in sys.argv   # also time the opt-in fp16-operand kernels (emo_conv_igemm_f16acc32)
+    f16_only = "--f16-only" in sys.argv
     torch.backends.cudnn.benchmark = True
     # (Cin, Cout, dims, k, ups)
     shapes = [(1536, 512, (64, 64), 1, False), (512, 512, (64, 64), 3, False),
@@ -57,7 +58,7 @@ def main():
         ms_t = 0.0 if quick else timeit(lambda: conv(xin, wd, padding=k // 2))
         rec = dict(B=B, cin=cin, cout=cout, dims=dims, k=k, ups=ups, torch_ms=round(ms_t, 3),
                    torch_tflops=round(flops / ms_t / 1e9, 1) if ms_t else None)
-        for cfg in (0, 1, 2, 3, 4, 5):
+        for cfg in (() if f16_only else (0, 1, 2, 3, 4, 5)):
             bm = {0: 128, 1: 64, 2: 32, 3: 64, 4: 64, 5: 32}[cfg]
             if cfg == 2 and cout > 96:
                 continue

@@ -6,7 +6,9 @@ emoportraits_amd/build.py).
                                                            # asm, and a register the compiler spills or copies while such a load is
                                                            # in flight is silent corruption (cdna_hip_programming.md section 5.7).
                                                            # Invariant checked in the generated ISA: NO scratch access between the
-                                                           # first pinned load (prologue) and the last MFMA of a kernel.  Exit code 1 on a violation.
+                                                           # first pinned load (prologue) and the last MFMA of a kernel, and no
+                                                           # instruction touches the destination of a load that the listing's
+                                                           # vmcnt waits have not yet covered.  Exit code 1 on a violation.
 """
 import concurrent.futures
 import glob
@@ -43,8 +45,92 @@ def show(row):
             f"scratch={row.get('ScratchSize [bytes/lane]')} occ={row.get('Occupancy [waves/SIMD]')}")
 
 
+_VREG = re.compile(r"\bv(\d+)\b")
+_VRANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(text):
+    regs = {int(m) for m in _VREG.findall(text)}
+    for a, b in _VRANGE.findall(text):
+        regs.update(range(int(a), int(b) + 1))
+    return regs
+
+
+def inflight_reads(lines):
+    """Instructions that touch the destination VGPR of a global load which, by the issue order and the vmcnt waits of the
+    listing, may still be in flight.  The kernels issue loads in inline asm and wait with hand-counted `s_waitcnt vmcnt(N)`:
+    a register copy or a too-small N corrupts data silently, so the listing itself is checked.  The K loop is walked
+    twice, the second time with the state the first pass left behind: loads stay in flight across the back edge.  Only loads issued from inline asm are tracked (the compiler
+    waits for its own), and only between the first asm statement and the last MFMA: prologue and K loop, where the control
+    flow is a single path plus exec-masked skips (the epilogue is compiler-scheduled, branchy code without pinned loads)."""
+    in_asm, flag = [], False
+    for l in lines:
+        if "#ASMSTART" in l:
+            flag = True
+        in_asm.append(flag)
+        if "#ASMEND" in l:
+            flag = False
+    mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+    first = next((i for i, l in enumerate(lines) if "#ASMSTART" in l), None)
+    if first is None or not mf:
+        return []
+    lo, hi = first, mf[-1]
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    state = {"seq": 0, "fl": {}}   # destination register (or a pseudo key for stores / LDS-DMA) -> issue sequence number
+    hits = []
+
+    def step(i):
+        t = lines[i].split(";")[0].strip()
+        if not t or t.startswith((".", "#")) or t.endswith(":"):
+            return
+        op = t.split()[0]
+        fl = state["fl"]
+        if op.startswith("global_load_lds") or (op.startswith("buffer_load") and " lds" in t):
+            lo_, hi_ = state.get("skip", (0, 0))
+            if not lo_ < i < hi_:   # a piece some waves skip (exec-masked) must not count as "newer"
+                fl[("dma", state["seq"])] = state["seq"]
+                state["seq"] += 1
+        elif op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
+            for r in (_vregs(t.split()[1].rstrip(",")) if in_asm[i] else [("ld", state["seq"])]):
+                fl[r] = state["seq"]
+            state["seq"] += 1
+        elif op.startswith(("global_store", "buffer_store", "flat_store", "scratch_store", "global_atomic", "buffer_atomic")):
+            fl[("st", state["seq"])] = state["seq"]
+            state["seq"] += 1
+        elif op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                keep = set(sorted(set(fl.values()))[-n:]) if n else set()
+                state["fl"] = {k: v for k, v in fl.items() if v in keep}
+        else:
+            used = _vregs(t) & {k for k in fl if isinstance(k, int)}
+            if used:
+                hits.append((i + 1, t, sorted(used)))
+
+    # walk the control flow: unconditional branches are followed, backward conditional branches are taken until every
+    # line of the loop has been visited twice, forward conditional branches (exec-masked skips, loop exits) fall through
+    visits, pc = {}, lo
+    while lo <= pc < len(lines) and pc <= hi + 40 and visits.get(pc, 0) < 2:
+        visits[pc] = visits.get(pc, 0) + 1
+        step(pc)
+        t = lines[pc].split(";")[0].strip()
+        m = re.match(r"s_(c?branch)\w*\s+(\.LBB\d+_\d+)", t)
+        tgt = labels.get(m.group(2)) if m else None
+        if tgt is not None and t.startswith("s_cbranch_execz") and tgt > pc:
+            state["skip"] = (pc, tgt)
+        if tgt is not None and (m.group(1) == "branch" or tgt < pc) and lo <= tgt and visits.get(tgt, 0) < 2:
+            pc = tgt
+        elif t.startswith("s_endpgm"):
+            break
+        else:
+            pc += 1
+    return hits
+
+
 def loop_scratch(src):
-    """per kernel of `src`: (name, scratch instructions between the first and the last MFMA, scratch instructions in total)"""
+    """per kernel of `src`: (name, scratch instructions between the first pinned load and the last MFMA, scratch instructions in
+    total, reads of possibly-in-flight load destinations)"""
     cmd = [B.HIPCC] + B.FLAGS + ["--cuda-device-only", "-S", src, "-o", "-"]
     asm = subprocess.run(cmd, capture_output=True, text=True).stdout.splitlines()
     out, name, lines = [], None, []
@@ -56,7 +142,7 @@ def loop_scratch(src):
                 sc = [i for i, l in enumerate(lines) if "scratch_" in l and not l.lstrip().startswith(";")]
                 lo = min(first_asm if first_asm is not None else 10 ** 9, mf[0] if mf else 10 ** 9)
                 inside = [i for i in sc if mf and lo < i < mf[-1]]
-                out.append((name, len(inside), len(sc)))
+                out.append((name, len(inside), len(sc), inflight_reads(lines)))
             m = re.search(r"Begin function (\S+)", line)
             name = m.group(1) if m else None
             lines = []
@@ -72,13 +158,16 @@ if __name__ == "__main__":
             res = list(ex.map(loop_scratch, files))
         bad = total = spilling = 0
         for f, rows in zip(files, res):
-            for name, inside, anywhere in rows:
+            for name, inside, anywhere, racy in rows:
                 total += 1
                 spilling += anywhere > 0
-                if inside:
+                if inside or racy:
                     bad += 1
                     nm = subprocess.run(["/usr/bin/c++filt", name], capture_output=True, text=True).stdout.strip()
-                    print(f"VIOLATION {os.path.basename(f)}: {nm[:110]}: {inside} scratch accesses inside the K loop")
+                    if inside:
+                        print(f"VIOLATION {os.path.basename(f)}: {nm[:110]}: {inside} scratch accesses inside the K loop")
+                    for ln, t, regs in racy[:4]:
+                        print(f"VIOLATION {os.path.basename(f)}: {nm[:110]}: '{t}' touches v{regs} while its load may be in flight")
         print(f"{total} kernels, {spilling} with scratch accesses outside the K loop (prologue / epilogue only), {bad} violations")
         sys.exit(1 if bad else 0)
     for src in sys.argv[1:]:

@@ -1,15 +1,20 @@
-"""launch one released-shape conv a few times (PMC target):  python tools/one_conv.py [B] [cfg] [cin] [cout] [hw]"""
+"""launch one conv layer a few times (PMC target):  python tools/one_conv.py cin cout H W [ups] [f16|f32] [B]"""
 import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emoportraits_amd import ops, pack
-arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
-B, cfg, cin, cout, hw = arg(1, 4), arg(2, 0), arg(3, 128), arg(4, 128), arg(5, 512)
-x = torch.randn(B, cin, hw, hw, device="cuda:0")
-w = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
-layer = pack.PackedConv("one", w, None, "cuda:0", cfg=cfg)
-scale = torch.rand(B, cin, device="cuda:0") + 0.5
-shift = torch.randn(B, cin, device="cuda:0") * 0.1
-out = ops.conv_igemm(x, layer, scale, shift, relu_in=True)
-for _ in range(3):
-    ops.conv_igemm(x, layer, scale, shift, relu_in=True, out=out)
+cin, cout, H, W = (int(v) for v in sys.argv[1:5])
+ups = len(sys.argv) > 5 and sys.argv[5] == "1"
+prec = sys.argv[6] if len(sys.argv) > 6 else "f16"
+B = int(sys.argv[7]) if len(sys.argv) > 7 else 16
+DEV = "cuda:0"
+g = torch.Generator().manual_seed(1)
+x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+scale = (torch.rand(B, cin, generator=g) + 0.5).to(DEV)
+shift = (torch.randn(B, cin, generator=g) * 0.1).to(DEV)
+layer = pack.PackedConv("b", w, None, DEV, precision=prec)
+out, _ = ops.conv_igemm(x, layer, scale, shift, relu_in=True, ups=ups), None
+out = out[0] if isinstance(out, tuple) else out
+for _ in range(6):
+    ops.conv_igemm(x, layer, scale, shift, relu_in=True, ups=ups, out=out)
 torch.cuda.synchronize()

@@ -1,23 +1,26 @@
 #!/bin/bash
-# SQ stall breakdown of ONE conv layer (two --pmc passes, no tracing):  bash tools/pmc_conv.sh <tag> [lib-variant-suffix] [B cfg cin cout hw]
+# SQ issue / wait counters of one conv layer (separate --pmc passes, no tracing):  bash tools/pmc_conv.sh <tag> cin cout H W [ups] [f16|f32] [B]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=$1; VAR=$2; shift 2
+TAG=$1; shift
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
-[ -n "$VAR" ] && export EMO_HIP_LIB=$R/emoportraits_amd/lib/libemoportraits_hip_$VAR.so
 cd /tmp
 CMD="python $R/tools/one_conv.py $@"
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL --output-format csv -d $R/gpurun_out/pmc_a -o x -- $CMD > $R/gpurun_out/${TAG}_pmc_a.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_b -o x -- $CMD > $R/gpurun_out/${TAG}_pmc_b.log 2>&1
+i=0
+for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc_c$i -o x -- $CMD > $R/gpurun_out/${TAG}_pmc_c$i.log 2>&1
+  (cd $R && python tools/summarize_rocprof.py pmc gpurun_out/pmc_c$i gpurun_out/${TAG}_pmc_c$i.json && rm -rf gpurun_out/pmc_c$i)
+done
 cd $R
-python tools/summarize_rocprof.py pmc gpurun_out/pmc_a gpurun_out/${TAG}_pmc_a.json
-python tools/summarize_rocprof.py pmc gpurun_out/pmc_b gpurun_out/${TAG}_pmc_b.json
-rm -rf gpurun_out/pmc_a gpurun_out/pmc_b
 python - <<PY
-import json
-for p in ("a", "b"):
-    d = json.load(open("gpurun_out/${TAG}_pmc_%s.json" % p))
-    for k, v in d.items():
-        if k.startswith("conv_igemm"):
-            print("${TAG}", p, {c: round(x["sum"] / x["launches"]) for c, x in v.items()})
+import json, glob
+out = {}
+for f in sorted(glob.glob("gpurun_out/${TAG}_pmc_c*.json")):
+    for k, v in json.load(open(f)).items():
+        if k.startswith("conv_igemm") or "conv_igemm" in k[:40]:
+            out.setdefault(k[:90], {}).update({c: round(x["mean"]) for c, x in v.items()})
+json.dump(out, open("gpurun_out/${TAG}_pmc_conv.json", "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))
 PY
