@@ -60,8 +60,8 @@ def inflight_reads(lines):
     """Instructions that touch the destination VGPR of a global load which, by the issue order and the vmcnt waits of the
     listing, may still be in flight.  The kernels issue loads in inline asm and wait with hand-counted `s_waitcnt vmcnt(N)`:
     a register copy or a too-small N corrupts data silently, so the listing itself is checked.  The K loop is walked
-    twice, the second time with the state the first pass left behind: loads stay in flight across the back edge.  Only loads issued from inline asm are tracked (the compiler
-    waits for its own), and only between the first asm statement and the last MFMA: prologue and K loop, where the control
+    twice, the second time with the state the first pass left behind: loads stay in flight across the back edge.  Only
+    loads issued from inline asm are tracked (the compiler waits for its own), and only between the first asm statement and the last MFMA: prologue and K loop, where the control
     flow is a single path plus exec-masked skips (the epilogue is compiler-scheduled, branchy code without pinned loads)."""
     in_asm, flag = [], False
     for l in lines:
@@ -76,7 +76,10 @@ def inflight_reads(lines):
         return []
     lo, hi = first, mf[-1]
     labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
-    state = {"seq": 0, "fl": {}}   # destination register (or a pseudo key for stores / LDS-DMA) -> issue sequence number
+    # outstanding VMEM operations in issue order: [sequence number, destination registers, definite]; `definite` is False
+    # for an operation inside a conditionally skipped region (exec-masked piece, wave-uniform branch): some waves do not
+    # issue it, so it must not be counted as "newer" when a wait is evaluated for an older load
+    state = {"seq": 0, "ops": [], "skip": (0, 0)}
     hits = []
 
     def step(i):
@@ -84,27 +87,28 @@ def inflight_reads(lines):
         if not t or t.startswith((".", "#")) or t.endswith(":"):
             return
         op = t.split()[0]
-        fl = state["fl"]
+        lo_, hi_ = state["skip"]
+        definite = not lo_ < i < hi_
         if op.startswith("global_load_lds") or (op.startswith("buffer_load") and " lds" in t):
-            lo_, hi_ = state.get("skip", (0, 0))
-            if not lo_ < i < hi_:   # a piece some waves skip (exec-masked) must not count as "newer"
-                fl[("dma", state["seq"])] = state["seq"]
-                state["seq"] += 1
+            state["ops"].append([state["seq"], set(), definite])
+            state["seq"] += 1
         elif op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
-            for r in (_vregs(t.split()[1].rstrip(",")) if in_asm[i] else [("ld", state["seq"])]):
-                fl[r] = state["seq"]
+            state["ops"].append([state["seq"], _vregs(t.split()[1].rstrip(",")) if in_asm[i] else set(), definite])
             state["seq"] += 1
         elif op.startswith(("global_store", "buffer_store", "flat_store", "scratch_store", "global_atomic", "buffer_atomic")):
-            fl[("st", state["seq"])] = state["seq"]
+            state["ops"].append([state["seq"], set(), definite])
             state["seq"] += 1
         elif op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", t)
             if m:
                 n = int(m.group(1))
-                keep = set(sorted(set(fl.values()))[-n:]) if n else set()
-                state["fl"] = {k: v for k, v in fl.items() if v in keep}
+                # vmcnt(n): all but the newest n operations have completed.  An operation is certainly complete when at
+                # least n DEFINITE operations are newer than it.
+                ops = state["ops"]
+                state["ops"] = [o for k, o in enumerate(ops) if sum(1 for o2 in ops[k + 1:] if o2[2]) < n] if n else []
         else:
-            used = _vregs(t) & {k for k in fl if isinstance(k, int)}
+            busy = set().union(*[o[1] for o in state["ops"]]) if state["ops"] else set()
+            used = _vregs(t) & busy
             if used:
                 hits.append((i + 1, t, sorted(used)))
 
@@ -117,7 +121,7 @@ def inflight_reads(lines):
         t = lines[pc].split(";")[0].strip()
         m = re.match(r"s_(c?branch)\w*\s+(\.LBB\d+_\d+)", t)
         tgt = labels.get(m.group(2)) if m else None
-        if tgt is not None and t.startswith("s_cbranch_execz") and tgt > pc:
+        if tgt is not None and m.group(1) == "cbranch" and pc < tgt <= hi:   # (a target past the last MFMA is the loop exit)
             state["skip"] = (pc, tgt)
         if tgt is not None and (m.group(1) == "branch" or tgt < pc) and lo <= tgt and visits.get(tgt, 0) < 2:
             pc = tgt
