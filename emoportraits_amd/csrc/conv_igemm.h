@@ -138,112 +138,118 @@ __device__ __forceinline__ void emo_wait_vmem0() { asm volatile("s_waitcnt vmcnt
 // after emo_wait_vmem0() this pins every use behind the wait)
 __device__ __forceinline__ void emo_touch(float& v) { asm volatile("" : "+v"(v)); }
 
-// sum over the 32 lanes of a half wave (lanes 0-31 / 32-63 separately), result in every lane: four DPP adds inside the
-// rows of 16 (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) + one ds_swizzle (xor 16).  No address registers.
-__device__ __forceinline__ float emo_sum32(float v) {
-#define EMO_DPP_ADD(ctrl_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, true))
-  EMO_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
-  EMO_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
-  EMO_DPP_ADD(0x141);   // row_half_mirror
-  EMO_DPP_ADD(0x140);   // row_mirror
-#undef EMO_DPP_ADD
-  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // bit mode: lane ^ 16
-  return v;
-}
-
 #define acc_at(i_, j_) ((j_) < TPH ? acc_lo[i_][(j_) < TPH ? (j_) : 0] : acc_hi[i_][(j_) >= TPH ? (j_) - TPH : 0])
 
 // Epilogue shared by the fp32 and the fp16-operand kernels (both accumulate in fp32 with the same C/D layout).
 // The accumulators live in two arrays of at most 64 floats each (see the kernel).
+//
+// The kernels issue their MFMAs with the operands swapped -- mfma(patch fragment, weight fragment) -- so a 32x32 result tile
+// is [position][channel]: col = lane & 31 is the output CHANNEL, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) the
+// POSITION.  Registers 4q .. 4q+3 of a lane are then 4 consecutive x positions of one channel: one 16-byte store (and one
+// 16-byte residual load) instead of four 4-byte ones, one bias load per lane, and GroupNorm sums that run over a lane's own
+// registers.  Global memory instructions are bound by their NUMBER on this chip (one wave-instruction per ~17 cycles and
+// CU whatever its width: tools/microbench/vmem_rate.hip), and the epilogue of a 64 x 256 tile was 64 store instructions per
+// wave; tools/fit_conv_overhead.py prices the per-block fixed cost at 7 % (fp32) to 30 % (fp16 operands) of a 128-channel
+// layer at 512^2.
+__device__ __forceinline__ void emo_store4(float* p, const floatx4& v, bool aligned) {
+  if (aligned) {
+    *reinterpret_cast<floatx4*>(p) = v;
+  } else {
+    p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3];
+  }
+}
+
 template <int TZ, int TR, int TW, int TM, int TP, int WGP, int BM>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, floatx16 (&acc_lo)[TM][TP > 2 ? TP / 2 : TP],
                                               floatx16 (&acc_hi)[TM][TP > 2 ? TP / 2 : TP], float* smem, int n, int cotile,
                                               int ptile, int ks, int x0, int y0, int z0, int m0, int p0, int wp, int half,
                                               int l32, int tid) {
   constexpr int TPH = TP > 2 ? TP / 2 : TP;
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  //      Bias and residual are fetched in batches of 16 under wave-uniform branches (a per-element `if (a.res) v += ...`
-  //      makes the compiler wait vmcnt(0) behind every single load: 128 dependent round trips per lane). ----
+  static_assert(TW % 4 == 0, "4 consecutive positions of a register quad lie in one tile row");
   const long plane = (long)a.Hl * a.Wl;
   const long ovol = (long)a.Dl * plane;
   const bool to_partial = a.partial != nullptr;
   const bool has_bias = a.bias != nullptr && !to_partial;
   const bool has_res = a.res != nullptr && !to_partial;
-  const int co_base = cotile * BM + m0 + 4 * half;
+  // 16-byte accesses need 16-byte aligned tensors (every tensor the host code allocates is; a caller's view may not be)
+  const bool out_al = ((reinterpret_cast<unsigned long long>(to_partial ? a.partial : a.out) & 15ull) == 0);
+  const bool res_al = has_res && ((reinterpret_cast<unsigned long long>(a.res) & 15ull) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
-    if (has_bias) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bv[r] = a.bias[min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
-    }
+    const int co = cotile * BM + m0 + i * 32 + l32;     // this lane's output channel
+    const bool co_ok = co < a.Cout;
+    const int cs = co_ok ? co : a.Cout - 1;
+    const float bv = has_bias ? a.bias[cs] : 0.0f;
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-      const int p = p0 + j * 32 + l32;
-      const int col = p % TW;
-      const int row = (p / TW) % TR;
-      const int pz = p / (TW * TR);
-      const int z = z0 + pz, y = y0 + row, x = x0 + col;
-      const long sp = (long)z * plane + (long)y * a.Wl + x;
-      if (to_partial) {
+      // the four register quads of the tile: positions p4 .. p4 + 3
+      long sp[4];
+      floatx4 rv[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (co < a.Cout) a.partial[(((long)ks * a.N + n) * a.Cout + co) * ovol + sp] = acc_at(i, j)[r];
-        }
-      } else {
-        float rv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = 0.0f;
-        if (has_res) {
-          long rsp = sp, rvol = ovol;
+      for (int q = 0; q < 4; ++q) {
+        const int p4 = p0 + j * 32 + 8 * q + 4 * half;
+        const int col = p4 % TW;
+        const int row = (p4 / TW) % TR;
+        const int pz = p4 / (TW * TR);
+        const int z = z0 + pz, y = y0 + row, x = x0 + col;
+        sp[q] = (long)z * plane + (long)y * a.Wl + x;
+        rv[q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (has_res) {   // wave-uniform: all loads of the tile are issued before the first use
           if (a.res_ups) {
             const int Wr = a.Wl >> 1, Hr = a.Hl >> 1;
-            rsp = ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
-            rvol = (long)a.Dl * Hr * Wr;
+            const float* rp = a.res + ((long)n * a.Cout + cs) * ((long)a.Dl * Hr * Wr) + ((long)z * Hr + (y >> 1)) * Wr + (x >> 1);
+            const float r0 = rp[0], r1 = rp[1];
+            rv[q] = floatx4{r0, r0, r1, r1};
+          } else {
+            const float* rp = a.res + ((long)n * a.Cout + cs) * ovol + sp[q];
+            if (res_al) rv[q] = *reinterpret_cast<const floatx4*>(rp);
+            else rv[q] = floatx4{rp[0], rp[1], rp[2], rp[3]};
           }
-          const float* rp = a.res + (long)n * a.Cout * rvol + rsp;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = rp[(long)min(co_base + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1) * rvol];
         }
-        float* op = a.out + (long)n * a.Cout * ovol + sp;
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2);
-          const float v = emo_act(acc_at(i, j)[r] + bv[r] + rv[r], a.act);
-          if (co < a.Cout) op[(long)co * ovol] = v;
-          acc_at(i, j)[r] = v;   // the stored value: what the next GroupNorm normalises
+      for (int q = 0; q < 4; ++q) {
+        floatx4 v;
+        if (to_partial) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc_at(i, j)[4 * q + e];
+          if (co_ok) emo_store4(a.partial + (((long)ks * a.N + n) * a.Cout + co) * ovol + sp[q], v, out_al);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = emo_act(acc_at(i, j)[4 * q + e] + bv + rv[q][e], a.act);
+            acc_at(i, j)[4 * q + e] = v[e];   // the stored value: what the next GroupNorm normalises
+          }
+          if (co_ok) emo_store4(a.out + ((long)n * a.Cout + co) * ovol + sp[q], v, out_al);
         }
       }
     }
   }
 
-  // ---- GroupNorm statistics of the output tile (wave-uniform branch).  Per channel row of this wave: mean over its
-  //      TP*32 positions (DPP butterfly over the 32 lanes that hold the row), then the sum of squares centred at that mean --
-  //      a two-pass variance on values that are still in registers.  The WGP waves that share the row combine their
-  //      (mean, M2) through LDS with the pairwise update of Chan et al. (equal counts).  No E[x^2] - mean^2 anywhere. ----
+  // ---- GroupNorm statistics of the output tile (wave-uniform branch).  A lane holds 16 * TP values of ITS channel, its
+  //      partner lane ^ 32 the other half of the wave's TP * 32 positions: mean = (own sum + partner's) / count, then the sum
+  //      of squares centred at that mean -- a two-pass variance on values that are still in registers.  The WGP waves that
+  //      share the channel combine their (mean, M2) through LDS with the pairwise update of Chan et al. (equal counts).
+  //      No E[x^2] - mean^2 anywhere. ----
   if (a.gn_stats != nullptr && !to_partial) {
     float* st_lds = smem;   // [WGP][BM][2]: the stage buffers are idle (the K loop ended with a barrier)
     constexpr float inv_cnt = 1.0f / (float)(TP * 32);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float s = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = acc_at(i, 0)[r];
+      for (int j = 0; j < TP; ++j)
 #pragma unroll
-        for (int j = 1; j < TP; ++j) s += acc_at(i, j)[r];
-        const float mean = emo_sum32(s) * inv_cnt;
-        float m2 = 0.0f;
+        for (int r = 0; r < 16; ++r) s += acc_at(i, j)[r];
+      s += __shfl_xor(s, 32);
+      const float mean = s * inv_cnt;
+      float m2 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < TP; ++j) { const float d = acc_at(i, j)[r] - mean; m2 = __fmaf_rn(d, d, m2); }
-        m2 = emo_sum32(m2);
-        if (l32 == 0) {
-          const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          *reinterpret_cast<float2*>(st_lds + (wp * BM + m) * 2) = make_float2(mean, m2);
-        }
-      }
+      for (int j = 0; j < TP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc_at(i, j)[r] - mean; m2 = __fmaf_rn(d, d, m2); }
+      m2 += __shfl_xor(m2, 32);
+      if (half == 0) *reinterpret_cast<float2*>(st_lds + (wp * BM + m0 + i * 32 + l32) * 2) = make_float2(mean, m2);
     }
     __syncthreads();
     if (tid < BM) {
@@ -384,6 +390,17 @@ void conv_igemm_kernel(const ConvArgs a) {
     p_pz[i] = pz;
   }
 
+  // TZ == 1 (every 2-D layer): an element's validity never changes, so zero padding rides on the clamp of the ReLU --
+  // v_med3(v, lo, hi) with [relu floor, +inf] inside the image and [0, 0] outside replaces max + select (and the mask
+  // arithmetic behind the select) in the staging of every stage; a missing channel / depth slice (wave-uniform) zeroes the
+  // scale and shift instead
+  float p_lo[EPC], p_hi[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) {
+    p_lo[i] = p_ok[i] ? relu_floor : 0.0f;
+    p_hi[i] = p_ok[i] ? __builtin_huge_valf() : 0.0f;
+  }
+
   const int nstages_all = a.n_cchunks * a.KD;
   const int st_begin = ks * a.stages_per_split;                       // this block's share of the K loop
   const int st_end = min(nstages_all, st_begin + a.stages_per_split);
@@ -403,14 +420,18 @@ void conv_igemm_kernel(const ConvArgs a) {
 // PINNED_: loads as asm volatile (EMO_CONV_PIPE 2) or ordinary loads (EMO_CONV_PIPE 1)
 #define EMO_ISSUE_PATCH(stage_, PINNED_)                                                              \
   {                                                                                                   \
-    const int cc_ = (stage_) / a.KD;                                                                  \
-    const int t_ = (stage_) - cc_ * a.KD;                                                             \
-    const int ci0_ = cc_ * KC;                                                                        \
+    const int scc_ = (stage_) / a.KD;                                                                 \
+    EMO_ISSUE_PATCH_AT(scc_, (stage_) - scc_ * a.KD, PINNED_)                                         \
+  }
+/* the same for a stage given as (channel chunk, depth tap): the K loop steps these instead of dividing every stage */
+#define EMO_ISSUE_PATCH_AT(cc_, t_, PINNED_)                                                          \
+  {                                                                                                   \
+    const int ci0_ = (cc_) * KC;                                                                      \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
       const int c_ = ci0_ + g * SW + chan0;                                                           \
       const bool cv_ = c_ < a.Cin;                                                                    \
       const int cs_ = cv_ ? c_ : 0;                                                                   \
-      const int zu_ = z0 + t_ - padD;           /* depth of tile slice 0 */                           \
+      const int zu_ = z0 + (t_) - padD;         /* depth of tile slice 0 */                           \
       const bool zv_ = (unsigned)zu_ < (unsigned)a.D;                                                 \
       const float* base_ = xn + (long)cs_ * DHW + (long)((TZ == 1 && zv_) ? zu_ : 0) * HW;            \
       sv[g] = cv_ && (TZ > 1 || zv_);                                                                 \
@@ -465,12 +486,18 @@ void conv_igemm_kernel(const ConvArgs a) {
     float* Ps_ = (buf_) + ASZ;                                                                        \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
       float* Pc_ = Ps_ + (g * SW + chan0) * CHS;                                                      \
-      const float sc_ = has_affine ? sc[g] : 1.0f, sh_ = has_affine ? sh[g] : 0.0f;                   \
+      float sc_ = has_affine ? sc[g] : 1.0f, sh_ = has_affine ? sh[g] : 0.0f;                         \
+      if (TZ == 1) { sc_ = sv[g] ? sc_ : 0.0f; sh_ = sv[g] ? sh_ : 0.0f; }                            \
       _Pragma("unroll") for (int i = 0; i < EPC; ++i) {                                               \
         const int e = lane + (i * WPC + part) * 64;                                                   \
-        float v = fmaxf(__fmaf_rn(pv[g * EPC + i], sc_, sh_), relu_floor);                            \
+        float v = __fmaf_rn(pv[g * EPC + i], sc_, sh_);                                               \
         /* zero padding applies to the transformed tensor */                                          \
-        v = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                        \
+        if (TZ == 1) {                                                                                \
+          v = __builtin_amdgcn_fmed3f(v, p_lo[i], p_hi[i]);                                           \
+        } else {                                                                                      \
+          v = fmaxf(v, relu_floor);                                                                   \
+          v = (p_ok[i] && sv[g] && pvz[g * EPC + i]) ? v : 0.0f;                                      \
+        }                                                                                             \
         float* d_ = ((i + 1) * WPC * 64 <= CHS || e < CHS) ? Pc_ + e : dump1;                         \
         *d_ = v;                                                                                      \
       }                                                                                               \
@@ -515,6 +542,7 @@ void conv_igemm_kernel(const ConvArgs a) {
     b_base[j] = half * CHS + pz * (PR * PW) + row * PW + col;
   }
 
+  int nx_cc = st_begin / a.KD, nx_t = st_begin - nx_cc * a.KD;   // (channel chunk, depth tap) of the stage being loaded
   for (int st = st_begin; st < st_end; ++st) {
     float* cur = smem + ((st - st_begin) & 1) * BUF;
     float* nxt = smem + ((st - st_begin + 1) & 1) * BUF;
@@ -525,7 +553,8 @@ void conv_igemm_kernel(const ConvArgs a) {
     const float* Ps = cur + ASZ;
     if (EMO_CONV_ABLATE == 0) {
       EMO_ISSUE_WEIGHTS(stn, nxt);
-      if (PINNED) { EMO_ISSUE_PATCH(stn, true); }
+      if (st + 1 < st_end && ++nx_t == a.KD) { nx_t = 0; ++nx_cc; }   // (chunk, tap) of stage stn
+      if (PINNED) { EMO_ISSUE_PATCH_AT(nx_cc, nx_t, true); }
     }
     // one MFMA step = one channel pair x one tap: 1 A read + 1 B read per 32x32 tile, TM*TP MFMAs
 #define EMO_READ_OPERANDS(step_, av__, bv__)                                                          \
@@ -556,7 +585,7 @@ void conv_igemm_kernel(const ConvArgs a) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j)
-          acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[cur_][i], bv_[cur_][j], acc_at(i, j), 0, 0, 0);
+          acc_at(i, j) = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_[cur_][j], av_[cur_][i], acc_at(i, j), 0, 0, 0);   // [position][channel]: conv_epilogue
     }
     if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
 #undef EMO_READ_OPERANDS
@@ -573,6 +602,7 @@ void conv_igemm_kernel(const ConvArgs a) {
 
 #undef acc_at
 #undef EMO_ISSUE_PATCH
+#undef EMO_ISSUE_PATCH_AT
 #undef EMO_WAIT_PATCH
 #undef EMO_ISSUE_WEIGHTS
 #undef EMO_STORE_STAGE

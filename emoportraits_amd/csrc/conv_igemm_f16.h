@@ -63,7 +63,10 @@ struct ConvCfgH {
   static constexpr int ASZ = ASZ_H / 2;                  // in floats
   static constexpr int BUF = ASZ + ((PSZ_H / 2 + 3) & ~3);
   static constexpr int SCT = 1024;                       // entries of the per-sample scale / shift tables kept in LDS
-  static constexpr int LDS_BYTES = (2 * BUF + 256 + 2 * SCT) * 4;   // two stage buffers + 64 dump slots + scale / shift tables
+#ifndef EMO_F16_EXPERIMENT
+#define EMO_F16_EXPERIMENT 0   /* measurement builds only: 1 = one block per CU (LDS padded), 2 = no sched_barrier pinning */
+#endif
+  static constexpr int LDS_BYTES = (2 * BUF + 256 + 2 * SCT) * 4 + (EMO_F16_EXPERIMENT == 1 ? 81 * 1024 - (2 * BUF + 256 + 2 * SCT) * 4 : 0);   // two stage buffers + 64 dump slots + scale / shift tables
   static constexpr int NDMA_MIN = (ASZ_H * 2) / 4096;    // LDS-DMA instructions EVERY wave issues per stage (some issue one more)
   static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
   // 2 blocks per CU at most: 64 accumulator + 48 fragment + 40 in-flight patch + 32 scale / shift registers per lane do
@@ -403,9 +406,10 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
       if (step + 2 < NSTEPS) EMO_H_LOAD_FRAGS((step + 2) % 3, step + 2)
 #pragma unroll
       for (int m = 0; m < NSLOT; ++m) {
-        acc_at(m / TP, m % TP) = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[step % 3][m / TP], fb_[step % 3][m % TP],
+        // operands swapped: the result tile is [position][channel] (conv_epilogue)
+        acc_at(m / TP, m % TP) = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[step % 3][m % TP], fa_[step % 3][m / TP],
                                                                          acc_at(m / TP, m % TP), 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (EMO_F16_EXPERIMENT != 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pc = 0; pc < NPIECE; ++pc) {
           if ((pc * NSTEPS * NSLOT) / PIECE_SPAN != step * NSLOT + m) continue;
@@ -425,7 +429,7 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
             EMO_H_HALO_TABLE()
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (EMO_F16_EXPERIMENT != 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);

@@ -252,7 +252,8 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
             raise ValueError("bad residual shape")
     positions = N * D * Hl * Wl
-    cfg, ks, prec = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl, ups, affine=scale is not None)
+    cfg, ks, prec = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl, ups, affine=scale is not None,
+                                   aligned16=x.data_ptr() % 16 == 0)
     if ksplit is not None:
         ks = int(ksplit)
     ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None

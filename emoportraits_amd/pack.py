@@ -274,10 +274,11 @@ class PackedConv:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
-    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False):
+    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False, aligned16=True):
         """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output; `affine`: the
-        launch carries a per-sample input scale / shift (the fp16-operand kernel keeps those in a 1024-entry LDS table)"""
-        if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D) \
+        launch carries a per-sample input scale / shift (the fp16-operand kernel keeps those in a 1024-entry LDS table);
+        `aligned16`: the input pointer is 16-byte aligned (that kernel loads 16-byte quads)"""
+        if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D) and aligned16 \
                 and not (affine and self.cin > F16_AFFINE_MAX_CIN):
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), "f16")
             return cfg, ks, "f16"
