@@ -23,7 +23,11 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_f16_pmc_fetch.json", f"{tag}_f16_stage2_pmc_fetch.json"),
                  (f"{tag}_f16_pmc_write.json", f"{tag}_f16_stage2_pmc_write.json"),
                  (f"{tag}_f16_conv.jsonl", f"{tag}_f16_conv_microbench.jsonl"),
-                 (f"{tag}_f16_driver512.jsonl", f"{tag}_f16_driver_breakdown_r512.jsonl")):
+                 (f"{tag}_f16_driver512.jsonl", f"{tag}_f16_driver_breakdown_r512.jsonl"),
+                 (f"{tag}_f16_512c_pmc_conv.json", f"{tag}_f16_pmc_sq_conv_512to512_at64.json"),
+                 (f"{tag}_f16_128c_pmc_conv.json", f"{tag}_f16_pmc_sq_conv_128to128_at512.json"),
+                 (f"{tag}_conv_overhead_fit.jsonl", f"{tag}_conv_overhead_fit.jsonl"),
+                 (f"{tag}_vmem_rate.jsonl", f"{tag}_vmem_rate_microbench.jsonl")):
     if os.path.exists(g + src):
         shutil.copy(g + src, p + dst)
 if os.path.exists(g + f"{tag}_pytest.log"):

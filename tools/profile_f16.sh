@@ -17,3 +17,10 @@ for p in mfma fetch write; do python tools/summarize_rocprof.py pmc gpurun_out/p
 rm -rf gpurun_out/prof_f16_kt gpurun_out/prof_f16_mfma gpurun_out/prof_f16_fetch gpurun_out/prof_f16_write
 timeout 200 python tools/bench_conv.py 16 --quick --f16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_f16_conv.jsonl
 timeout 200 python tools/bench_driver.py 512 16 --f16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_f16_driver512.jsonl
+# SQ issue / wait / LDS counters of two decoder-shape layers on the fp16-operand kernel, the per-block overhead fit of both conv
+# kernels and the global-load instruction-rate microbenchmark that motivates the 16-byte staging loads
+bash tools/pmc_conv.sh ${TAG}_f16_512c 512 512 64 64 0 f16 > /dev/null 2>&1
+bash tools/pmc_conv.sh ${TAG}_f16_128c 128 128 512 512 0 f16 > /dev/null 2>&1
+(timeout 100 python tools/fit_conv_overhead.py f16 512 128 4; timeout 100 python tools/fit_conv_overhead.py f32 512 128 4) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_conv_overhead_fit.jsonl
+[ -x tools/microbench/vmem_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/vmem_rate.hip -o tools/microbench/vmem_rate 2>/dev/null
+timeout 60 tools/microbench/vmem_rate > gpurun_out/${TAG}_vmem_rate.jsonl 2>&1
