@@ -167,6 +167,8 @@ def test_conv_split_k_equals_single_pass(case, ksplit):
     dict(N=2, Cin=96, Cout=130, dims=(64, 64), k=1, cfg=3, ups=True),
     dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, ksplit=3),
     dict(N=1, Cin=24, Cout=64, dims=(256, 256), k=3, cfg=3, affine=True, relu_in=True, res=True),
+    dict(N=1, Cin=32, Cout=64, dims=(64, 64), k=3, cfg=3, ups=True, affine=True, relu_in=True),    # 2 x 128 tile on source pixels
+    dict(N=2, Cin=16, Cout=96, dims=(32, 32), k=3, cfg=3, ups=True, affine=True),                  # 4 x 64 tile, no ReLU
 ])
 def test_conv_fp16_operands(case):
     """opt-in reduced-precision mode (BASELINE configs[4]): fp16 MFMA operands (32x32x16), fp32 accumulation, 64 x 256 tile.
@@ -199,6 +201,30 @@ def test_conv_fp16_layer_falls_back_to_fp32_on_narrow_maps_and_writes_tile_stati
     s1, h1 = ops.groupnorm_affine(out, stats=st)
     s0, h0 = ops.groupnorm_affine(out)
     assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item()
+
+
+def test_conv_on_tensors_that_are_not_16_byte_aligned():
+    """the fp16-operand kernel loads 16-byte quads and the epilogue stores 16 bytes per lane: a 4-byte-aligned input falls back
+    to the exact-fp32 kernel, a 4-byte-aligned output (or residual) to scalar stores -- same results"""
+    g = torch.Generator().manual_seed(23)
+    N, C, S = 1, 32, 64
+    w = torch.randn(64, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    xa = torch.randn(N, C, S, S, generator=g).to(DEV)
+    xm = torch.empty(xa.numel() + 1, device=DEV)[1:].view_as(xa)
+    xm.copy_(xa)
+    assert xm.data_ptr() % 16 == 4
+    ref = F.conv2d(xa, w.to(DEV), padding=1)
+    lh = pack.PackedConv("h", w, None, DEV, precision="f16")
+    got_h = ops.conv_igemm(xm, lh)
+    assert rel_err(got_h, ref) < 2e-5                       # fp32 accuracy: the fp32 kernel ran
+    assert rel_err(ops.conv_igemm(xa, lh), ref) > 1e-5      # (the aligned tensor does take the fp16-operand kernel)
+    lf = pack.PackedConv("f", w, None, DEV)
+    om = torch.empty(ref.numel() + 1, device=DEV)[1:].view_as(ref)
+    rm = torch.empty(ref.numel() + 1, device=DEV)[1:].view_as(ref)
+    rm.copy_(torch.randn(ref.shape, generator=g).to(DEV))
+    got = ops.conv_igemm(xa, lf, res=rm, out=om)
+    assert got.data_ptr() == om.data_ptr()
+    assert rel_err(got, ref + rm) < 2e-5
 
 
 def test_conv_fp16_operands_saturate():
