@@ -213,7 +213,7 @@ def test_conv_on_tensors_that_are_not_16_byte_aligned():
     xm = torch.empty(xa.numel() + 1, device=DEV)[1:].view_as(xa)
     xm.copy_(xa)
     assert xm.data_ptr() % 16 == 4
-    ref = F.conv2d(xa, w.to(DEV), padding=1)
+    ref = F.conv2d(xa.cpu(), w, padding=1)
     lh = pack.PackedConv("h", w, None, DEV, precision="f16")
     got_h = ops.conv_igemm(xm, lh)
     assert rel_err(got_h, ref) < 2e-5                       # fp32 accuracy: the fp32 kernel ran
@@ -221,10 +221,11 @@ def test_conv_on_tensors_that_are_not_16_byte_aligned():
     lf = pack.PackedConv("f", w, None, DEV)
     om = torch.empty(ref.numel() + 1, device=DEV)[1:].view_as(ref)
     rm = torch.empty(ref.numel() + 1, device=DEV)[1:].view_as(ref)
-    rm.copy_(torch.randn(ref.shape, generator=g).to(DEV))
+    r = torch.randn(ref.shape, generator=g)
+    rm.copy_(r.to(DEV))
     got = ops.conv_igemm(xa, lf, res=rm, out=om)
-    assert got.data_ptr() == om.data_ptr()
-    assert rel_err(got, ref + rm) < 2e-5
+    assert got.data_ptr() == om.data_ptr() and om.data_ptr() % 16 == 4
+    assert rel_err(got, ref + r) < 2e-5
 
 
 def test_conv_fp16_operands_saturate():
