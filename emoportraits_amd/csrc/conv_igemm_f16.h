@@ -40,6 +40,11 @@
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef int emo_intx4 __attribute__((ext_vector_type(4)));
 
+#ifndef EMO_F16_EXPERIMENT
+#define EMO_F16_EXPERIMENT 0   /* measurement builds only (tools/session/r2_exp_f16.sh): 1 = one block per CU (LDS request padded
+                                  to 81 KB), 2 = no sched_barrier pinning of the staging pieces between the MFMAs */
+#endif
+
 template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
 struct ConvCfgH {
   static constexpr int BM = WGM * TM * 32;
@@ -63,10 +68,8 @@ struct ConvCfgH {
   static constexpr int ASZ = ASZ_H / 2;                  // in floats
   static constexpr int BUF = ASZ + ((PSZ_H / 2 + 3) & ~3);
   static constexpr int SCT = 1024;                       // entries of the per-sample scale / shift tables kept in LDS
-#ifndef EMO_F16_EXPERIMENT
-#define EMO_F16_EXPERIMENT 0   /* measurement builds only: 1 = one block per CU (LDS padded), 2 = no sched_barrier pinning */
-#endif
-  static constexpr int LDS_BYTES = (2 * BUF + 256 + 2 * SCT) * 4 + (EMO_F16_EXPERIMENT == 1 ? 81 * 1024 - (2 * BUF + 256 + 2 * SCT) * 4 : 0);   // two stage buffers + 64 dump slots + scale / shift tables
+  static constexpr int LDS_USED = (2 * BUF + 256 + 2 * SCT) * 4;    // two stage buffers + 64 dump slots + scale / shift tables
+  static constexpr int LDS_BYTES = EMO_F16_EXPERIMENT == 1 ? 81 * 1024 : LDS_USED;
   static constexpr int NDMA_MIN = (ASZ_H * 2) / 4096;    // LDS-DMA instructions EVERY wave issues per stage (some issue one more)
   static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
   // 2 blocks per CU at most: 64 accumulator + 48 fragment + 40 in-flight patch + 32 scale / shift registers per lane do

@@ -198,3 +198,20 @@ def test_detection_box_and_mixing_theta_match_reference(glue):
         got = H.mixing_theta(m["source"].numpy(), m["target"].numpy(), m["mix_old"])
         assert got.shape == tuple(m["out"].shape)
         assert np.abs(got.astype(np.float32) - m["out"].numpy()).max() <= 1e-6
+
+
+def test_fp16_plan_falls_back_to_fp32_where_the_fp16_kernel_cannot_run():
+    """PackedConv(precision="f16").plan_for: the fp16-operand kernel needs a 64 x 256 output tile, a 16-byte aligned input and --
+    with a fused scale / shift -- at most 1024 input channels (its LDS tables); everything else takes the exact-fp32 kernel"""
+    import torch
+    from emoportraits_amd import pack
+    lay = pack.PackedConv("p", torch.zeros(64, 64, 3, 3), None, "cpu", precision="f16")
+    assert lay.plan_for(32, 64, 64)[2] == "f16"
+    assert lay.plan_for(32, 64, 64, aligned16=False)[2] == "f32"
+    assert lay.plan_for(2, 16, 16)[2] == "f32"                      # no 256-pixel tile shape fits a 16 x 16 plane
+    assert lay.plan_for(32, 64, 64, affine=True)[2] == "f16"
+    wide = pack.PackedConv("w", torch.zeros(64, 1536, 1, 1), None, "cpu", precision="f16")
+    assert wide.plan_for(32, 64, 64)[2] == "f16"                    # identity tables wrap: no limit without an affine
+    assert wide.plan_for(32, 64, 64, affine=True)[2] == "f32"
+    assert pack.F16_AFFINE_MAX_CIN == 1024
+    assert pack.PackedConv("f", torch.zeros(64, 64, 3, 3), None, "cpu").plan_for(32, 64, 64)[2] == "f32"
