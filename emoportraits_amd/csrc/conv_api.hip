@@ -14,6 +14,7 @@ conv_launch_fn conv_lookup_1x7_A(int, int);
 conv_launch_fn conv_lookup_1x7_B(int, int);
 conv_launch_fn conv_lookup_f16_3x3_D(int, int);
 conv_launch_fn conv_lookup_f16_1x1_D(int, int);
+conv_launch_fn conv_lookup_f16_3x3_G(int, int);
 
 enum { PREC_F32 = 0, PREC_F16 = 1 };   // MFMA operand format (accumulation and all tensors in HBM are fp32 either way)
 
@@ -28,9 +29,11 @@ static int shape_of_width(int Wl) {
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
   if (prec == PREC_F16) {
-    if (cfg != CFG_D) return 0;   // the fp16-operand kernels exist for the 64 x 256 tile only
+    if (cfg == CFG_G) return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : 0;   // 128 x 256 tile: 3x3 only
+    if (cfg != CFG_D) return 0;   // otherwise the fp16-operand kernels exist for the 64 x 256 tile only
     return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : (KH == 1 && KW == 1) ? EMO_CONV_KC_F16_1X1 : 0;
   }
+  if (cfg == CFG_G) return 0;                                   // fp16 operands only
   if (KH == 3 && KW == 3) return cfg == CFG_A ? EMO_CONV_KC_3X3_A : EMO_CONV_KC_3X3;
   if (cfg == CFG_D || cfg == CFG_E || cfg == CFG_F) return 0;   // 3x3 (x3) only
   if (KH == 1 && KW == 1) return EMO_CONV_KC_1X1;
@@ -48,7 +51,7 @@ extern "C" int emo_conv_pack_info(int KH, int KW, int cfg, int* BM, int* KC) {
 // output positions per block of a config (the tile the GroupNorm statistics of gn_stats are reduced over)
 extern "C" int emo_conv_tile_positions(int cfg) {
   if (cfg == CFG_A || cfg == CFG_B || cfg == CFG_C) return 128;
-  if (cfg == CFG_D || cfg == CFG_F) return 256;
+  if (cfg == CFG_D || cfg == CFG_F || cfg == CFG_G) return 256;
   if (cfg == CFG_E) return 512;
   return EMO_ERR_BAD_ARG;
 }
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* 
 // launch heuristic: split the K loop until the launch has >= 2 blocks per CU, keeping >= 8 stages per split
 extern "C" int emo_conv_pack_info_f16(int KH, int KW, int cfg, int* BM, int* KC) {
   if (!BM || !KC) return EMO_ERR_BAD_ARG;
-  if (cfg == CFG_D) *BM = 64; else return EMO_ERR_UNSUPPORTED;
+  if (cfg == CFG_D) *BM = 64; else if (cfg == CFG_G) *BM = 128; else return EMO_ERR_UNSUPPORTED;
   *KC = kc_of(KH, KW, cfg, PREC_F16);
   return *KC ? EMO_OK : EMO_ERR_UNSUPPORTED;
 }
@@ -93,8 +96,8 @@ extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int
                                      int cfg) {
   const int kc = kc_of(KH, KW, cfg);
   if (!kc || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 || cfg < 0 || cfg >= N_CFGS) return EMO_ERR_BAD_ARG;
-  const int bm = cfg == CFG_A ? 128 : (cfg == CFG_B || cfg == CFG_D || cfg == CFG_E) ? 64 : 32;
-  const int bp = (cfg == CFG_D || cfg == CFG_F) ? 256 : cfg == CFG_E ? 512 : 128;
+  const int bm = (cfg == CFG_A || cfg == CFG_G) ? 128 : (cfg == CFG_B || cfg == CFG_D || cfg == CFG_E) ? 64 : 32;
+  const int bp = (cfg == CFG_D || cfg == CFG_F || cfg == CFG_G) ? 256 : cfg == CFG_E ? 512 : 128;
   const long pos = (long)N * D * (ups ? 4 : 1) * H * W;
   const long blocks = ((pos + bp - 1) / bp) * ((Cout + bm - 1) / bm);
   const int nstages = ((Cin + kc - 1) / kc) * KD;
@@ -133,10 +136,13 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   conv_launch_fn fn = nullptr;
   if (prec == PREC_F16) {
     if (KD != 1 && !(KD == 3 && KH == 3)) return EMO_ERR_UNSUPPORTED;
-    if (cfg != CFG_D || Cin % 8) return EMO_ERR_UNSUPPORTED;
-    if (KH == 3 && KW == 3) fn = conv_lookup_f16_3x3_D(shape, ups);
+    if ((cfg != CFG_D && cfg != CFG_G) || Cin % 8) return EMO_ERR_UNSUPPORTED;
+    if (cfg == CFG_G) fn = (KH == 3 && KW == 3) ? conv_lookup_f16_3x3_G(shape, ups) : nullptr;
+    else if (KH == 3 && KW == 3) fn = conv_lookup_f16_3x3_D(shape, ups);
     else if (KH == 1 && KW == 1) fn = conv_lookup_f16_1x1_D(shape, ups);
     else return EMO_ERR_UNSUPPORTED;
+  } else if (cfg == CFG_G) {
+    return EMO_ERR_UNSUPPORTED;   // fp16 operands only
   } else if (cfg == CFG_D || cfg == CFG_E || cfg == CFG_F) {
     // position tiles of one depth slice (TZ = 1): 2-D layers, and 3-D layers whose depth taps run as K stages
     if (!(KH == 3 && KW == 3 && (KD == 1 || (KD == 3 && cfg != CFG_E)))) return EMO_ERR_UNSUPPORTED;

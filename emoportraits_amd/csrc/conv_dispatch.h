@@ -10,7 +10,9 @@ enum { SHAPE_W128 = 0, SHAPE_W64 = 1, SHAPE_W32 = 2, SHAPE_W16 = 3, SHAPE_W8 = 4
 // position than 1x128 / 2x64 / 4x32); 2-D 3x3 layers only
 // E = 64 co x 512 pos (waves 1x4, wave tile 64x128 = 8 accumulators): half of D's staging traffic per MFMA again, 2 waves / SIMD
 // F = 32 co x 256 pos (waves 1x4, wave tile 32x64): D for layers with 32 or fewer output channels
-enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_D = 3, CFG_E = 4, CFG_F = 5, N_CFGS = 6 };
+// G = 128 co x 256 pos (waves 2x2, wave tile 64x128 = 8 accumulators), fp16-operand 3x3 kernel only: the patch staged per block
+//     feeds twice the MFMAs of D and a step reads 6 fragments for 8 MFMAs instead of 4 for 4; one block per CU (512 registers)
+enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_D = 3, CFG_E = 4, CFG_F = 5, CFG_G = 6, N_CFGS = 7 };
 
 typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
 
@@ -35,6 +37,16 @@ typedef int (*conv_launch_fn)(ConvArgs, hipStream_t);
                                    : &conv_igemm_f16_launch<KH, KW, KC, 1, 4, 64, 2, 2, 1, 4, false>)            \
    : (shape) == SHAPE_W32 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 8, 32, 2, 2, 1, 4, true>              \
                                    : &conv_igemm_f16_launch<KH, KW, KC, 1, 8, 32, 2, 2, 1, 4, false>)            \
+                          : (conv_launch_fn) nullptr)
+
+// fp16-operand kernels, 128 x 256 tiles (CFG_G)
+#define CONV_FOR_SHAPE_F16_G(KH, KW, KC, shape, ups)                                                            \
+  ((shape) == SHAPE_W128 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 2, 128, 2, 4, 2, 2, true>              \
+                                  : &conv_igemm_f16_launch<KH, KW, KC, 1, 2, 128, 2, 4, 2, 2, false>)            \
+   : (shape) == SHAPE_W64 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 4, 64, 2, 4, 2, 2, true>              \
+                                   : &conv_igemm_f16_launch<KH, KW, KC, 1, 4, 64, 2, 4, 2, 2, false>)            \
+   : (shape) == SHAPE_W32 ? ((ups) ? &conv_igemm_f16_launch<KH, KW, KC, 1, 8, 32, 2, 4, 2, 2, true>              \
+                                   : &conv_igemm_f16_launch<KH, KW, KC, 1, 8, 32, 2, 4, 2, 2, false>)            \
                           : (conv_launch_fn) nullptr)
 
 #define CONV_FOR_SHAPE(KH, KW, KC, TM, TP, WGM, WGP, shape, ups)                                              \

@@ -73,8 +73,8 @@ struct ConvCfgH {
   static constexpr int NDMA_MIN = (ASZ_H * 2) / 4096;    // LDS-DMA instructions EVERY wave issues per stage (some issue one more)
   static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
   // 2 blocks per CU at most: 64 accumulator + 48 fragment + 40 in-flight patch + 32 scale / shift registers per lane do
-  // not fit the 168-VGPR budget of 3 waves per SIMD
-  static constexpr int OCC = BY_LDS < 1 ? 1 : (BY_LDS > 2 ? 2 : BY_LDS);
+  // not fit the 168-VGPR budget of 3 waves per SIMD; with 8 accumulator tiles (CFG_G) one block per CU, 512 registers
+  static constexpr int OCC = (BY_LDS < 1 || TM * TP > 4) ? 1 : (BY_LDS > 2 ? 2 : BY_LDS);
   static_assert(WGM * WGP == 4, "4 waves per block");
   static_assert(TZ == 1 && TR * TW == BP, "planar position tile of BP pixels");
   static_assert(KH == KW && (KH == 1 || KH == 3), "1x1 and 3x3 kernels");
@@ -83,7 +83,7 @@ struct ConvCfgH {
   static_assert(PR * NQ <= QPG, "one interior quad per thread and stage");
   static_assert(NHALO <= 64, "the halo pixels of a stage are staged by one wave");
   static_assert((ASZ_H * 2) % 16 == 0, "weight tile must be 16-byte copyable");
-  static_assert(TM * TP <= 4, "accumulator budget");
+  static_assert(TM * TP <= 8, "accumulator budget");
   static_assert(2 * BUF >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the stage buffers");
 };
 

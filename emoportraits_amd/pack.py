@@ -14,9 +14,9 @@ import torch
 
 from . import hip
 
-CFG_A, CFG_B, CFG_C, CFG_D, CFG_E, CFG_F = 0, 1, 2, 3, 4, 5
-_BM = {CFG_A: 128, CFG_B: 64, CFG_C: 32, CFG_D: 64, CFG_E: 64, CFG_F: 32}            # output channels per block
-_BP = {CFG_A: 128, CFG_B: 128, CFG_C: 128, CFG_D: 256, CFG_E: 512, CFG_F: 256}       # output positions per block
+CFG_A, CFG_B, CFG_C, CFG_D, CFG_E, CFG_F, CFG_G = 0, 1, 2, 3, 4, 5, 6   # G: fp16-operand 3x3 kernel only (128 x 256 tile)
+_BM = {CFG_A: 128, CFG_B: 64, CFG_C: 32, CFG_D: 64, CFG_E: 64, CFG_F: 32, CFG_G: 128}            # output channels per block
+_BP = {CFG_A: 128, CFG_B: 128, CFG_C: 128, CFG_D: 256, CFG_E: 512, CFG_F: 256, CFG_G: 256}       # output positions per block
 _PACK_AS = {CFG_D: CFG_B, CFG_E: CFG_B, CFG_F: CFG_C}                                 # configs sharing another one's weight layout
 
 
@@ -122,7 +122,9 @@ def pack_weight(w, cfg):
 # for a quarter of the work
 # the 64 x 256 tile (D) halves the weight-tile traffic per MFMA and stages 25-33 % less patch per position: 131-141 TF on
 # every 2-D 3x3 decoder layer (B: 126-135), bench 127.3 -> 132.0 frames/s (profiles/r2_conv_microbench.jsonl)
-_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 1.03, CFG_E: 0.0, CFG_F: 0.92}
+_CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 1.03, CFG_E: 0.0, CFG_F: 0.92, CFG_G: 0.0}
+if __import__("os").environ.get("EMO_F16_CFG_G") == "1":   # opt-in: plan fp16-operand 3x3 layers with the 128 x 256 tile
+    _CFG_EFF[CFG_G] = 1.15                                  # (one block per CU; built and parity-tested, not yet the default)
 if __import__("os").environ.get("EMO_CONV_CFG_D") == "0":   # A/B switch: plan without the 64 x 256 tile
     _CFG_EFF[CFG_D] = 0.0
 if __import__("os").environ.get("EMO_CONV_CFG_E") == "1":   # A/B switch: plan with the 64 x 512 tile
@@ -258,11 +260,11 @@ class PackedConv:
             self.packed(first if first in self.allowed else CFG_B)
 
     def packed(self, cfg, precision="f32"):
-        """packed weights for a block config: fp32 layout, or the fp16 operand layout (64 x 256 tile only)"""
+        """packed weights for a block config: fp32 layout, or the fp16 operand layout (64 x 256 and 128 x 256 tiles)"""
         if precision == "f16":
-            key = ("f16", CFG_D)
+            key = ("f16", CFG_G if cfg == CFG_G else CFG_D)
             if key not in self._packed:
-                self._packed[key] = pack_weight_f16(self._weight, CFG_D).to(self.device)
+                self._packed[key] = pack_weight_f16(self._weight, key[1]).to(self.device)
             return self._packed[key]
         cfg = _PACK_AS.get(cfg, cfg)
         if cfg not in self._packed:
@@ -278,11 +280,14 @@ class PackedConv:
         """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output; `affine`: the
         launch carries a per-sample input scale / shift (the fp16-operand kernel keeps those in a 1024-entry LDS table);
         `aligned16`: the input pointer is 16-byte aligned (that kernel loads 16-byte quads)"""
-        if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D) and aligned16 \
-                and not (affine and self.cin > F16_AFFINE_MAX_CIN):
-            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), "f16")
+        if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D, CFG_G) and aligned16 \
+                and not (affine and self.cin > F16_AFFINE_MAX_CIN) and not (self.pinned_cfg == CFG_G and self.kh != 3):
+            tiles = (self.pinned_cfg,) if self.pinned_cfg is not None else \
+                (CFG_D, CFG_G) if (_CFG_EFF[CFG_G] > 0 and self.kh == 3) else (CFG_D,)
+            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, tiles, "f16")
             return cfg, ks, "f16"
-        allowed = (self.pinned_cfg,) if self.pinned_cfg is not None else self.allowed
+        pinned = None if self.pinned_cfg == CFG_G else self.pinned_cfg   # (G exists for fp16 operands only)
+        allowed = (pinned,) if pinned is not None else self.allowed
         if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl):
             allowed = allowed + (CFG_D,)
             if _CFG_EFF[CFG_F] > 0 and (not ups or Wl % 128 == 0):

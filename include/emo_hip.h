@@ -163,7 +163,8 @@ int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int W, int KD,
 /* Reduced-precision mode (BASELINE.json configs[4], "fp16 MFMA convs"; opt-in per layer, never the default): the same
  * convolution with fp16 MFMA operands (v_mfma_f32_32x32x16_f16) and fp32 accumulation.  Tensors in HBM stay fp32; the
  * producer's norm + ReLU is applied in fp32 and rounded to fp16 on the way into LDS.  3x3 (2-D / 3-D) and 1x1 kernels,
- * cfg 3 (64 x 256 tile) only, output widths that are multiples of 128, or 64 / 32, Cin % 8 == 0.  wpk16: fp16 weights packed
+ * cfg 3 (64 x 256 tile) or, 3x3 only, cfg 6 (128 x 256 tile, one block per CU); output widths that are multiples of 128, or
+ * 64 / 32; Cin % 8 == 0; x 16-byte aligned; Cin <= 1024 when scale / shift are given.  wpk16: fp16 weights packed
  * [co_tile][Cin chunk of KC][kd][q = KC/16][tap][half][BM][8] (channel in chunk = 16*q + 8*half + 0..7), BM / KC from
  * emo_conv_pack_info_f16.  Other arguments, incl. gn_stats, as emo_conv_igemm_f32. */
 int emo_conv_pack_info_f16(int KH, int KW, int cfg, int* BM, int* KC);

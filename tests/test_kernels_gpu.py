@@ -119,6 +119,22 @@ def test_conv_config_D_tile_statistics_and_unsupported_shapes():
         ops.conv_igemm(torch.randn(1, 16, 16, 16, device=DEV), pack.PackedConv("d3", torch.randn(64, 16, 3, 3), None, DEV, cfg=3))
 
 
+def test_conv_fp16_config_G_tile_statistics():
+    """128 x 256 tile of the fp16-operand kernel (config 6): GroupNorm tile statistics of its epilogue (2 x 2 waves) describe
+    the tensor it wrote"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 64, 64, generator=g)
+    w = torch.randn(160, 32, 3, 3, generator=g) / 17
+    layer = pack.PackedConv("g", w, None, DEV, cfg=6, precision="f16")
+    assert layer.plan_for(64, 64, 64)[0] == 6
+    out, st = ops.conv_igemm(x.to(DEV), layer, want_stats=True, ksplit=1)
+    assert st.cnt == 256 and st.stats.shape == (2, 64 * 64 // 256, 160, 2)
+    s1, h1 = ops.groupnorm_affine(out, stats=st)
+    s0, h0 = ops.groupnorm_affine(out)
+    assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item() and (h1 - h0).abs().max().item() <= 2e-6
+    assert 1e-5 < rel_err(out, F.conv2d(x, w, padding=1)) < 3e-3
+
+
 @pytest.mark.parametrize("cfg", [3, 5])
 @pytest.mark.parametrize("dims", [(8, 32, 32), (4, 64, 64), (2, 128, 128), (64, 64), (128, 128)])
 def test_conv_256_position_tiles_2d_and_3d(cfg, dims):
@@ -169,6 +185,13 @@ def test_conv_split_k_equals_single_pass(case, ksplit):
     dict(N=1, Cin=24, Cout=64, dims=(256, 256), k=3, cfg=3, affine=True, relu_in=True, res=True),
     dict(N=1, Cin=32, Cout=64, dims=(64, 64), k=3, cfg=3, ups=True, affine=True, relu_in=True),    # 2 x 128 tile on source pixels
     dict(N=2, Cin=16, Cout=96, dims=(32, 32), k=3, cfg=3, ups=True, affine=True),                  # 4 x 64 tile, no ReLU
+    # the 128 x 256 tile (config 6, one block per CU): channel tail, upsample + residual, 3-D taps, statistics-free K split
+    dict(N=2, Cin=40, Cout=200, dims=(64, 64), k=3, cfg=6, affine=True, relu_in=True, res=True),
+    dict(N=2, Cin=64, Cout=128, dims=(16, 16), k=3, cfg=6, ups=True, res=True, res_ups=True, act="tanh"),
+    dict(N=1, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=6, affine=True, relu_in=True),
+    dict(N=1, Cin=72, Cout=130, dims=(8, 32, 32), k=3, cfg=6, affine=True, relu_in=True, bias=False),
+    dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=6, affine=True, relu_in=True, ksplit=3),
+    dict(N=1, Cin=32, Cout=256, dims=(64, 64), k=3, cfg=6, ups=True, affine=True, relu_in=True),
 ])
 def test_conv_fp16_operands(case):
     """opt-in reduced-precision mode (BASELINE configs[4]): fp16 MFMA operands (32x32x16), fp32 accumulation, 64 x 256 tile.
