@@ -151,9 +151,13 @@ __device__ __forceinline__ void emo_touch(float& v) { asm volatile("" : "+v"(v))
 // CU whatever its width: tools/microbench/vmem_rate.hip), and the epilogue of a 64 x 256 tile was 64 store instructions per
 // wave; tools/fit_conv_overhead.py prices the per-block fixed cost at 7 % (fp32) to 30 % (fp16 operands) of a 128-channel
 // layer at 512^2.
+#ifndef EMO_CONV_NT_STORE
+#define EMO_CONV_NT_STORE 0   /* 1: non-temporal output stores (A/B measurement) */
+#endif
 __device__ __forceinline__ void emo_store4(float* p, const floatx4& v, bool aligned) {
   if (aligned) {
-    *reinterpret_cast<floatx4*>(p) = v;
+    if (EMO_CONV_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<floatx4*>(p));
+    else *reinterpret_cast<floatx4*>(p) = v;
   } else {
     p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3];
   }
