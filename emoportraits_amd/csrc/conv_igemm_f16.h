@@ -13,16 +13,15 @@
 //     GroupNorm affine + ReLU in fp32, zero padding, saturation to +-65504, round-to-nearest-even to fp16, 4 ds_write_b128.
 //     Why quads: global loads on this chip are bound by wave-INSTRUCTIONS, not bytes -- one per ~17 cycles per CU whether a
 //     lane asks for 4 or 16 bytes (tools/microbench/vmem_rate.hip: 15 / 27 / 53 B/clk/CU for dword / x2 / x4).  Staging
-//     pixel by pixel (one dword load per element, the first round-2 kernel) needs 394 VMEM instructions per CU and stage =
-//     ~6.9k cycles against 2.3k cycles of MFMA work: that, not the matrix pipe, LDS or instruction issue, held it at
-//     0.22-0.35 of the fp16 peak however the loop was scheduled.  Quads need 8 per wave and stage (+8 dword loads in one
-//     wave for the two halo columns of a 3x3 patch).
+//     pixel by pixel (one dword load per element, the first kernel of round 2) needs 394 VMEM instructions per CU and stage
+//     = ~6.9k cycles against 2.3k cycles of MFMA work; quads need 8 per wave and stage (+8 dword loads in one wave for the
+//     two halo columns of a 3x3 patch): a third of that, worth +5-10 % (what bounds the kernel now: DESIGN.md section 3.1).
 //   * with a fused nearest x2 upsample the LDS patch holds the SOURCE pixels (a quarter of the upsampled patch): staging
 //     never expands, the B-fragment slots of a lane map its output pixel and tap to (y+r-1)>>1, (x+s-1)>>1.
 //   * LDS patch slots: an interior pixel (patch row pr, quad qx, i = x & 3) lives at slot i * SUB + pr * NQ1 + qx, the left /
 //     right halo pixel of a row at sub-row 0 / 1 of the pseudo-quad qx = NQ of that row.  The 4 stores of a lane then go to
-//     4 sub-rows, consecutive lanes to consecutive 16-byte slots (conflict-free), and SUB = 4 (mod 16) spreads the 16 lanes
-//     of a ds_read_b128 group over all 64 banks for every tap shift.
+//     4 sub-rows, consecutive lanes to consecutive 16-byte slots, and SUB = 4 (mod 16) staggers the sub-rows over the banks
+//     (measured: a fifth of the LDS cycles are still conflict cycles; LDS is busy 37 % of the time, not the limiter).
 //   * a stage is KC = 16 channels (3x3: 9 MFMA steps of K = 16) or 32 (1x1: 2 steps); tile 64 output channels x 256
 //     positions, 2 blocks per CU (LDS: 18 KB weights + 17 KB patch per stage, double-buffered).
 //   * software pipeline ("rolling"): EVERY VMEM instruction of the K loop is inline asm -- the patch loads and the weight
