@@ -42,6 +42,10 @@
 #pragma once
 #include "common.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -300,17 +304,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, floatx16 (&acc_
                                 one that is transforming / storing its patch (cdna_hip_programming.md T5).  Measured +0.4 %
                                 (132.4 vs 131.8 frames/s, twice each) */
 #endif
+#ifndef EMO_CONV_QUAD_1X1
+#define EMO_CONV_QUAD_1X1 0   /* 1: 1x1 kernels stage their patch by 16-byte quads (see the kernel template); 0: element by element.
+                                 Measured neutral (tools/session/r2_call22.sh: 1536->512 at 64^2 115.6 vs 114.3 TF, 512->320 98.5 /
+                                 111.5 vs 93.7 / 113.1, all 225 GPU tests green with it on): the loop shrinks from 252 to 175
+                                 instructions per stage and the rate does not move -- the 1x1 layers are not bound by staging
+                                 instructions; their 128 x 128 tile re-reads 9x more patch per MFMA than a 3x3 tile from L2 */
+#endif
 #ifndef EMO_CONV_ABLATE
 #define EMO_CONV_ABLATE 0   /* timing experiments only (results are WRONG for any value != 0): 1 = no global loads, no LDS-DMA and
                                no LDS stores in the loop; 5 = LDS stores of stale registers, no global loads, no LDS-DMA */
 #endif
 
-template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS>
+// QUAD (1x1 kernels without upsample, chosen by the launcher when the input is 16-byte aligned): the patch is staged by quads
+// -- a lane loads 4 consecutive positions of one channel with one 16-byte load and stores them with one ds_write_b128 -- and
+// the per-channel scale / shift arrive as one per-lane load each.  A 1x1 stage has 9x less MFMA work per staged element than
+// a 3x3 one, and global loads are bound by their number (tools/microbench/vmem_rate.hip): per wave and stage 2 + 4 VMEM
+// instructions instead of 8 + 8.  The LDS image, and with it the MFMA side of the kernel, is the same.
+template <int KH, int KW, int KC, int TZ, int TR, int TW, int TM, int TP, int WGM, int WGP, bool UPS, bool QUAD = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>::OCC,
                                    ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>::OCC)))
 void conv_igemm_kernel(const ConvArgs a) {
   using Cfg = ConvCfg<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
+  static_assert(!QUAD || (KH == 1 && KW == 1 && !UPS), "quad staging: 1x1 kernels on the source grid");
   constexpr int BM = Cfg::BM, TAPS = Cfg::TAPS, PR = Cfg::PR, PW = Cfg::PW, CHS = Cfg::CHS;
   constexpr int ASZ = Cfg::ASZ, BUF = Cfg::BUF, NPE = Cfg::NPE, NSTEPS = Cfg::NSTEPS;
   constexpr int SW = Cfg::SW, WPC = Cfg::WPC, CPW = Cfg::CPW, EPC = Cfg::EPC;
@@ -405,6 +422,23 @@ void conv_igemm_kernel(const ConvArgs a) {
     p_hi[i] = p_ok[i] ? __builtin_huge_valf() : 0.0f;
   }
 
+  // ---- quad staging map (QUAD): thread t owns quad t % QPC of channel slot t / QPC; a stage has KC / CPP passes ----
+  constexpr int QPC = QUAD ? CHS / 4 : 1;             // quads per channel
+  constexpr int CPP = QUAD ? 256 / QPC : 1;           // channels staged per pass of the whole block
+  constexpr int NPASS = QUAD ? KC / CPP : 1;
+  static_assert(!QUAD || (CHS % 4 == 0 && TW % 4 == 0 && 256 % QPC == 0 && KC % CPP == 0), "whole quads, whole passes");
+  const int q_i = tid % QPC, q_cs = tid / QPC;
+  unsigned q_off = 0;                                 // byte offset of the quad inside a channel volume
+  if (QUAD) {
+    const int e0 = 4 * q_i;
+    const int pz = e0 / (PR * PW), rem2 = e0 - pz * (PR * PW);
+    const int pr = rem2 / PW, pc = rem2 - pr * PW;
+    q_off = (unsigned)(((z0 + pz) * a.H + (y0 + pr)) * a.W + (x0 + pc)) * 4u;   // 1x1: no halo, always inside the volume
+  }
+  floatx4 qv[NPASS];    // the quads of a stage (pinned asm loads)
+  float qsc[NPASS], qsh[NPASS];
+  bool qcv[NPASS];      // the quad's channel exists
+
   const int nstages_all = a.n_cchunks * a.KD;
   const int st_begin = ks * a.stages_per_split;                       // this block's share of the K loop
   const int st_end = min(nstages_all, st_begin + a.stages_per_split);
@@ -429,7 +463,19 @@ void conv_igemm_kernel(const ConvArgs a) {
   }
 /* the same for a stage given as (channel chunk, depth tap): the K loop steps these instead of dividing every stage */
 #define EMO_ISSUE_PATCH_AT(cc_, t_, PINNED_)                                                          \
-  {                                                                                                   \
+  if (QUAD) {                                                                                         \
+    _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                            \
+      const int c_ = (cc_) * KC + ps * CPP + q_cs;                                                    \
+      qcv[ps] = c_ < a.Cin;                                                                           \
+      const unsigned cs_ = qcv[ps] ? (unsigned)c_ : 0u;                                               \
+      /* 32-bit byte offsets inside the sample: the launcher checks Cin * D * H * W * 4 < 2^32 */     \
+      qv[ps] = emo_gload4_pinned(xn, q_off + cs_ * (unsigned)DHW * 4u);                               \
+      if (has_affine) {                                                                               \
+        qsc[ps] = emo_gload_pinned(scale_n, cs_ * 4u);                                                \
+        qsh[ps] = emo_gload_pinned(shift_n, cs_ * 4u);                                                \
+      }                                                                                               \
+    }                                                                                                 \
+  } else {                                                                                            \
     const int ci0_ = (cc_) * KC;                                                                      \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
       const int c_ = ci0_ + g * SW + chan0;                                                           \
@@ -463,7 +509,13 @@ void conv_igemm_kernel(const ConvArgs a) {
 
 /* wait for the pinned loads of EMO_ISSUE_PATCH and pin every consumer behind the wait */
 #define EMO_WAIT_PATCH()                                                                              \
-  {                                                                                                   \
+  if (QUAD) {                                                                                         \
+    emo_wait_vmem0();                                                                                 \
+    _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                            \
+      emo_touch4(qv[ps]);                                                                             \
+      if (has_affine) { emo_touch(qsc[ps]); emo_touch(qsh[ps]); }                                     \
+    }                                                                                                 \
+  } else {                                                                                            \
     emo_wait_vmem0();                                                                                 \
     _Pragma("unroll") for (int q_ = 0; q_ < NPE; ++q_) emo_touch(pv[q_]);                             \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) { emo_touch(sc[g]); emo_touch(sh[g]); }           \
@@ -486,7 +538,18 @@ void conv_igemm_kernel(const ConvArgs a) {
 
 /* Stores are unconditional: lanes beyond the tile write to a private dump slot (address select, no branch). */ \
 #define EMO_STORE_STAGE(buf_)                                                                         \
-  {                                                                                                   \
+  if (QUAD) {                                                                                         \
+    float* Ps_ = (buf_) + ASZ;                                                                        \
+    _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                            \
+      float sc_ = has_affine ? qsc[ps] : 1.0f, sh_ = has_affine ? qsh[ps] : 0.0f;                     \
+      sc_ = qcv[ps] ? sc_ : 0.0f;                     /* a missing channel stages zeros */            \
+      sh_ = qcv[ps] ? sh_ : 0.0f;                                                                     \
+      floatx4 v_;                                                                                     \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                   \
+        v_[e] = __builtin_amdgcn_fmed3f(__fmaf_rn(qv[ps][e], sc_, sh_), relu_floor, __builtin_huge_valf()); \
+      *reinterpret_cast<floatx4*>(Ps_ + (ps * CPP + q_cs) * CHS + 4 * q_i) = v_;                      \
+    }                                                                                                 \
+  } else {                                                                                            \
     float* Ps_ = (buf_) + ASZ;                                                                        \
     _Pragma("unroll") for (int g = 0; g < CPW; ++g) {                                                 \
       float* Pc_ = Ps_ + (g * SW + chan0) * CHS;                                                      \
@@ -509,6 +572,7 @@ void conv_igemm_kernel(const ConvArgs a) {
   }
 
   constexpr bool PINNED = EMO_CONV_PIPE == 2;
+  static_assert(!QUAD || PINNED, "quad staging exists for the pinned-load schedule only");
   constexpr int STORE_STEP = (NSTEPS * (PINNED ? EMO_CONV_STORE_EIGHTHS : 4)) / 8;
 
   // ---- prologue: stage st_begin into buffer 0 ----
@@ -611,18 +675,21 @@ void conv_igemm_kernel(const ConvArgs a) {
 #undef EMO_ISSUE_WEIGHTS
 #undef EMO_STORE_STAGE
 
-// opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) once per (kernel, device)
+// opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) once per (kernel, device).  Every instantiation
+// has the same function-pointer TYPE, so the bookkeeping is keyed by the pointer VALUE.
 template <typename K>
 static int emo_raise_dynamic_lds(K kern) {
-  static bool raised[64] = {};   // per device; idempotent, so a benign race
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> raised;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  if (dev < 0 || dev >= 64) return EMO_ERR_UNSUPPORTED;
-  if (!raised[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const std::pair<const void*, int> key(reinterpret_cast<const void*>(kern), dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!raised.count(key)) {
+    e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    raised[dev] = true;
+    raised.insert(key);
   }
   return EMO_OK;
 }
@@ -641,7 +708,14 @@ int conv_igemm_launch(ConvArgs a, hipStream_t s) {
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
   const size_t lds = (size_t)Cfg::LDS_BYTES;
   if (lds > 160 * 1024) return EMO_ERR_UNSUPPORTED;
-  auto kern = conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS>;
+  // 1x1 kernels stage by 16-byte quads when they can: input 16-byte aligned (rows are: W % 4 == 0 follows from the tile
+  // shapes) and 32-bit byte offsets inside a sample
+  constexpr bool CAN_QUAD = KH == 1 && KW == 1 && !UPS && EMO_CONV_PIPE == 2 && EMO_CONV_QUAD_1X1 &&
+                            (TZ * TR * TW) % 4 == 0 && 256 % ((TZ * TR * TW) / 4) == 0 && KC % (256 / ((TZ * TR * TW) / 4)) == 0;
+  const bool quad = CAN_QUAD && (reinterpret_cast<unsigned long long>(a.x) & 15ull) == 0 && (a.W & 3) == 0 &&
+                    (unsigned long long)a.Cin * a.D * a.H * a.W * 4ull < (1ull << 32);
+  void (*kern)(const ConvArgs) = conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS, false>;
+  if (quad) kern = conv_igemm_kernel<KH, KW, KC, TZ, TR, TW, TM, TP, WGM, WGP, UPS, CAN_QUAD>;
   if (lds > 64 * 1024) {
     const int rc = emo_raise_dynamic_lds(kern);
     if (rc != EMO_OK) return rc;
