@@ -27,6 +27,13 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-Wno-unused-function", "-Wno-unused-variable", "-mllvm", "-pragma-unroll-threshold=100000"]
 
 
+# per-file extra flags.  gs3d_tile_pad_*: hipcc's SLP vectorizer turns the sampler's per-channel multiply / add into v_pk_*_f32
+# and, to feed them, hoists a {w, w} splat of every corner weight out of the loops -- 16 extra VGPRs per owned voxel, i.e.
+# spills at the 4-waves-per-SIMD budget (measured: 104 spilled VGPRs with, 0 without).
+EXTRA_FLAGS = {"gs3d_tile_pad_zeros.hip": ["-fno-slp-vectorize"], "gs3d_tile_pad_border.hip": ["-fno-slp-vectorize"],
+               "gs3d_tile_pad_reflection.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -38,6 +45,8 @@ def _digest(paths):
             h.update(p.encode())
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    for p in sorted(paths):
+        h.update(" ".join(EXTRA_FLAGS.get(os.path.basename(p), [])).encode())
     return h.hexdigest()
 
 
@@ -49,7 +58,8 @@ def _compile(src):
     stamp = obj + ".sha"
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    extra = EXTRA_FLAGS.get(os.path.basename(src), [])
+    cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -19,6 +19,8 @@
 // (row a2: notebooks/infer.py:441-444, :583-588), removing the 0.79 MB grid tensor from HBM.
 #include "common.h"
 
+#define EMO_GS3D_TILE_FLAG (1 << 30)   /* variant bit: NCDHW -> NCDHW through the LDS-staged planar kernel (gs3d_tile.h) */
+
 namespace {
 
 struct Taps {
@@ -815,6 +817,12 @@ int launch_pad(const float* vol, const float* grid, const float* theta, const fl
 
 }  // namespace
 
+int emo_gs3d_tile_dispatch(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
+                           const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                           int64_t vol_batch_stride, int padding_mode, int in_layout, int out_layout, int variant,
+                           int grid_kind, void* stream);
+int emo_repack_p4_dispatch(const float* in, float* out, int N, int C, int DHW, int to_p4, void* stream);
+
 extern "C" int emo_grid_sample3d_f32(const float* vol, const float* grid, const float* theta, const float* lin_x,
                                      const float* lin_y, const float* lin_z, float* out, int N, int C, int D, int H,
                                      int W, int Do, int Ho, int Wo, int64_t vol_batch_stride, int padding_mode,
@@ -828,6 +836,16 @@ extern "C" int emo_grid_sample3d_f32(const float* vol, const float* grid, const 
   if (N > 65535) return EMO_ERR_UNSUPPORTED;
   if ((long)D * H * W >= (1L << 31) / 4 || (long)Do * Ho * Wo >= (1L << 31) / 4) return EMO_ERR_UNSUPPORTED;
   if (!emo_aligned16(vol) || !emo_aligned16(out)) return EMO_ERR_ALIGN;
+  if (in_layout == EMO_LAYOUT_P4)
+    return emo_gs3d_tile_dispatch(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_batch_stride,
+                                  padding_mode, in_layout, out_layout, variant, grid_kind, stream);
+  if (in_layout == EMO_LAYOUT_NCDHW && out_layout == EMO_LAYOUT_NCDHW && (variant & EMO_GS3D_TILE_FLAG)) {
+    // LDS-staged planar kernel; shapes it does not take (W % 4, huge extents) fall through to the direct-gather kernel
+    const int rc = emo_gs3d_tile_dispatch(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_batch_stride,
+                                          padding_mode, in_layout, out_layout, variant & ~EMO_GS3D_TILE_FLAG, grid_kind, stream);
+    if (rc != EMO_ERR_UNSUPPORTED) return rc;
+    variant = 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   switch (padding_mode) {
     case EMO_PAD_ZEROS:
@@ -858,6 +876,8 @@ extern "C" int emo_volume_repack_f32(const float* in, float* out, int N, int C, 
                                      void* stream) {
   if (!in || !out || N <= 0 || C <= 0 || DHW <= 0) return EMO_ERR_BAD_ARG;
   if (N > 65535) return EMO_ERR_UNSUPPORTED;
+  if (to_channels_last == 4 || to_channels_last == 5)     // NCDHW <-> packed-4
+    return emo_repack_p4_dispatch(in, out, N, C, DHW, to_channels_last == 4, stream);
   if (to_channels_last == 2 || to_channels_last == 3) {   // NCDHW <-> CG8
     if (C % 32 || C / 8 > 64) return EMO_ERR_UNSUPPORTED;
     dim3 g(emo_cdiv(DHW, 64), 8, N);

@@ -23,8 +23,10 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
                   variant=0, out=None, delta=None):
     """5-D trilinear grid_sample, align_corners=False  (== F.grid_sample(vol, grid, padding_mode=...)).
 
-    vol    [Nv,C,D,H,W] ('ncdhw'), [Nv,D,H,W,C] ('ndhwc') or [Nv,8,D,H,W,C/8] ('cg8': 8 channel groups, one per XCD, see
+    vol    [Nv,C,D,H,W] ('ncdhw'), [Nv,C/4,D,H,W,4] ('p4': packed channel quads, the layout of the LDS-staged tile kernels,
+           out_layout 'p4' or 'ncdhw'), [Nv,D,H,W,C] ('ndhwc') or [Nv,8,D,H,W,C/8] ('cg8': 8 channel groups, one per XCD, see
            include/emo_hip.h EMO_LAYOUT_CG8; out_layout 'cg8' or 'ncdhw'); Nv == N or 1 (volume shared by all N samples).
+    variant  tuning word (include/emo_hip.h); with 'ncdhw' -> 'ncdhw', TILE selects the LDS-staged planar kernel.
     grid   [N,Do,Ho,Wo,3]; or None with theta [N,3,4] / [N,4,4]: the sampling grid is then the head-pose affine of
            the identity lattice (notebooks/infer.py:583-588), generated inside the kernel, output size = D,H,W.
     delta  [N,3,Do,Ho,Wo] planar deltas: grid = identity lattice + delta (WarpGenerator output,
@@ -35,10 +37,15 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     if theta is not None:
         theta = theta.float().contiguous()      # e.g. torch.linalg.inv returns a column-major result
         hip.require_cuda_f32(theta)
-    layouts = {"ncdhw": hip.LAYOUT_NCDHW, "ndhwc": hip.LAYOUT_NDHWC, "cg8": hip.LAYOUT_CG8}
+    layouts = {"ncdhw": hip.LAYOUT_NCDHW, "ndhwc": hip.LAYOUT_NDHWC, "cg8": hip.LAYOUT_CG8, "p4": hip.LAYOUT_P4}
     if in_layout not in layouts or out_layout not in layouts:
-        raise ValueError("layouts are 'ncdhw', 'ndhwc' or 'cg8'")
-    if in_layout == "ndhwc":
+        raise ValueError("layouts are 'ncdhw', 'p4', 'ndhwc' or 'cg8'")
+    if in_layout == "p4":
+        Nv, Q4, D, H, W, four = vol.shape
+        if four != 4:
+            raise ValueError("a 'p4' volume is [N, C/4, D, H, W, 4]")
+        C = 4 * Q4
+    elif in_layout == "ndhwc":
         Nv, D, H, W, C = vol.shape
     elif in_layout == "cg8":
         Nv, G8, D, H, W, CG = vol.shape
@@ -74,7 +81,8 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     if Nv not in (1, N):
         raise ValueError(f"volume batch {Nv} does not match grid batch {N}")
     stride = 0 if (Nv == 1 and N > 1) else C * D * H * W
-    shape = {"ndhwc": (N, Do, Ho, Wo, C), "cg8": (N, 8, Do, Ho, Wo, C // 8), "ncdhw": (N, C, Do, Ho, Wo)}[out_layout]
+    shape = {"ndhwc": (N, Do, Ho, Wo, C), "cg8": (N, 8, Do, Ho, Wo, C // 8), "ncdhw": (N, C, Do, Ho, Wo),
+             "p4": (N, C // 4, Do, Ho, Wo, 4)}[out_layout]
     if out is None:
         out = torch.empty(shape, device=vol.device, dtype=torch.float32)
     else:
@@ -113,6 +121,45 @@ def volume_to_channels_last(vol):
     N, C, D, H, W = vol.shape
     out = torch.empty((N, D, H, W, C), device=vol.device, dtype=torch.float32)
     hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, C, D * H * W, 1, hip.current_stream()),
+              "emo_volume_repack_f32")
+    return out
+
+
+TILE = 1 << 30      # grid_sample3d(variant=TILE | tuning): NCDHW -> NCDHW through the LDS-staged planar kernel
+
+
+def tile_variant(tile=None, units_per_block=0, lds_kib=0, threads=256):
+    """tuning word of the LDS-staged sampler (include/emo_hip.h): tile = (tx, ty, tz) output voxels per block, powers of two
+    with tx * ty * tz in {threads, 2 * threads}; 0 / None = the kernel's default"""
+    v = 0
+    if tile is not None:
+        tx, ty, tz = (int(t).bit_length() - 1 for t in tile)
+        v |= tx | (ty << 4) | (tz << 8)
+    v |= (int(units_per_block) & 31) << 12
+    v |= (int(lds_kib) & 255) << 17
+    if threads == 512:
+        v |= 1 << 25
+    return v
+
+
+def volume_to_p4(vol):
+    """[N,C,D,H,W] -> [N,C/4,D,H,W,4] (EMO_LAYOUT_P4: a voxel's channel quad is one 16-byte slot)"""
+    lib = hip.load()
+    hip.require_cuda_f32(vol)
+    N, C, D, H, W = vol.shape
+    out = torch.empty((N, C // 4, D, H, W, 4), device=vol.device, dtype=torch.float32)
+    hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, C, D * H * W, 4, hip.current_stream()),
+              "emo_volume_repack_f32")
+    return out
+
+
+def volume_from_p4(vol):
+    """[N,C/4,D,H,W,4] -> [N,C,D,H,W]"""
+    lib = hip.load()
+    hip.require_cuda_f32(vol)
+    N, Q, D, H, W, _ = vol.shape
+    out = torch.empty((N, 4 * Q, D, H, W), device=vol.device, dtype=torch.float32)
+    hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, 4 * Q, D * H * W, 5, hip.current_stream()),
               "emo_volume_repack_f32")
     return out
 

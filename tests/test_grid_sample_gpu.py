@@ -21,6 +21,13 @@ PADS = ["zeros", "border", "reflection"]
 DEV = "cuda:0"
 
 
+# (tag, tuning word) of the LDS-staged kernels: default; one voxel per thread; two bricks per thread; 512-thread blocks;
+# a 2 KiB stage (union box never fits: brick-by-brick and direct passes); 1 channel unit per block
+TILE_TUNINGS = [("", 0), ("_8x8x4", ops.tile_variant((8, 8, 4))), ("_16x8x4", ops.tile_variant((16, 8, 4), units_per_block=5)),
+                ("_8x8x16_512", ops.tile_variant((8, 8, 16), threads=512)),
+                ("_tiny_stage", ops.tile_variant((8, 8, 8), lds_kib=2)), ("_upb1", ops.tile_variant((4, 8, 8), units_per_block=1, lds_kib=16))]
+
+
 def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=False):
     """run every (in_layout, out_layout) combination; return dict name -> NCDHW cpu tensor"""
     vol = vol_cpu.to(DEV)
@@ -48,6 +55,19 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
         ocl1 = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=1)
         res["cl_v1"] = ocl1.cpu().permute(0, 4, 1, 2, 3).contiguous()
         res["cl2ncdhw_v1"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw", variant=1).cpu()
+    if vol.shape[1] % 4 == 0:
+        # LDS-staged tile kernels: packed-4 layout [N, C/4, D, H, W, 4] (csrc/gs3d_tile.h), default + forced tunings
+        vp4 = ops.volume_to_p4(vol)
+        N_, C_, D_, H_, W_ = vol_cpu.shape
+        assert torch.equal(vp4.cpu(), vol_cpu.view(N_, C_ // 4, 4, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
+        assert torch.equal(ops.volume_from_p4(vp4).cpu(), vol_cpu)
+        for tag, var in TILE_TUNINGS:
+            o = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="p4", variant=var)
+            res["p4" + tag] = ops.volume_from_p4(o).cpu()
+            res["p4_to_ncdhw" + tag] = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="ncdhw", variant=var).cpu()
+    if vol.shape[4] % 4 == 0:
+        for tag, var in TILE_TUNINGS:
+            res["ncdhw_tile" + tag] = ops.grid_sample3d(vol, grid, theta, pm, variant=ops.TILE | var).cpu()
     if vol.shape[1] % 32 == 0:
         # channel-group-per-XCD layout [N, 8, D, H, W, C/8]
         vcg = ops.volume_to_cg8(vol)
@@ -182,6 +202,12 @@ def test_delta_grid_mode_equals_materialised_warp(pm):
     ref = F.grid_sample(vol.expand(N, -1, -1, -1, -1), warp, padding_mode=pm, align_corners=False)
     v = vol.to(DEV)
     assert torch.equal(ops.grid_sample3d(v, delta=delta.to(DEV), padding_mode=pm).cpu(), ref)
+    vp4 = ops.volume_to_p4(v)
+    for tag, var in TILE_TUNINGS:
+        assert torch.equal(ops.grid_sample3d(v, delta=delta.to(DEV), padding_mode=pm, variant=ops.TILE | var).cpu(), ref), tag
+        assert torch.equal(ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="ncdhw", variant=var).cpu(), ref), tag
+        o = ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="p4", variant=var)
+        assert torch.equal(ops.volume_from_p4(o).cpu(), ref), tag
     vcl = ops.volume_to_channels_last(v)
     assert torch.equal(ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw").cpu(), ref)
     o = ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ndhwc")
