@@ -95,7 +95,7 @@ class SamplerMeter:
             grid_bytes = (grid.numel() if grid is not None else 0) * 4 + (delta.numel() if delta is not None else 0) * 4
             # a volume shared by the batch is read once per STEP (amortised over the samples that share it),
             # however many launches the step's frames are split into
-            shared = vol.shape[0] == 1 and out.shape[0] > 1
+            shared = vol.shape[0] == 1 and bool(meter.frames_per_step) and meter.frames_per_step > 1   # also a trailing 1-frame chunk
             vol_bytes = vol.numel() * 4 * (out.shape[0] / meter.frames_per_step if shared and meter.frames_per_step else 1.0)
             meter.bytes += vol_bytes + grid_bytes + out.numel() * 4
             return out
@@ -143,7 +143,7 @@ def cpu_baseline(cfg, sd, inputs):
     """SURVEY.md section 8(d) 'CPU baseline timing': the oracle driver pass (oracle/restate.py -- a restatement of the
     reference's PyTorch forward that oracle/validate_restatement.py pins BIT-EXACTLY, max |delta| = 0.0 on every stage,
     against the reference's own nn.Modules; /root/reference does not exist on the GPU box) on the physical host cores,
-    batch 1 per call as the reference does, 1 warm-up + 3 timed frames per thread count (bounded sample), median.  Plus the
+    batch 1 per call as the reference does, 1 warm-up + 5 timed frames per thread count (bounded sample), median.  Plus the
     1-thread figure of the 3-D sampler alone: ATen's CPU grid_sampler_3d (what the reference calls, va.py:264-265) does
     not parallelise at N = 1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -165,9 +165,9 @@ def cpu_baseline(cfg, sd, inputs):
     with torch.no_grad():
         # all physical cores as SURVEY.md 8(d) specifies -- and half of them: on a 2-socket box torch's intra-op pool gets
         # SLOWER past one socket (measured 4.5 s vs 2.2 s per frame); the better one is reported as the baseline
-        per_threads = {physical: frames_at(physical, 3)}
+        per_threads = {physical: frames_at(physical, 5)}
         if physical >= 16:
-            per_threads[physical // 2] = frames_at(physical // 2, 3)
+            per_threads[physical // 2] = frames_at(physical // 2, 5)
         threads_used = min(per_threads, key=per_threads.get)
         med = per_threads[threads_used]
         # the sampler alone, 1 thread, the reference's call at its own batch size (N = 1, explicit grid)
@@ -197,7 +197,7 @@ def cpu_baseline(cfg, sd, inputs):
     return dict(value=round(1.0 / med, 4), unit="frames/s", cores=threads_used, kind="port",
                 physical_cores=physical, logical_cpus=logical, cpu_model=model, threads=threads_used,
                 s_per_frame_by_threads={str(k): round(v, 4) for k, v in per_threads.items()},
-                sample=f"3 driver frames at {cfg['image_size']}x{cfg['image_size']} per thread count, batch 1 per call "
+                sample=f"5 driver frames at {cfg['image_size']}x{cfg['image_size']} per thread count, batch 1 per call "
                        f"(1 warm-up call excluded), median; oracle/restate.py = bit-exact restatement of the reference "
                        f"PyTorch forward, torch CPU fp32; torch.set_num_threads(all {physical} physical cores) and "
                        f"({physical // 2}), the faster one is the value",
@@ -207,6 +207,116 @@ def cpu_baseline(cfg, sd, inputs):
                                          f"[1,{c},{d},{s_},{s_}] with an explicit [1,{d},{s_},{s_},3] grid, median of 3",
                                  "GBps_algorithmic": round((2 * vol.numel() + grid.numel()) * 4 / (samp_ms * 1e-3) / 1e9, 3)},
                 reference_classes=ref)
+
+
+def _time_loop(fn, seconds=2.0, min_iters=3, max_iters=200):
+    """median wall time of fn() (device-synchronised), bounded to about `seconds`"""
+    fn()
+    torch.cuda.synchronize()
+    ts, t_end = [], time.perf_counter() + seconds
+    while len(ts) < min_iters or (time.perf_counter() < t_end and len(ts) < max_iters):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
+    """Secondary figures under the driver's clock (rank 0, N = 1, a few seconds each; the headline value is measured before):
+    batch-1 latency, R256, stage 2 (BASELINE configs[4]) in exact-fp32 and fp16-operand mode, stage 1 + stage 2, the
+    frames-in -> frames-out pipeline (embedders + hot path + uint8 packing) and the reference's emotion-driver hooks
+    (forward(custome_target_pose_embed=, custome_target_theta_embed=), notebooks/infer.py:565-566,603-604)."""
+    import tempfile
+    from emoportraits_amd import embedders as E, stage2
+    from emoportraits_amd.infer import InferenceWrapper
+    out = {}
+    B = pose.shape[0]
+    theta = ops.pose_theta(*srt)
+    # batch-1 latency of the hot path (what one reference-style forward() call costs on the device)
+    t = _time_loop(lambda: ops.pack_rgb8(hp.driver_pass(ccl, idt, pose[:1], theta[:1])))
+    out["latency_b1_ms"] = round(t * 1e3, 3)
+    # stage 2 at 512x512 (notebooks/infer_s2.py:351-376), 8 frames per call
+    g = torch.Generator().manual_seed(11)
+    s2cfg = stage2.stage2_config(overrides=dict(output_size_s2=512))
+    s2sd = stage2.random_state_dict(s2cfg, seed=0)
+    img8 = torch.rand(8, 3, 512, 512, generator=g).to(dev)
+    m8 = (torch.rand(8, 1, 512, 512, generator=g) > 0.1).float().to(dev)
+    f8 = (torch.rand(8, 1, 512, 512, generator=g) > 0.3).float().to(dev)
+    s2 = {}
+    for prec in ("f32", "f16"):
+        s2[prec] = stage2.Stage2(s2sd, s2cfg, dev, precision=prec)
+        t = _time_loop(lambda: s2[prec].refine(img8, m8, f8))
+        out[f"stage2_{prec}_fps"] = round(8 / t, 2)
+    if S == 512:
+        # stage 1 + stage 2 per frame: exact fp32, and BASELINE configs[4]'s mode (fp16 MFMA operands in both stages)
+        mask = torch.ones(B, 1, S, S, device=dev)
+        t = _time_loop(lambda: ops.pack_rgb8(s2["f32"].refine(hp.driver_pass(ccl, idt, pose, theta), mask, mask)))
+        out["stage1_plus_stage2_f32_fps"] = round(B / t, 2)
+        hp16 = nets.HotPath(sd, cfg, dev, with_source=False, precision="f16")
+        t = _time_loop(lambda: ops.pack_rgb8(s2["f16"].refine(hp16.driver_pass(ccl, idt, pose, theta), mask, mask)))
+        out["stage1_plus_stage2_f16_operands_fps"] = round(B / t, 2)
+        t = _time_loop(lambda: ops.pack_rgb8(hp16.driver_pass(ccl, idt, pose, theta)))
+        out["stage1_f16_operands_fps"] = round(B / t, 2)
+        del hp16
+    del s2
+    # R256 (BASELINE configs[0]/[1] size): same hot path, 32 frames per step
+    cfg256 = config.hot_path_config(overrides={"image_size": 256})
+    sd256 = random_init.trained_like_state_dict(cfg256, seed=0, with_source=False)
+    hp256 = nets.HotPath(sd256, cfg256, dev, with_source=False)
+    B2 = 32
+    g2 = torch.Generator().manual_seed(12)
+    pose2 = torch.randn(B2, cfg256["lpe_output_channels_expression"], generator=g2).to(dev)
+    th2 = ops.pose_theta(*[x.to(dev) for x in (1 + 0.05 * torch.randn(B2, 3, generator=g2), 0.3 * torch.randn(B2, 3, generator=g2),
+                                               0.05 * torch.randn(B2, 3, generator=g2))])
+    t = _time_loop(lambda: ops.pack_rgb8(hp256.driver_pass(ccl, idt, pose2, th2)))
+    out["r256_fps"] = round(B2 / t, 2)
+    del hp256
+    # frames in -> frames out through the wrapper (HeadPoseRegressor + ExpressionEmbed + hot path + uint8 D2H ring) and the
+    # emotion-driver hooks, on a wrapper built like the reference's (args.txt + checkpoint layout)
+    ecfg = E.embedder_config()
+    full = dict(random_init.trained_like_state_dict(cfg, seed=0))
+    full.update(E.random_state_dict(E.idt_schema(ecfg), 1))
+    full.update(E.random_state_dict(E.expression_schema(ecfg), 2))
+    hp_sd = E.random_state_dict(E.head_pose_schema(), 3)
+    hp_sd["fc.weight"] *= 0.05
+    hp_sd["fc.bias"] = torch.tensor([1.0, 1.0, 1.0, 0.1, -0.2, 0.05, 0.02, -0.03, 0.01])
+    root = tempfile.mkdtemp()
+    os.makedirs(os.path.join(root, "logs", "exp", "checkpoints"))
+    with open(os.path.join(root, "logs", "exp", "args.txt"), "wt") as f:
+        for k, v in {**cfg, **ecfg}.items():
+            f.write(f"{k}: {v}\n")
+    torch.save(hp_sd, os.path.join(root, "hp.pth"))
+    w = InferenceWrapper(experiment_name="exp", model_file_name="x", project_dir=root, folder="logs", state_dict=full,
+                         print_params=False, head_pose_regressor_path=os.path.join(root, "hp.pth"))
+    g3 = torch.Generator().manual_seed(13)
+    w.forward(source_image=torch.rand(1, 3, S, S, generator=g3), crop=False, source_mask=torch.ones(1, 1, S, S))
+    frames = (torch.rand(B * 6, S, S, 3, generator=g3) * 255).to(torch.uint8).pin_memory()
+    for _ in w.animate_frames(frames[:B * 2], batch_size=B):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = sum(o.shape[0] for _, o in w.animate_frames(frames, batch_size=B))
+    out["pipeline_frames_in_out_fps"] = round(n / (time.perf_counter() - t0), 2)
+    # emotion driver: expression vectors and (scale, rotation, translation) poses fed through the reference's hooks, one
+    # forward() call per frame as the reference API has it (PIL image out)
+    ge = torch.Generator().manual_seed(14)
+    embeds = torch.randn(16, 1, cfg["lpe_output_channels_expression"], generator=ge).to(dev)
+    poses = [(1 + 0.05 * torch.randn(1, 3, generator=ge), 0.3 * torch.randn(1, 3, generator=ge), 0.05 * torch.randn(1, 3, generator=ge))
+             for _ in range(16)]
+    poses = [tuple(x.to(dev) for x in p) for p in poses]
+
+    def emo_loop():
+        for e, p in zip(embeds, poses):
+            w.forward(custome_target_pose_embed=e, custome_target_theta_embed=p, crop=False)
+    t = _time_loop(emo_loop, seconds=3.0)
+    out["emotion_driver_forward_fps"] = round(16 / t, 2)
+    out["what"] = ("latency_b1_ms: one driver frame through the hot path; stage2_*: Stage2.refine at 512x512, 8 frames per call; "
+                   "stage1_plus_stage2_*: driver pass + refinement + uint8 pack, B frames per call; r256_fps: R256 driver pass, 32 frames "
+                   "per call; pipeline_frames_in_out_fps: InferenceWrapper.animate_frames (uint8 in, embedders, hot path, uint8 out); "
+                   "emotion_driver_forward_fps: forward(custome_target_pose_embed=, custome_target_theta_embed=) per frame, PIL out")
+    return out
 
 
 def relaunch_under_torchrun(n):
@@ -220,9 +330,8 @@ def relaunch_under_torchrun(n):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: needed by RCCL on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
+    env = dict(os.environ)                                # (HSA_ENABLE_IPC_MODE_LEGACY=0 is defaulted by emoportraits_amd.parallel)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
@@ -238,6 +347,8 @@ def main():
                     help="profiling aid: use a synthetic canonical volume instead of running the source pass, so that "
                          "a rocprofv3 trace of this command contains driver-pass launches only")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--raw-weights", action="store_true", help="plain seeded initialisation instead of the trained-like checkpoint")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (extras)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -254,7 +365,10 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = config.hot_path_config(overrides={"image_size": a.image_size})
-    sd = random_init.random_state_dict(cfg, seed=a.seed)
+    # seeded "trained-like" checkpoint (random_init.trained_like_state_dict): spectral norms ~1, predicted warps within one
+    # voxel of the identity, unsaturated image -- the statistics of a trained model, which the released one (not obtainable
+    # here) has; --raw-weights times the plain seeded initialisation of rounds 1-2 (uv warp of +-30 voxels) instead
+    sd = random_init.random_state_dict(cfg, seed=a.seed) if a.raw_weights else random_init.trained_like_state_dict(cfg, seed=a.seed)
     hp = nets.HotPath(sd, cfg, dev, with_source=(rank == 0 and not a.no_source_pass))
     c, d, s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
     S, B = a.image_size, a.batch
@@ -282,8 +396,9 @@ def main():
         cache = {"canonical": canonical, "idt_embed": idt_cpu.to(dev), "theta_src": th_s}
     shapes = dict(canonical=(1, c, d, s, s), idt_embed=(1, cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4))
     names = list(shapes)
-    bc = lambda: parallel.broadcast_source_cache(cache, shapes if rank == 0 else None, src=0, device=dev, world=world,
-                                                 rank=rank, names=names)
+    # every rank knows the shapes: one flat RCCL broadcast, no header exchange, no host synchronisation
+    bc = lambda: parallel.broadcast_source_cache(cache, shapes, src=0, device=dev, world=world, rank=rank, names=names,
+                                                 exchange_shapes=False)
     broadcast_ms = None
     if world > 1:
         bc()                               # first collective: communicator set-up, not the steady-state cost
@@ -346,11 +461,15 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"released stage-1 architecture R{S}, full HIP driver pass (pose theta, warp embed, uv WarpGenerator, "
                                f"2x 3-D grid_sample, decoder, uint8 pack), 1 source identity, {B} driver frames per GPU per step",
-                   "image_size": S, "frames_per_gpu_per_step": B, "weights": "seeded random, reference key layout",
+                   "image_size": S, "frames_per_gpu_per_step": B,
+                   "weights": ("seeded random, reference key layout" if a.raw_weights else
+                               "seeded trained-like (spectral norms ~1, |uv delta| < ~1 voxel, unsaturated image), reference key layout"),
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 32x32x2 MFMA implicit-GEMM conv, all instantiations)",
                      "achieved": round(conv_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc,
+                     "traffic_source": (f"{os.path.relpath(pmc_path, ROOT)}: rocprofv3 --pmc passes of this command (guide-corrected "
+                                        "HBM bytes per launch), NOT measured in this run" if pmc is not None else None),
                      "launches_per_step": conv_meter.launches // max(1, a.steps),
                      "avg_launch_ms": round(conv_ms / max(1, conv_meter.launches), 4),
                      "share_of_step": round(conv_ms / (elapsed * 1e3), 3)},
@@ -361,6 +480,11 @@ def main():
         "source_pass_ms": None if source_ms is None else round(source_ms, 2),
         "broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 3),   # one flat RCCL broadcast of the source cache, max over ranks
     }
+    if world == 1 and not a.no_extras:
+        try:
+            rec["extras"] = extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S)
+        except Exception as e:                                    # secondary figures must never cost the headline line
+            rec["extras"] = {"error": repr(e)}
     if world == 1 and not a.no_cpu_baseline:
         inputs = dict(canonical=cache["canonical"].cpu(), idt=idt_cpu, pose=pose.cpu(), theta=ops.pose_theta(*srt).cpu())
         rec["cpu_baseline"] = cpu_baseline(cfg, sd, inputs)

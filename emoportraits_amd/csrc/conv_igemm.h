@@ -238,7 +238,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, floatx16 (&acc_
   //      partner lane ^ 32 the other half of the wave's TP * 32 positions: mean = (own sum + partner's) / count, then the sum
   //      of squares centred at that mean -- a two-pass variance on values that are still in registers.  The WGP waves that
   //      share the channel combine their (mean, M2) through LDS with the pairwise update of Chan et al. (equal counts).
-  //      No E[x^2] - mean^2 anywhere. ----
+  //      No fp32 E[x^2] - mean^2 inside a tile; the cross-tile combine (gn_from_tiles_kernel) is done in fp64. ----
   if (a.gn_stats != nullptr && !to_partial) {
     float* st_lds = smem;   // [WGP][BM][2]: the stage buffers are idle (the K loop ended with a barrier)
     constexpr float inv_cnt = 1.0f / (float)(TP * 32);

@@ -838,7 +838,7 @@ extern "C" int emo_grid_sample3d_f32(const float* vol, const float* grid, const 
   if (!emo_aligned16(vol) || !emo_aligned16(out)) return EMO_ERR_ALIGN;
   if (in_layout == EMO_LAYOUT_P4)
     return emo_gs3d_tile_dispatch(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_batch_stride,
-                                  padding_mode, in_layout, out_layout, variant, grid_kind, stream);
+                                  padding_mode, in_layout, out_layout, variant & ~EMO_GS3D_TILE_FLAG, grid_kind, stream);
   if (in_layout == EMO_LAYOUT_NCDHW && out_layout == EMO_LAYOUT_NCDHW && (variant & EMO_GS3D_TILE_FLAG)) {
     // LDS-staged planar kernel; shapes it does not take (W % 4, huge extents) fall through to the direct-gather kernel
     const int rc = emo_gs3d_tile_dispatch(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_batch_stride,

@@ -57,6 +57,8 @@ struct TileParams {
 };
 
 constexpr int TILE_HDR_BYTES = 128;   // box min/max of up to 4 bricks
+// LDS of a block: [header][16 bytes per thread: output transpose scratch, packed-4 -> NCDHW only][stage]
+constexpr int tile_scratch_bytes(bool in_p4, bool out_p4, int threads) { return (in_p4 && !out_p4) ? threads * 16 : 0; }
 
 #if defined(GS3D_HOST_EMULATION)
 #define GS_UNIFORM(x) (x)
@@ -80,6 +82,7 @@ struct f4 { float x, y, z, w; };
 GS_FN f4 lds_read16(const unsigned char* lds, int off) { f4 v; memcpy(&v, lds + off, 16); return v; }
 GS_FN float lds_read4(const unsigned char* lds, int off) { float v; memcpy(&v, lds + off, 4); return v; }
 GS_FN void lds_zero16(unsigned char* lds, int off) { memset(lds + off, 0, 16); }
+GS_FN void lds_write16(unsigned char* lds, int off, f4 v) { memcpy(lds + off, &v, 16); }
 GS_FN int lds_geti(const unsigned char* lds, int off) { int v; memcpy(&v, lds + off, 4); return v; }
 GS_FN void lds_seti(unsigned char* lds, int off, int v) { memcpy(lds + off, &v, 4); }
 GS_FN void lds_atomic_min(unsigned char* lds, int off, int v) { int c = lds_geti(lds, off); if (v < c) lds_seti(lds, off, v); }
@@ -95,6 +98,7 @@ typedef float4 f4;
 GS_FN f4 lds_read16(const unsigned char* lds, int off) { return *reinterpret_cast<const f4*>(lds + off); }
 GS_FN float lds_read4(const unsigned char* lds, int off) { return *reinterpret_cast<const float*>(lds + off); }
 GS_FN void lds_zero16(unsigned char* lds, int off) { *reinterpret_cast<f4*>(lds + off) = make_float4(0.f, 0.f, 0.f, 0.f); }
+GS_FN void lds_write16(unsigned char* lds, int off, f4 v) { *reinterpret_cast<f4*>(lds + off) = v; }
 GS_FN int lds_geti(const unsigned char* lds, int off) { return *reinterpret_cast<const int*>(lds + off); }
 GS_FN void lds_seti(unsigned char* lds, int off, int v) { *reinterpret_cast<int*>(lds + off) = v; }
 GS_FN void lds_atomic_min(unsigned char* lds, int off, int v) { atomicMin(reinterpret_cast<int*>(lds + off), v); }
@@ -122,7 +126,9 @@ struct TileThread {
   static_assert(IN_P4 || !OUT_P4, "packed-4 output needs packed-4 input");
   static constexpr int ELEM = IN_P4 ? 16 : 4;       // LDS bytes of one box voxel of one unit
   static constexpr int XPS = IN_P4 ? 1 : 4;          // box voxels (along x) per 16-byte slot
-  static constexpr int DATA0 = TILE_HDR_BYTES;
+  static constexpr int SCRATCH0 = TILE_HDR_BYTES;
+  static constexpr int DATA0 = TILE_HDR_BYTES + tile_scratch_bytes(IN_P4, OUT_P4, THREADS);
+  static constexpr bool TRANSPOSED_OUT = IN_P4 && !OUT_P4;   // NCDHW output of packed-4 accumulators
 
   // ---- uniform over the block ----
   TileParams p;
@@ -328,47 +334,69 @@ struct TileThread {
   // Voxel-outer, unit-inner: only one voxel's weights and corner values are live inside the inner loop (the scheduling
   // barrier keeps hipcc from interleaving the voxels of a thread, which costs more registers than it hides latency:
   // the other waves of the CU cover the LDS latency).
+  GS_MFN f4 gather_acc(int j, int a00) {
+    const int sy = bw * ELEM, sz = bw * bh * ELEM;
+    const int a01 = a00 + sy, a10 = a00 + sz, a11 = a10 + sy;
+    f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+    if (IN_P4) {
+      f4 v[8];
+      v[0] = lds_read16(lds, a00); v[1] = lds_read16(lds, a00 + 16);
+      v[2] = lds_read16(lds, a01); v[3] = lds_read16(lds, a01 + 16);
+      v[4] = lds_read16(lds, a10); v[5] = lds_read16(lds, a10 + 16);
+      v[6] = lds_read16(lds, a11); v[7] = lds_read16(lds, a11 + 16);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float wc = w[j][c];
+        acc.x = gs_fadd(acc.x, gs_fmul(v[c].x, wc));
+        acc.y = gs_fadd(acc.y, gs_fmul(v[c].y, wc));
+        acc.z = gs_fadd(acc.z, gs_fmul(v[c].z, wc));
+        acc.w = gs_fadd(acc.w, gs_fmul(v[c].w, wc));
+      }
+    } else {
+      float v[8];
+      v[0] = lds_read4(lds, a00); v[1] = lds_read4(lds, a00 + 4);
+      v[2] = lds_read4(lds, a01); v[3] = lds_read4(lds, a01 + 4);
+      v[4] = lds_read4(lds, a10); v[5] = lds_read4(lds, a10 + 4);
+      v[6] = lds_read4(lds, a11); v[7] = lds_read4(lds, a11 + 4);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc.x = gs_fadd(acc.x, gs_fmul(v[c], w[j][c]));
+    }
+    if (pk[j] == -1) { acc.x = acc.y = acc.z = acc.w = 0.0f; }
+    return acc;
+  }
+
+  // Is the packed-4 -> NCDHW output of this block written as 16-byte stores of 4 x-consecutive voxels of ONE channel?
+  // The 4 lanes of an x-aligned quad exchange their (voxel, 4 channels) accumulators through a 16-byte LDS slot per
+  // lane (same wave: no barrier): a dword store writes 32-byte runs of a tile row of 8, which the write path charges as
+  // whole requests (measured: + 8 us per frame against 16-byte stores).  Needs whole quads inside the lattice.
+  GS_MFN bool quad_stores() const { return TRANSPOSED_OUT && p.txs >= 2 && (p.Wo & 3) == 0; }
+
+  GS_MFN void emit_a(f4 acc) {                       // stage 1 of a transposed store: park the accumulator
+    lds_write16(lds, SCRATCH0 + tid * 16, acc);
+  }
+  GS_MFN void emit_b(int unit, int j) {              // stage 2: lane (quad g, channel e) stores voxels 4g..4g+3 of channel e
+    if (vox[j] < 0) return;
+    const int e = tid & 3;
+    const int q0 = SCRATCH0 + (tid & ~3) * 16 + e * 4;
+    f4 o;
+    o.x = lds_read4(lds, q0); o.y = lds_read4(lds, q0 + 16); o.z = lds_read4(lds, q0 + 32); o.w = lds_read4(lds, q0 + 48);
+    unsigned char* ub = reinterpret_cast<unsigned char*>(p.out + ((long)n * p.C + 4 * unit + e) * nvox);
+    glob_write16(reinterpret_cast<float*>(ub + (unsigned)(vox[j] - e) * 4u), o);
+  }
+  GS_MFN void emit(int unit, int j, f4 acc) {
+    if (!IN_P4) store1(unit, j, acc.x);
+    else if (quad_stores()) { emit_a(acc); emit_b(unit, j); }
+    else store(unit, j, acc);
+  }
+
   GS_MFN void gather(int ps, int u0) {
     const int nuc = imin(nu, u_end - u0);
-    const int sy = bw * ELEM, sz = bw * bh * ELEM;
     const int ustride = nslots * 16;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       if (!in_pass(j, ps)) continue;
-      const bool dead = pk[j] == -1;
       int a00 = DATA0 + ebase[j] * ELEM;
-      for (int k = 0; k < nuc; ++k, a00 += ustride) {
-        const int a01 = a00 + sy, a10 = a00 + sz, a11 = a10 + sy;
-        if (IN_P4) {
-          f4 v[8];
-          v[0] = lds_read16(lds, a00); v[1] = lds_read16(lds, a00 + 16);
-          v[2] = lds_read16(lds, a01); v[3] = lds_read16(lds, a01 + 16);
-          v[4] = lds_read16(lds, a10); v[5] = lds_read16(lds, a10 + 16);
-          v[6] = lds_read16(lds, a11); v[7] = lds_read16(lds, a11 + 16);
-          f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const float wc = w[j][c];
-            acc.x = gs_fadd(acc.x, gs_fmul(v[c].x, wc));
-            acc.y = gs_fadd(acc.y, gs_fmul(v[c].y, wc));
-            acc.z = gs_fadd(acc.z, gs_fmul(v[c].z, wc));
-            acc.w = gs_fadd(acc.w, gs_fmul(v[c].w, wc));
-          }
-          if (dead) { acc.x = acc.y = acc.z = acc.w = 0.0f; }
-          store(u0 + k, j, acc);
-        } else {
-          float v[8];
-          v[0] = lds_read4(lds, a00); v[1] = lds_read4(lds, a00 + 4);
-          v[2] = lds_read4(lds, a01); v[3] = lds_read4(lds, a01 + 4);
-          v[4] = lds_read4(lds, a10); v[5] = lds_read4(lds, a10 + 4);
-          v[6] = lds_read4(lds, a11); v[7] = lds_read4(lds, a11 + 4);
-          float acc = 0.0f;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) acc = gs_fadd(acc, gs_fmul(v[c], w[j][c]));
-          if (dead) acc = 0.0f;
-          store1(u0 + k, j, acc);
-        }
-      }
+      for (int k = 0; k < nuc; ++k, a00 += ustride) emit(u0 + k, j, gather_acc(j, a00));
       GS_SCHED_BARRIER();
     }
   }

@@ -103,7 +103,7 @@ int launch_tile(const float* vol, const float* grid, const float* theta, const f
   p.upb = upb;
   p.ngroups = emo_cdiv(p.units, upb);
   const size_t lds = (size_t)lds_kib * 1024;
-  p.cap_slots = (int)((lds - TILE_HDR_BYTES) / 16);
+  p.cap_slots = (int)((lds - TILE_HDR_BYTES - tile_scratch_bytes(IN_P4, OUT_P4, threads)) / 16);
   if (p.cap_slots > TILE_MAXI * threads) p.cap_slots = TILE_MAXI * threads;
   if (threads == 256) {
     if (lv == 0) return launch_tile_cfg<PAD, MODE, IN_P4, OUT_P4, 256, 1>(p, lds, s);

@@ -387,12 +387,13 @@ class InferenceWrapper:
                     vol = hp.volume_source(vol)                                                        # infer.py:490-491
                 self.source_latent_volume = vol if c_source_latent_volume is None else \
                     c_source_latent_volume.to(self.device).float().contiguous()
-                inv = torch.linalg.inv(pred_source_theta.float().cpu()).to(self.device)                # infer.py:443
+                inv = ops.mat4_inverse(pred_source_theta.float().contiguous())                         # infer.py:443, on the device
                 self._source_theta_inv = inv
                 self.source_rotation_warp = ops.affine_grid3d(inv, (d, s, s))                          # infer.py:441-444
                 self.source_xy_warp_resize = delta_xy
-                rot = ops.grid_sample3d(self.source_latent_volume, theta=inv, padding_mode=hp.pad)     # infer.py:499-500
-                tv = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=hp.pad)
+                rot = ops.grid_sample3d(ops.volume_to_channels_last(self.source_latent_volume), theta=inv, padding_mode=hp.pad,
+                                        in_layout="ndhwc", out_layout="ndhwc")                         # infer.py:499-500
+                tv = ops.grid_sample3d(rot, delta=delta_xy, padding_mode=hp.pad, in_layout="ndhwc", out_layout="ncdhw")
                 self.target_latent_volume_1 = tv if c_target_latent_volume is None else \
                     c_target_latent_volume.to(self.device).float().contiguous()
                 self._set_source_cache(canonical=hp.volume_process(self.target_latent_volume_1))      # infer.py:507
@@ -429,6 +430,9 @@ class InferenceWrapper:
             # the reference runs the expression embedder on every driver frame (infer.py:596-601) and only then overrides
             # its output (:603-604); target_img_align (:608) comes from that run
             self.target_img_align = None
+            if driver_img_crop is None and custome_target_pose_embed is None:
+                raise RuntimeError("forward(driver_image=None, custome_target_theta_embed=...) also needs "
+                                   "custome_target_pose_embed=: without a driver frame there is no expression to embed")
             if driver_img_crop is not None and (custome_target_pose_embed is None or 'expression_embedder' in self.embedders):
                 target_pose_embed, self.target_img_align = self._expression(driver_img_crop, pred_target_theta,
                                                                             'a driver call')
@@ -472,8 +476,9 @@ class InferenceWrapper:
         The driver-side matte (MODNet) of the reference is computed but unused with use_seg=False (infer.py:592-601): skipped.
         to_host: results go D2H into a ring of `ring` pinned buffers on a copy stream; a batch is yielded once ITS copy
         event has completed, i.e. the host only ever waits for a batch that is `ring - 1` batches behind the GPU.
-        Yields (first_frame_index, uint8 [b,S,S,3]) -- a pinned host tensor (valid until `ring - 1` more batches have been
-        yielded) or, with to_host=False, the device tensor.  Frames are sharded contiguously across ranks as in animate()."""
+        Yields (first_frame_index, uint8 [b,S,S,3]) -- a view of a pinned ring slot, valid ONLY until the generator is resumed
+        (the next batch's copy may be queued into the same slot right away: consume or copy it before calling next()) --
+        or, with to_host=False, the device tensor.  Frames are sharded contiguously across ranks as in animate()."""
         if self._canonical_cl is None:
             raise RuntimeError("call forward with a source_image first")
         S = self.cfg["image_size"]

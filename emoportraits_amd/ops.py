@@ -26,7 +26,8 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     vol    [Nv,C,D,H,W] ('ncdhw'), [Nv,C/4,D,H,W,4] ('p4': packed channel quads, the layout of the LDS-staged tile kernels,
            out_layout 'p4' or 'ncdhw'), [Nv,D,H,W,C] ('ndhwc') or [Nv,8,D,H,W,C/8] ('cg8': 8 channel groups, one per XCD, see
            include/emo_hip.h EMO_LAYOUT_CG8; out_layout 'cg8' or 'ncdhw'); Nv == N or 1 (volume shared by all N samples).
-    variant  tuning word (include/emo_hip.h); with 'ncdhw' -> 'ncdhw', TILE selects the LDS-staged planar kernel.
+    variant  'p4' input (always the LDS-staged tile kernels): tile_variant(...) tuning word, 0 = defaults;
+             'ncdhw' -> 'ncdhw': TILE | tile_variant(...) selects the LDS-staged planar kernel instead of the direct gather.
     grid   [N,Do,Ho,Wo,3]; or None with theta [N,3,4] / [N,4,4]: the sampling grid is then the head-pose affine of
            the identity lattice (notebooks/infer.py:583-588), generated inside the kernel, output size = D,H,W.
     delta  [N,3,Do,Ho,Wo] planar deltas: grid = identity lattice + delta (WarpGenerator output,
@@ -300,7 +301,7 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
             raise ValueError("bad residual shape")
     positions = N * D * Hl * Wl
     cfg, ks, prec = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl, ups, affine=scale is not None,
-                                   aligned16=x.data_ptr() % 16 == 0)
+                                   aligned16=x.data_ptr() % 16 == 0, in_elems_per_sample=x.numel() // max(1, N))
     if ksplit is not None:
         ks = int(ksplit)
     ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None

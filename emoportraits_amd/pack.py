@@ -276,11 +276,14 @@ class PackedConv:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
-    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False, aligned16=True):
+    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False, aligned16=True, in_elems_per_sample=0):
         """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output; `affine`: the
         launch carries a per-sample input scale / shift (the fp16-operand kernel keeps those in a 1024-entry LDS table);
-        `aligned16`: the input pointer is 16-byte aligned (that kernel loads 16-byte quads)"""
+        `aligned16`: the input pointer is 16-byte aligned (that kernel loads 16-byte quads); `in_elems_per_sample`:
+        Cin*D*H*W of the input -- that kernel addresses a sample with 32-bit byte offsets (conv_igemm_f16_launch), larger
+        inputs take the exact-fp32 kernel like every other unsupported case"""
         if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D, CFG_G) and aligned16 \
+                and in_elems_per_sample * 4 < (1 << 32) \
                 and not (affine and self.cin > F16_AFFINE_MAX_CIN) and not (self.pinned_cfg == CFG_G and self.kh != 3):
             tiles = (self.pinned_cfg,) if self.pinned_cfg is not None else \
                 (CFG_D, CFG_G) if (_CFG_EFF[CFG_G] > 0 and self.kh == 3) else (CFG_D,)

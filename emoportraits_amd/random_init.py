@@ -23,12 +23,19 @@ def _kaiming(shape, g):
     return torch.randn(shape, generator=g) * math.sqrt(2.0 / max(fan_in, 1))
 
 
-def random_state_dict(cfg, seed=0, trained_like=True, with_source=True, image_head_gain=None):
+def random_state_dict(cfg, seed=0, trained_like=True, with_source=True, image_head_gain=None, warp_head_gain=None):
     """image_head_gain: scales the affine of the last GroupNorm of the image decoder (dec_img_head.0).  The head is a
     weight-standardised 1x1 conv over 128 ReLU channels followed by a sigmoid: with unit norm weights its pre-activation has
     a standard deviation of ~8, i.e. a random network paints saturated 0/1 images and every rounding difference that moves a
     pre-activation across zero flips a pixel.  A trained decoder produces natural images: logits within a few units.  A gain
-    of ~0.2 gives the seeded checkpoint that statistic (pre-activation std ~1.5) without touching anything else."""
+    of ~0.2 gives the seeded checkpoint that statistic (pre-activation std ~1.5) without touching anything else.
+
+    warp_head_gain: scales the affine of the GroupNorm in front of the tanh head of both WarpGenerators (pre_head.0) and the
+    head's bias.  The head
+    is a spectrally normalised 3x3x3 conv over 32 ReLU channels: with unit norm weights its pre-activation has a standard
+    deviation of ~0.6, i.e. a random generator emits deltas of +-1 in normalised coordinates -- 32 voxels -- and four fifths
+    of the sample points leave the volume.  A trained generator emits the small expression / canonicalisation offsets the
+    volumes were trained with: a gain of ~0.02 keeps |delta| below one voxel (0.03 in x, y)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     schema = hot_path_schema(cfg, with_source)
@@ -69,7 +76,19 @@ def random_state_dict(cfg, seed=0, trained_like=True, with_source=True, image_he
                     u = torch.mv(w, v)
                     u = u / u.norm().clamp_min(1e-12)
                 sd[p + ".weight_u"], sd[p + ".weight_v"] = u, v
+    if warp_head_gain is not None:
+        for net in ("uv_generator_nw", "xy_generator_nw"):
+            for k in (net + ".pre_head.0.weight", net + ".pre_head.0.bias", net + ".head.0.0.bias"):
+                if k in sd:
+                    sd[k] = sd[k] * float(warp_head_gain)
     if image_head_gain is not None:
         for k in ("decoder_nw.img_decoder.dec_img_head.0.weight", "decoder_nw.img_decoder.dec_img_head.0.bias"):
             sd[k] = sd[k] * float(image_head_gain)
     return sd
+
+
+def trained_like_state_dict(cfg, seed=0, with_source=True):
+    """The seeded checkpoint every full-size tolerance and the benchmark are characterised on (the released weights are not
+    obtainable here, README.md:125-139): spectral norms ~1, norm affines near (1, 0) with a 10 % spread, activations O(1)..O(50)
+    at every stage, predicted warps within one voxel of the identity, unsaturated image (logit std ~1.5)."""
+    return random_state_dict(cfg, seed=seed, trained_like=True, with_source=with_source, image_head_gain=0.2, warp_head_gain=0.01)

@@ -123,8 +123,9 @@ int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S, int G, flo
                              void* workspace, int64_t workspace_bytes, void* stream);
 /* The same affine from the per-tile statistics emo_conv_igemm_f32 leaves in `gn_stats` (no pass over the activation):
  *   stats [N][T][C][2] = (mean, centred sum of squares) of `cnt` values each, T tiles per sample and channel
- *   (emo_conv_igemm_f32: cnt = emo_conv_tile_positions(cfg), T = D*Hl*Wl / cnt).  Combined per (sample, group) in fp64 with the equal-count
- *   pairwise update (Chan et al.): no E[x^2] - mean^2 cancellation.  Other arguments as emo_groupnorm_affine_f32. */
+ *   (emo_conv_igemm_f32: cnt = emo_conv_tile_positions(cfg), T = D*Hl*Wl / cnt).  Combined per (sample, group) in fp64: the tile M2 values add, and the
+ *   between-tile term cnt * (sum(mean_i^2) - K * mean^2) is evaluated in fp64 on the fp32 tile means (an fp64 combine of
+ *   fp32 tile statistics; within a tile the conv epilogue uses centred sums, so no fp32 E[x^2] - mean^2 is ever formed).  Other arguments as emo_groupnorm_affine_f32. */
 int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_t T, int cnt, int G, float eps,
                                         const float* gamma, const float* beta,
                                         const float* ada_gamma, const float* ada_beta, int64_t ada_stride,

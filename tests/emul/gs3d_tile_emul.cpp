@@ -20,7 +20,7 @@ template <int PAD, int MODE, bool IN_P4, bool OUT_P4, int THREADS, int VPT>
 int run(const gs3d::TileParams& p, Stats* st) {
   typedef gs3d::TileThread<PAD, MODE, IN_P4, OUT_P4, THREADS, VPT, 16> TT;
   const int nblocks = p.ngroups * p.N * p.ntx * p.nty * p.ntz;
-  const size_t lds_bytes = gs3d::TILE_HDR_BYTES + (size_t)p.cap_slots * 16;
+  const size_t lds_bytes = gs3d::TILE_HDR_BYTES + gs3d::tile_scratch_bytes(IN_P4, OUT_P4, THREADS) + (size_t)p.cap_slots * 16;
   std::vector<unsigned char> lds(lds_bytes);
   std::vector<TT> th(THREADS);
   for (int b = 0; b < nblocks; ++b) {
@@ -48,7 +48,20 @@ int run(const gs3d::TileParams& p, Stats* st) {
         for (int t = 0; t < THREADS; ++t) th[t].fill(u0);
         st->stages++;
         st->slots_filled += (long)th[0].nslots * gs3d::imin(th[0].nu, th[0].u_end - u0);
-        for (int t = 0; t < THREADS; ++t) th[t].gather(ps, u0);
+        if (!th[0].quad_stores()) {
+          for (int t = 0; t < THREADS; ++t) th[t].gather(ps, u0);
+        } else {
+          // the transposed store exchanges accumulators between the lanes of a wave: run its two stages in lock step
+          const int nuc = gs3d::imin(th[0].nu, th[0].u_end - u0);
+          for (int j = 0; j < VPT; ++j) {
+            if (!th[0].in_pass(j, ps)) continue;
+            for (int k = 0; k < nuc; ++k) {
+              for (int t = 0; t < THREADS; ++t)
+                th[t].emit_a(th[t].gather_acc(j, TT::DATA0 + th[t].ebase[j] * TT::ELEM + k * th[t].nslots * 16));
+              for (int t = 0; t < THREADS; ++t) th[t].emit_b(u0 + k, j);
+            }
+          }
+        }
       }
     }
   }

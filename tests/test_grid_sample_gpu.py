@@ -62,9 +62,9 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
         assert torch.equal(vp4.cpu(), vol_cpu.view(N_, C_ // 4, 4, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
         assert torch.equal(ops.volume_from_p4(vp4).cpu(), vol_cpu)
         for tag, var in TILE_TUNINGS:
-            o = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="p4", variant=var)
-            res["p4" + tag] = ops.volume_from_p4(o).cpu()
-            res["p4_to_ncdhw" + tag] = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="ncdhw", variant=var).cpu()
+            o = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="p4", variant=ops.TILE | var)
+            res["p4_tile" + tag] = ops.volume_from_p4(o).cpu()
+            res["p4_tile_to_ncdhw" + tag] = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="ncdhw", variant=ops.TILE | var).cpu()
     if vol.shape[4] % 4 == 0:
         for tag, var in TILE_TUNINGS:
             res["ncdhw_tile" + tag] = ops.grid_sample3d(vol, grid, theta, pm, variant=ops.TILE | var).cpu()
@@ -205,8 +205,8 @@ def test_delta_grid_mode_equals_materialised_warp(pm):
     vp4 = ops.volume_to_p4(v)
     for tag, var in TILE_TUNINGS:
         assert torch.equal(ops.grid_sample3d(v, delta=delta.to(DEV), padding_mode=pm, variant=ops.TILE | var).cpu(), ref), tag
-        assert torch.equal(ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="ncdhw", variant=var).cpu(), ref), tag
-        o = ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="p4", variant=var)
+        assert torch.equal(ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="ncdhw", variant=ops.TILE | var).cpu(), ref), tag
+        o = ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="p4", variant=ops.TILE | var)
         assert torch.equal(ops.volume_from_p4(o).cpu(), ref), tag
     vcl = ops.volume_to_channels_last(v)
     assert torch.equal(ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw").cpu(), ref)

@@ -46,6 +46,9 @@ def _worker(rank, world, port, q):
     # only the source rank knows (and checks) the shapes; receivers learn them from the broadcast header
     got = parallel.broadcast_source_cache(cache, shapes if rank == 0 else None, src=0, world=w, rank=r, names=list(shapes))
     ok = all(torch.equal(got[k], full[k]) and got[k].data_ptr() % 16 == 0 for k in shapes)
+    # shapes known on every rank: a single collective, no header
+    got2 = parallel.broadcast_source_cache(cache, shapes, src=0, world=w, rank=r, names=list(shapes), exchange_shapes=False)
+    ok = ok and all(torch.equal(got2[k], full[k]) for k in shapes)
     # frame sharding: every rank processes its contiguous slice of 11 "frames"; union must be all frames
     lo, hi = parallel.shard_range(11, r, w)
     t = parallel.max_over_ranks(float(rank + 1))

@@ -39,12 +39,14 @@ def test_driver_pair_packed4_bit_exact(pm, case):
     vol, delta, theta, warp = _pair_inputs(C, D, S, N, C + N, amp)
     ref1 = F.grid_sample(vol.expand(N, -1, -1, -1, -1), warp, padding_mode=pm, align_corners=False)
     vp4 = ops.volume_to_p4(vol.to(DEV))
-    mid = ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="p4")
-    assert mid.shape == (N, C // 4, D, S, S, 4)
-    assert torch.equal(ops.volume_from_p4(mid).cpu(), ref1)
-    out = ops.grid_sample3d(mid, theta=theta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="ncdhw")
     grid2 = ops.affine_grid3d(theta.to(DEV), (D, S, S)).cpu()
-    assert torch.equal(out.cpu(), F.grid_sample(ref1, grid2, padding_mode=pm, align_corners=False))
+    ref2 = F.grid_sample(ref1, grid2, padding_mode=pm, align_corners=False)
+    for variant in (0, ops.tile_variant((16, 8, 4), 6), ops.tile_variant((16, 16, 4), 12, threads=512)):
+        mid = ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="p4", variant=variant)
+        assert mid.shape == (N, C // 4, D, S, S, 4)
+        assert torch.equal(ops.volume_from_p4(mid).cpu(), ref1)
+        out = ops.grid_sample3d(mid, theta=theta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="ncdhw", variant=variant)
+        assert torch.equal(out.cpu(), ref2)
     # the planar (reference layout) LDS-staged kernel on the same two calls
     a = ops.grid_sample3d(vol.to(DEV), delta=delta.to(DEV), padding_mode=pm, variant=ops.TILE)
     assert torch.equal(a.cpu(), ref1)
@@ -61,12 +63,13 @@ def test_tile_kernel_equals_direct_gather_kernels_at_batch_16():
     mid_ref = ops.grid_sample3d(v, delta=delta.to(DEV))
     out_ref = ops.grid_sample3d(mid_ref, theta=theta.to(DEV))
     vp4 = ops.volume_to_p4(v)
-    for chunk in (16, 4):
+    for chunk, variant in ((16, 0), (4, ops.tile_variant((16, 8, 4), 24))):
         out = torch.empty_like(out_ref)
         for a in range(0, N, chunk):
-            mid = ops.grid_sample3d(vp4, delta=delta[a:a + chunk].to(DEV), in_layout="p4", out_layout="p4")
+            mid = ops.grid_sample3d(vp4, delta=delta[a:a + chunk].to(DEV), in_layout="p4", out_layout="p4", variant=variant)
             assert torch.equal(ops.volume_from_p4(mid), mid_ref[a:a + chunk])
-            ops.grid_sample3d(mid, theta=theta[a:a + chunk].to(DEV), in_layout="p4", out_layout="ncdhw", out=out[a:a + chunk])
+            ops.grid_sample3d(mid, theta=theta[a:a + chunk].to(DEV), in_layout="p4", out_layout="ncdhw", out=out[a:a + chunk],
+                              variant=variant)
         assert torch.equal(out, out_ref)
 
 
@@ -76,7 +79,7 @@ def test_tile_kernel_rejects_what_it_cannot_index():
                           out_layout="ndhwc")
     with pytest.raises(RuntimeError, match="BAD_ARG"):       # tile of 128 voxels: fewer than one per thread
         ops.grid_sample3d(torch.randn(1, 1, 2, 4, 4, 4, device=DEV), torch.zeros(1, 2, 2, 2, 3, device=DEV), in_layout="p4",
-                          out_layout="p4", variant=ops.tile_variant((4, 4, 8)))
+                          out_layout="p4", variant=ops.TILE | ops.tile_variant((4, 4, 8)))
     # a planar volume whose rows are not 16-byte multiples silently takes the direct-gather kernel (same result)
     v5 = torch.randn(1, 4, 3, 5, 5, device=DEV)
     g5 = torch.rand(1, 3, 5, 5, 3, device=DEV) * 2 - 1
