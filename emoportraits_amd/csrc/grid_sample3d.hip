@@ -17,7 +17,7 @@
 //
 // The analytic variant (theta != NULL) fuses the head-pose affine of the identity lattice into the sampler
 // (row a2: notebooks/infer.py:441-444, :583-588), removing the 0.79 MB grid tensor from HBM.
-#include "common.h"
+#include "gs3d_coord.h"
 
 #define EMO_GS3D_TILE_FLAG (1 << 30)   /* variant bit: NCDHW -> NCDHW through the LDS-staged planar kernel (gs3d_tile.h) */
 
@@ -29,53 +29,21 @@ struct Taps {
   unsigned inb;    // bit k set <=> corner k is inside the volume
 };
 
-template <int PAD>
-__device__ __forceinline__ float source_index(float g, int size) {
-  // grid_sampler_unnormalize, align_corners=False: ((coord + 1) * size - 1) / 2
-  float c = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(g, 1.0f), (float)size), 1.0f), 2.0f);
-  if (PAD == EMO_PAD_BORDER) {
-    const float lim = (float)(size - 1);
-    c = (c < 0.0f) ? 0.0f : c;           // std::max(in, 0)
-    c = (c < lim) ? c : lim;             // std::min(lim, .)
-  } else if (PAD == EMO_PAD_REFLECTION) {
-    // reflect_coordinates(c, twice_low=-1, twice_high=2*size-1)
-    const float mn = -0.5f;
-    const float span = (float)size;
-    float in = fabsf(__fsub_rn(c, mn));
-    float extra = fmodf(in, span);
-    int flips = (int)floorf(__fdiv_rn(in, span));
-    c = (flips % 2 == 0) ? __fadd_rn(extra, mn) : __fadd_rn(__fsub_rn(span, extra), mn);
-    const float lim = (float)(size - 1);
-    c = (c < 0.0f) ? 0.0f : c;
-    c = (c < lim) ? c : lim;
-  }
-  return c;
-}
+using gs3d::MODE_DELTA;
+using gs3d::MODE_GRID;
+using gs3d::MODE_THETA;
+using gs3d::load_coord;
+using gs3d::xcd_remap;
 
+// floor corner + weights (gs3d_coord.h, bit-identical to ATen) -> per-corner offsets and the in-range mask
 template <int PAD>
 __device__ __forceinline__ void compute_taps(float gx, float gy, float gz, int D, int H, int W, Taps& t) {
-  float ix = source_index<PAD>(gx, W);
-  float iy = source_index<PAD>(gy, H);
-  float iz = source_index<PAD>(gz, D);
-  // non-finite / absurdly large coordinates: every corner out of range (ATen's int cast would be UB there)
-  const bool sane = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
-  if (!sane) { ix = -100.0f; iy = -100.0f; iz = -100.0f; }
-  const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
-  const float x1f = __fadd_rn(x0f, 1.0f), y1f = __fadd_rn(y0f, 1.0f), z1f = __fadd_rn(z0f, 1.0f);
-  const float wx0 = __fsub_rn(x1f, ix), wx1 = __fsub_rn(ix, x0f);
-  const float wy0 = __fsub_rn(y1f, iy), wy1 = __fsub_rn(iy, y0f);
-  const float wz0 = __fsub_rn(z1f, iz), wz1 = __fsub_rn(iz, z0f);
-  const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+  int x0, y0, z0;
+  gs3d::corner_weights<PAD>(gx, gy, gz, D, H, W, x0, y0, z0, t.w);
   const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
   const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
   const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
   const bool vz0 = (unsigned)z0 < (unsigned)D, vz1 = (unsigned)z1 < (unsigned)D;
-  const float wxy00 = __fmul_rn(wx0, wy0), wxy10 = __fmul_rn(wx1, wy0);
-  const float wxy01 = __fmul_rn(wx0, wy1), wxy11 = __fmul_rn(wx1, wy1);
-  t.w[0] = __fmul_rn(wxy00, wz0); t.w[1] = __fmul_rn(wxy10, wz0);
-  t.w[2] = __fmul_rn(wxy01, wz0); t.w[3] = __fmul_rn(wxy11, wz0);
-  t.w[4] = __fmul_rn(wxy00, wz1); t.w[5] = __fmul_rn(wxy10, wz1);
-  t.w[6] = __fmul_rn(wxy01, wz1); t.w[7] = __fmul_rn(wxy11, wz1);
   const bool v[8] = {vz0 && vy0 && vx0, vz0 && vy0 && vx1, vz0 && vy1 && vx0, vz0 && vy1 && vx1,
                      vz1 && vy0 && vx0, vz1 && vy0 && vx1, vz1 && vy1 && vx0, vz1 && vy1 && vx1};
   const int HW = H * W;
@@ -88,48 +56,6 @@ __device__ __forceinline__ void compute_taps(float gx, float gy, float gz, int D
     m |= v[k] ? (1u << k) : 0u;
   }
   t.inb = m;
-}
-
-// identity_grid_3d.bmm(theta[:, :3]^T): k-ordered fma chain starting from 0 (what the reference's GEMM does)
-__device__ __forceinline__ float affine_row(const float* __restrict__ t, float u, float v, float w) {
-  float acc = __fmul_rn(u, t[0]);
-  acc = __fmaf_rn(v, t[1], acc);
-  acc = __fmaf_rn(w, t[2], acc);
-  acc = __fmaf_rn(1.0f, t[3], acc);
-  return acc;
-}
-
-// where the sampling coordinate of output voxel `vox` comes from
-enum { MODE_GRID = 0,    // explicit grid [N,Do,Ho,Wo,3]
-       MODE_THETA = 1,   // head-pose affine of the identity lattice (a2)
-       MODE_DELTA = 2 }; // identity lattice + planar deltas [N,3,Do,Ho,Wo]: WarpGenerator's
-                         // warp = (identity_grid + deltas).permute(0,2,3,4,1)  (warp_generator_resnet.py:178)
-
-template <int MODE>
-__device__ __forceinline__ void load_coord(const float* __restrict__ grid, const float* __restrict__ theta,
-                                           const float* __restrict__ lin_x, const float* __restrict__ lin_y,
-                                           const float* __restrict__ lin_z, int n, int vox, int nvox, int Ho, int Wo,
-                                           float& gx, float& gy, float& gz) {
-  if (MODE == MODE_GRID) {
-    const float* g = grid + ((long)n * nvox + vox) * 3;
-    gx = g[0]; gy = g[1]; gz = g[2];
-  } else {
-    const int x = vox % Wo;
-    const int y = (vox / Wo) % Ho;
-    const int z = vox / (Wo * Ho);
-    const float u = lin_x[x], v = lin_y[y], w = lin_z[z];
-    if (MODE == MODE_THETA) {
-      const float* t = theta + (long)n * 12;
-      gx = affine_row(t + 0, u, v, w);
-      gy = affine_row(t + 4, u, v, w);
-      gz = affine_row(t + 8, u, v, w);
-    } else {
-      const float* d = grid + (long)n * 3 * nvox + vox;
-      gx = __fadd_rn(u, d[0]);
-      gy = __fadd_rn(v, d[nvox]);
-      gz = __fadd_rn(w, d[2L * nvox]);
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -188,96 +114,6 @@ __global__ __launch_bounds__(256) void gs3d_ncdhw_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------
-// NDHWC -> NDHWC.  item = (voxel, channel quad); lanes of a voxel are adjacent so that each corner is read
-// as LPV consecutive float4 (C*4 contiguous bytes).  grid = (ceil(nvox*LPV/256), 1, N)
-// ------------------------------------------------------------------------------------------------------
-template <int PAD, int MODE>
-__global__ __launch_bounds__(256) void gs3d_cl_kernel(
-    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
-    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
-    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
-  const int LPV = C >> 2;
-  const int nvox = Do * Ho * Wo;
-  const long item = (long)blockIdx.x * 256 + threadIdx.x;
-  if (item >= (long)nvox * LPV) return;
-  const int vox = (int)(item / LPV);
-  const int q = (int)(item - (long)vox * LPV);
-  const int n = blockIdx.z;
-  float gx, gy, gz;
-  load_coord<MODE>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
-  Taps t;
-  compute_taps<PAD>(gx, gy, gz, D, H, W, t);
-  const float4* vp = reinterpret_cast<const float4*>(vol + (long)n * vol_bstride) + q;
-  float4 v[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = vp[(long)t.off[k] * LPV];
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const bool in = (t.inb >> k) & 1u;
-    const float w = t.w[k];
-    acc.x = __fadd_rn(acc.x, __fmul_rn(in ? v[k].x : 0.0f, w));
-    acc.y = __fadd_rn(acc.y, __fmul_rn(in ? v[k].y : 0.0f, w));
-    acc.z = __fadd_rn(acc.z, __fmul_rn(in ? v[k].z : 0.0f, w));
-    acc.w = __fadd_rn(acc.w, __fmul_rn(in ? v[k].w : 0.0f, w));
-  }
-  reinterpret_cast<float4*>(out)[((long)n * nvox + vox) * LPV + q] = acc;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// NDHWC -> NCDHW.  One block per output row (n, z, y): Wo voxels x LPV quads, results transposed through
-// LDS so that the NCDHW stores are full 256-byte rows.  dynamic LDS = C * (Wo + 1) floats.
-// ------------------------------------------------------------------------------------------------------
-template <int PAD, int MODE>
-__global__ __launch_bounds__(256) void gs3d_cl2ncdhw_kernel(
-    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
-    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
-    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][Wo + 1]
-  const int LPV = C >> 2;
-  const int nvox = Do * Ho * Wo;
-  const int row = blockIdx.x;              // z * Ho + y
-  const int n = blockIdx.z;
-  const int ld = Wo + 1;
-  const float4* vbase = reinterpret_cast<const float4*>(vol + (long)n * vol_bstride);
-  for (int item = threadIdx.x; item < Wo * LPV; item += 256) {
-    const int x = item / LPV;
-    const int q = item - x * LPV;
-    const int vox = row * Wo + x;
-    float gx, gy, gz;
-    load_coord<MODE>(grid, theta, lin_x, lin_y, lin_z, n, vox, nvox, Ho, Wo, gx, gy, gz);
-    Taps t;
-    compute_taps<PAD>(gx, gy, gz, D, H, W, t);
-    const float4* vp = vbase + q;
-    float4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = vp[(long)t.off[k] * LPV];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const bool in = (t.inb >> k) & 1u;
-      const float w = t.w[k];
-      acc.x = __fadd_rn(acc.x, __fmul_rn(in ? v[k].x : 0.0f, w));
-      acc.y = __fadd_rn(acc.y, __fmul_rn(in ? v[k].y : 0.0f, w));
-      acc.z = __fadd_rn(acc.z, __fmul_rn(in ? v[k].z : 0.0f, w));
-      acc.w = __fadd_rn(acc.w, __fmul_rn(in ? v[k].w : 0.0f, w));
-    }
-    const int c = q * 4;
-    tile[(c + 0) * ld + x] = acc.x;
-    tile[(c + 1) * ld + x] = acc.y;
-    tile[(c + 2) * ld + x] = acc.z;
-    tile[(c + 3) * ld + x] = acc.w;
-  }
-  __syncthreads();
-  float* obase = out + (long)n * C * nvox + (long)row * Wo;
-  for (int i = threadIdx.x; i < C * Wo; i += 256) {
-    const int c = i / Wo;
-    const int x = i - c * Wo;
-    obase[(long)c * nvox + x] = tile[c * ld + x];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // v2 channels-last kernels: taps are computed ONCE per voxel (64 voxels per block, one lane each), parked in
 // LDS, and every (voxel, channel-quad) item then only does: 5 broadcast LDS reads, 8 x 16-byte gathers,
 // 64 mul/add.  v1 recomputed the ~150-instruction tap math in each of the C/4 lanes of a voxel and was
@@ -290,68 +126,25 @@ struct __attribute__((aligned(16))) TapRec {
   unsigned inb;
   unsigned pad[3];
 };
-// XCD-aware block order (cdna_hip_programming.md T1).  The dispatcher places block b on XCD b % 8, each XCD has a
-// private 4 MiB L2, and the 8 corner rows of neighbouring output rows / slices overlap: with the default order
-// the 8 XCDs each pull (almost) the whole 25 MB volume through their own L2.  Remapped, XCD k walks one
-// contiguous eighth of the (sample, z, y, x) ordered work, so a corner row is fetched from HBM / Infinity Cache
-// once and re-used out of that XCD's L2 by the following rows and the next z-slice.  Bijective for any total.
-__device__ __forceinline__ int xcd_remap(int b, int total) {
-  const int q = total >> 3, r = total & 7;
-  const int xcd = b & 7, idx = b >> 3;
-  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return start + idx;
-}
-
-// Block order of one launch.  ORDER 0: dispatch order.  1: XCD-contiguous (above).  2: XCD-contiguous AND, inside an
-// XCD's share, z-slice-major over the samples of that share (needs N % 8 == 0): when N driver frames sample ONE shared
-// canonical volume with near-identity warps, the same few z-slices of the volume then serve all of the XCD's samples
-// back to back out of its L2 instead of being re-streamed once per sample.
+// Block order of one launch.  ORDER 1: XCD-contiguous (gs3d::xcd_remap: block b runs on XCD b % 8, each XCD has a private
+// 4 MiB L2; remapped, XCD k walks one contiguous eighth of the (sample, z, y, x) ordered work, so a corner row is fetched
+// once and re-used out of that XCD's L2 by the following rows and the next z-slice).  ORDER 3: XCD-contiguous AND, inside an
+// XCD's share, (z-slice, group of 8 blocks, sample, block in group) -- needs N % 8 == 0: when N driver frames sample ONE
+// shared canonical volume with near-identity warps, a group's corner rows (a few hundred KB of the shared volume) stay in
+// L2 while all of the XCD's samples pass over them.  (Other orders, 128 / 256 voxels per block, the first-generation
+// kernels and the channel-group-per-XCD layout were measured in rounds 1-2 and retired: DESIGN.md section 3.2.)
 template <int ORDER>
 __device__ __forceinline__ void block_to_work(int b, int total, int bps, int nslices, int& n, int& blk) {
   constexpr int G = 8;                          // blocks (= output rows at Wo = 64) per row group
-  if (ORDER == 0) { n = b / bps; blk = b - n * bps; return; }
   if (ORDER == 1) { const int L = xcd_remap(b, total); n = L / bps; blk = L - n * bps; return; }
-  const int bpz = bps / nslices;               // blocks per z-slice of one sample
-  if (ORDER == 4) {
-    // XCD-contiguous over samples; inside a sample (row group, z, row): the corner rows of a row group are re-used by
-    // the next z-slice while they are still L2-resident (a whole z-slice of 96 channels is 1.5 MB x 2 corner planes)
-    const int L = xcd_remap(b, total);
-    n = L / bps;
-    const int i = L - n * bps;
-    const int rg = i / (nslices * G);
-    const int rem = i - rg * (nslices * G);
-    const int z = rem / G;
-    blk = z * bpz + rg * G + (rem - z * G);
-    return;
-  }
   const int xcd = b & 7, idx = b >> 3;
   const int spx = (total / bps) >> 3;          // samples per XCD
-  if (ORDER == 2) {
-    const int z = idx / (spx * bpz);
-    const int rem = idx - z * (spx * bpz);
-    const int j = rem / bpz;
-    n = xcd * spx + j;
-    blk = z * bpz + (rem - j * bpz);
-  } else if (ORDER == 3) {
-    // (z-slice, group of 8 blocks, sample, block in group): the group's corner rows (a few hundred KB of the
-    // shared volume) stay in L2 while all of the XCD's samples pass over them
-    const int per_group = spx * G;
-    const int grp = idx / per_group;            // global group index = z * (bpz / G) + row group
-    const int rem = idx - grp * per_group;
-    const int j = rem / G;
-    n = xcd * spx + j;
-    blk = grp * G + (rem - j * G);
-  } else {
-    // ORDER 5: (row group, z-slice, sample, block in group): ORDER 3 with the z sweep inside the row group
-    const int per_rg = nslices * spx * G;
-    const int rg = idx / per_rg;
-    int rem = idx - rg * per_rg;
-    const int z = rem / (spx * G);
-    rem -= z * (spx * G);
-    const int j = rem / G;
-    n = xcd * spx + j;
-    blk = z * bpz + rg * G + (rem - j * G);
-  }
+  const int per_group = spx * G;
+  const int grp = idx / per_group;              // global group index = z * (bpz / G) + row group
+  const int rem = idx - grp * per_group;
+  const int j = rem / G;
+  n = xcd * spx + j;
+  blk = grp * G + (rem - j * G);
 }
 
 // voxel i (0..63) of 4x4x4 brick `blk` of a Do x Ho x Wo output lattice (all three multiples of 4): bricks x-fastest
@@ -516,201 +309,53 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   }
 }
 
-template <int PAD, int MODE, int VPB, int ORDER>
+constexpr int CL_VPB = 64;      // output voxels per block of the row-shaped kernels
+
+template <int PAD, int MODE, int ORDER>
 int launch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                  const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                  long vol_bstride, bool out_cl, hipStream_t s) {
   const int nvox = Do * Ho * Wo;
-  const int bps = emo_cdiv(nvox, VPB);
+  const int bps = emo_cdiv(nvox, CL_VPB);
   const long total = (long)bps * N;
   if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  if (ORDER == 4 && ((bps % Do) || (nvox % VPB) || ((bps / Do) % 8)))
-    return launch_cl_v2<PAD, MODE, VPB, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
-                                           vol_bstride, out_cl, s);
-  if (ORDER >= 2 && ORDER != 4 && ((N & 7) || (bps % Do) || (nvox % VPB) || ((bps / Do) % 8)))   // whole slices / groups, N % 8 == 0
-    return launch_cl_v2<PAD, MODE, VPB, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
-                                           vol_bstride, out_cl, s);
+  if (ORDER == 3 && ((N & 7) || (bps % Do) || (nvox % CL_VPB) || ((bps / Do) % 8)))   // whole slices / groups, N % 8 == 0
+    return launch_cl_v2<PAD, MODE, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                      out_cl, s);
   if (out_cl) {
-    hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, VPB, ORDER>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
+    hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, CL_VPB, ORDER>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
                        theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
   } else {
-    const size_t lds = VPB * sizeof(TapRec) + (size_t)C * (VPB + 1) * sizeof(float);
+    const size_t lds = CL_VPB * sizeof(TapRec) + (size_t)C * (CL_VPB + 1) * sizeof(float);
     if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, VPB, ORDER>), dim3((unsigned)total), dim3(256), lds, s, vol,
+    hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, CL_VPB, ORDER>), dim3((unsigned)total), dim3(256), lds, s, vol,
                        grid, theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
   }
   return emo_launch_status();
 }
 
-// variant: 0 = default (XCD-remapped, 64 voxels per block; shared volumes also sample-interleaved = 9); 2 = XCD-remapped;
-//          3 = no remap; 4 / 5 = 128 voxels (remap / not);
-//          6 / 7 = 256 voxels (NDHWC output only); 8 / 9 = XCD-remapped + z-slice-major / row-group-major over the XCD's samples.  Kept selectable for in-process A/B measurements.
+// variant of the channels-last kernels: 0 = default; 1 = row-shaped blocks forced (A/B of the brick shape).
+// Default: NDHWC output with Do, Ho, Wo multiples of 4 -> 4 x 4 x 4 output bricks per block (half the L1 fills per voxel:
+// measured - 10 ... 12 % on the uv call); otherwise 64-voxel rows, XCD-contiguous, and for a volume shared by N % 8 == 0
+// samples also row-group-major over the XCD's samples.
 template <int PAD, int MODE>
 int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                    const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                    long vol_bstride, bool out_cl, int variant, hipStream_t s) {
-#define EMO_CLV2(VPB_, ORDER_)                                                                                   \
-  return launch_cl_v2<PAD, MODE, VPB_, ORDER_>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, \
-                                               Wo, vol_bstride, out_cl, s)
-  switch (variant) {
-    case 0:   // default: XCD-contiguous; for a volume shared by N % 8 == 0 samples also row-group-major over the samples
-      if (vol_bstride == 0 && N >= 8) EMO_CLV2(64, 3);
-      EMO_CLV2(64, 1);
-    case 2: EMO_CLV2(64, 1);
-    case 3: EMO_CLV2(64, 0);
-    case 4: EMO_CLV2(128, 1);
-    case 5: EMO_CLV2(128, 0);
-    case 6: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, 1);
-    case 7: if (!out_cl) return EMO_ERR_UNSUPPORTED; EMO_CLV2(256, 0);
-    case 8: EMO_CLV2(64, 2);
-    case 9: EMO_CLV2(64, 3);
-    case 10: EMO_CLV2(64, 4);
-    case 11: EMO_CLV2(64, 5);
-    case 12: {   // 4x4x4 output bricks (NDHWC output only), XCD-contiguous block order
-      if (!out_cl || (Do & 3) || (Ho & 3) || (Wo & 3)) return EMO_ERR_UNSUPPORTED;
-      const int nvox_ = Do * Ho * Wo;
-      const int bps_ = nvox_ >> 6;
-      const long total_ = (long)bps_ * N;
-      if (total_ > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((gs3d_cl_brick_kernel<PAD, MODE, 1>), dim3((unsigned)total_), dim3(256), 0, s, vol, grid, theta, lin_x,
-                         lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps_);
-      return emo_launch_status();
-    }
-    default: return EMO_ERR_BAD_ARG;
+  if (variant != 0 && variant != 1) return EMO_ERR_BAD_ARG;
+  if (variant == 0 && out_cl && !(Do & 3) && !(Ho & 3) && !(Wo & 3)) {
+    const int bps = (Do * Ho * Wo) >> 6;
+    const long total = (long)bps * N;
+    if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((gs3d_cl_brick_kernel<PAD, MODE, 1>), dim3((unsigned)total), dim3(256), 0, s, vol, grid, theta, lin_x,
+                       lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
+    return emo_launch_status();
   }
-#undef EMO_CLV2
-}
-
-// ------------------------------------------------------------------------------------------------------
-// v3: channel-group-per-XCD kernels (EMO_LAYOUT_CG8).  Layout [N][8][D][H][W][C/8]: the C channels are split into 8
-// groups and the group index is the SLOWEST dimension below the sample, so a group's sub-volume is one contiguous
-// C/8-channel NDHWC volume (3.1 MB for 96 x 16 x 64 x 64).  Block b samples channel group b % 8 -- the dispatcher places
-// block b on XCD b % 8 (MI355X_MICROARCH.md, speed only, never correctness) -- so each XCD's private 4 MiB L2 only ever
-// sees ITS eighth of the volume.  Measured reason (profiles/r2_pmc_sampler_*.json, rocprofv3 TCC counters of the v2
-// kernels at 16 frames): the shared-volume call issued 3.8 M fabric read requests = 0.49 GB against 38 MB of algorithmic
-// reads -- every XCD streams the whole 25 MB canonical volume through its L2 twice (each z-plane as the lower and, a whole
-// z-slice of output writes later, as the upper corner plane) -- on top of the 0.40 GB it writes: the kernel sat at
-// ~4.5 TB/s of fabric traffic while delivering 2.2 TB/s of algorithmic bytes.  With one group per XCD the sub-volume stays
-// L2-resident and the volume crosses the fabric once per launch.
-// A block: 256 voxels (4 x-rows at Wo = 64), taps once per voxel in LDS (as v2), then (voxel, quad) items: C/32 quads per
-// voxel, lanes of a voxel adjacent => each corner is one contiguous C/8*4-byte read and x-neighbours continue it.
-// Block order inside an XCD: z-slice major over the samples when the volume is shared (the two corner planes of a slice,
-// 0.4 MB per group, serve all samples back to back), sample major otherwise.
-// ------------------------------------------------------------------------------------------------------
-constexpr int CG8_VPB = 256;
-
-template <int PAD, int MODE, bool OUT_NCDHW>
-__global__ __launch_bounds__(256) void gs3d_cg8_kernel(
-    const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
-    const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
-    float* __restrict__ out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int bps,
-    int slice_major) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  TapRec* recs = reinterpret_cast<TapRec*>(smem);                       // CG8_VPB * 80 B
-  float* tile = smem + CG8_VPB * (sizeof(TapRec) / 4);                  // OUT_NCDHW: [C/8][CG8_VPB + 1]
-  constexpr int LD = CG8_VPB + 1;
-  const int CG = C >> 3;                 // channels per group
-  const int QPV = CG >> 2;               // float4 quads per voxel
-  const int nvox = Do * Ho * Wo;
-  const int g = blockIdx.x & 7;          // channel group == XCD of this block
-  const int idx = blockIdx.x >> 3;
-  int n, blk;
-  if (slice_major) {                     // (z-slice, sample, block in slice); needs bps % Do == 0
-    const int bpz = bps / Do;
-    const int z = idx / (N * bpz);
-    const int rem = idx - z * (N * bpz);
-    n = rem / bpz;
-    blk = z * bpz + (rem - n * bpz);
-  } else {
-    n = idx / bps;
-    blk = idx - n * bps;
-  }
-  const int vox0 = blk * CG8_VPB;
-  stage_taps<PAD, MODE, CG8_VPB>(recs, grid, theta, lin_x, lin_y, lin_z, n, vox0, nvox, D, H, W, Ho, Wo);
-  __syncthreads();
-  const long gvol = (long)D * H * W * CG;                               // floats of one group's sub-volume
-  const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride + (long)g * gvol);
-  const unsigned row_bytes = (unsigned)CG * 4u;
-  const int nv = min(CG8_VPB, nvox - vox0);
-  const int nitems = nv * QPV;
-  float4* obase = reinterpret_cast<float4*>(out + (((long)n * 8 + g) * nvox + vox0) * CG);   // CG8 output
-  for (int item = threadIdx.x; item < nitems; item += 256) {
-    const int v = item / QPV;
-    const int q = item - v * QPV;
-    const TapRec r = recs[v];
-    const float4 acc = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
-    if (OUT_NCDHW) {
-      const int c = q * 4;
-      tile[(c + 0) * LD + v] = acc.x;
-      tile[(c + 1) * LD + v] = acc.y;
-      tile[(c + 2) * LD + v] = acc.z;
-      tile[(c + 3) * LD + v] = acc.w;
-    } else {
-      obase[item] = acc;
-    }
-  }
-  if (OUT_NCDHW) {
-    __syncthreads();
-    float* ob = out + ((long)n * C + (long)g * CG) * nvox + vox0;      // channel g*CG + c, voxels vox0 .. vox0 + nv
-    for (int i = threadIdx.x; i < CG * CG8_VPB; i += 256) {
-      const int c = i / CG8_VPB;
-      const int v = i - c * CG8_VPB;
-      if (v < nv) ob[(long)c * nvox + v] = tile[c * LD + v];
-    }
-  }
-}
-
-template <int PAD, int MODE>
-int launch_cg8(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
-               const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
-               long vol_bstride, int out_layout, hipStream_t s) {
-  if (C % 32) return EMO_ERR_UNSUPPORTED;                               // 8 groups of whole float4 quads
-  if ((long)D * H * W * (C / 8) * 4 >= (1L << 32)) return EMO_ERR_UNSUPPORTED;   // 32-bit byte offsets inside a group
-  const int nvox = Do * Ho * Wo;
-  const int bps = emo_cdiv(nvox, CG8_VPB);
-  const long total = (long)bps * N * 8;
-  if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  const int slice_major = (vol_bstride == 0 && N > 1 && (nvox % CG8_VPB) == 0 && (bps % Do) == 0) ? 1 : 0;
-  if (out_layout == EMO_LAYOUT_CG8) {
-    const size_t lds = CG8_VPB * sizeof(TapRec);
-    hipLaunchKernelGGL((gs3d_cg8_kernel<PAD, MODE, false>), dim3((unsigned)total), dim3(256), lds, s, vol, grid, theta,
-                       lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride, bps, slice_major);
-  } else if (out_layout == EMO_LAYOUT_NCDHW) {
-    const size_t lds = CG8_VPB * sizeof(TapRec) + (size_t)(C / 8) * (CG8_VPB + 1) * sizeof(float);
-    if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((gs3d_cg8_kernel<PAD, MODE, true>), dim3((unsigned)total), dim3(256), lds, s, vol, grid, theta,
-                       lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride, bps, slice_major);
-  } else {
-    return EMO_ERR_UNSUPPORTED;
-  }
-  return emo_launch_status();
-}
-
-// layout repack NCDHW [N][C][S] -> CG8 [N][8][S][C/8] (and back): per group a [C/8][S] <-> [S][C/8] transpose
-__global__ __launch_bounds__(256) void repack_cg8_kernel(const float* __restrict__ in, float* __restrict__ out, int CG,
-                                                         int S, int to_cg8) {
-  // one block per (64 spatial positions, group, sample); CG <= 64
-  __shared__ float tile[64][65];
-  const int n = blockIdx.z, g = blockIdx.y, s0 = blockIdx.x * 64;
-  const long base = ((long)n * 8 + g) * CG * S;            // both layouts keep (sample, group) outermost
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  if (to_cg8) {
-    for (int c = ty; c < CG; c += 4)
-      if (s0 + tx < S) tile[c][tx] = in[base + (long)c * S + s0 + tx];
-    __syncthreads();
-    for (int i = threadIdx.x; i < 64 * CG; i += 256) {
-      const int sp = i / CG, c = i - sp * CG;
-      if (s0 + sp < S) out[base + (long)(s0 + sp) * CG + c] = tile[c][sp];
-    }
-  } else {
-    for (int i = threadIdx.x; i < 64 * CG; i += 256) {
-      const int sp = i / CG, c = i - sp * CG;
-      if (s0 + sp < S) tile[c][sp] = in[base + (long)(s0 + sp) * CG + c];
-    }
-    __syncthreads();
-    for (int c = ty; c < CG; c += 4)
-      if (s0 + tx < S) out[base + (long)c * S + s0 + tx] = tile[c][tx];
-  }
+  if (vol_bstride == 0 && N >= 8)
+    return launch_cl_v2<PAD, MODE, 3>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                      out_cl, s);
+  return launch_cl_v2<PAD, MODE, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                    out_cl, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -747,33 +392,11 @@ int launch(const float* vol, const float* grid, const float* theta, const float*
     dim3 g(emo_cdiv(nvox, 256), emo_cdiv(C, cpb), N);
     hipLaunchKernelGGL((gs3d_ncdhw_kernel<PAD, MODE>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
                        out, C, D, H, W, Do, Ho, Wo, vol_bstride, cpb);
-  } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NDHWC) {
+  } else if (in_layout == EMO_LAYOUT_NDHWC && (out_layout == EMO_LAYOUT_NDHWC || out_layout == EMO_LAYOUT_NCDHW)) {
     if (C % 4) return EMO_ERR_UNSUPPORTED;
     if ((long)D * H * W * C * 4 >= (1L << 32)) return EMO_ERR_UNSUPPORTED;   // 32-bit byte offsets
-    if (variant == 1) {
-      dim3 g(emo_cdiv((long)nvox * (C / 4), 256), 1, N);
-      hipLaunchKernelGGL((gs3d_cl_kernel<PAD, MODE>), g, dim3(256), 0, s, vol, grid, theta, lin_x, lin_y, lin_z,
-                         out, C, D, H, W, Do, Ho, Wo, vol_bstride);
-    } else {
-      return dispatch_cl_v2<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
-                                       vol_bstride, true, variant, s);
-    }
-  } else if (in_layout == EMO_LAYOUT_NDHWC && out_layout == EMO_LAYOUT_NCDHW) {
-    if (C % 4) return EMO_ERR_UNSUPPORTED;
-    if ((long)D * H * W * C * 4 >= (1L << 32)) return EMO_ERR_UNSUPPORTED;
-    if (variant == 1) {
-      const size_t lds = (size_t)C * (Wo + 1) * sizeof(float);
-      if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
-      dim3 g(Do * Ho, 1, N);
-      hipLaunchKernelGGL((gs3d_cl2ncdhw_kernel<PAD, MODE>), g, dim3(256), lds, s, vol, grid, theta, lin_x, lin_y,
-                         lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride);
-    } else {
-      return dispatch_cl_v2<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo,
-                                       vol_bstride, false, variant, s);
-    }
-  } else if (in_layout == EMO_LAYOUT_CG8) {
-    return launch_cg8<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
-                                 out_layout, s);
+    return dispatch_cl_v2<PAD, MODE>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                     out_layout == EMO_LAYOUT_NDHWC, variant, s);
   } else {
     return EMO_ERR_UNSUPPORTED;
   }
@@ -878,12 +501,6 @@ extern "C" int emo_volume_repack_f32(const float* in, float* out, int N, int C, 
   if (N > 65535) return EMO_ERR_UNSUPPORTED;
   if (to_channels_last == 4 || to_channels_last == 5)     // NCDHW <-> packed-4
     return emo_repack_p4_dispatch(in, out, N, C, DHW, to_channels_last == 4, stream);
-  if (to_channels_last == 2 || to_channels_last == 3) {   // NCDHW <-> CG8
-    if (C % 32 || C / 8 > 64) return EMO_ERR_UNSUPPORTED;
-    dim3 g(emo_cdiv(DHW, 64), 8, N);
-    hipLaunchKernelGGL(repack_cg8_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, C / 8, DHW, to_channels_last == 2);
-    return emo_launch_status();
-  }
   if (to_channels_last != 0 && to_channels_last != 1) return EMO_ERR_BAD_ARG;
   const int R = to_channels_last ? C : DHW;       // rows of the input matrix
   const int Ccols = to_channels_last ? DHW : C;   // columns of the input matrix

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMO_HIP_LIB") or os.path.join(_HERE, "lib", "libemoportraits_hip.so")
 
 PAD_MODES = {"zeros": 0, "border": 1, "reflection": 2}
-LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_CG8, LAYOUT_P4 = 0, 1, 2, 3
+LAYOUT_NCDHW, LAYOUT_NDHWC, LAYOUT_P4 = 0, 1, 3
 ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 _c_int, _c_i64, _c_void, _c_float = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float

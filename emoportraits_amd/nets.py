@@ -292,15 +292,10 @@ class HotPath:
         self.pad = cfg["grid_sample_padding_mode"]
         self.c, self.d, self.s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
         self.with_source = with_source
-        # channels-last volumes for the samplers.  EMO_SAMPLER_LAYOUT=cg8 selects the channel-group-per-XCD kernels instead:
-        # they cut the fabric reads of the shared-volume call 4x (rocprofv3 TCC counters, profiles/r2_pmc_sampler_*.json) but
-        # are not faster -- the samplers are bound by the per-CU L1 path, not by L2 / HBM
-        want = os.environ.get("EMO_SAMPLER_LAYOUT", "ndhwc")
-        self.sampler_layout = "cg8" if (want == "cg8" and self.c % 32 == 0) else "ndhwc"
         # frames per sampler launch pair: the warped intermediate of a chunk (25 MB per frame) is consumed by the second
         # call while it is still in the 256 MiB Infinity Cache (measured: 27.1 -> 23.5 us per frame for the pair at 16 frames)
         self.sampler_chunk = int(os.environ.get("EMO_SAMPLER_CHUNK", "4"))
-        self.sampler_uv_variant = int(os.environ.get("EMO_SAMPLER_UV_VARIANT", "0"))   # 12: 4x4x4 output bricks (A/B)
+        self.sampler_uv_variant = int(os.environ.get("EMO_SAMPLER_UV_VARIANT", "0"))   # 1: row-shaped blocks instead of bricks (A/B)
         from .pack import conv_precision
         # fp16 mode: the WarpGenerators stay exact fp32 (EMO_WARP_PRECISION=f16 overrides) -- their output is GEOMETRY (where
         # the volume is sampled): measured at R256, fp16 operands there put 2e-3 on the deltas and 2e-2 of max on the warped
@@ -341,10 +336,7 @@ class HotPath:
         return canonical
 
     def prepare_canonical(self, canonical):
-        """sampler-layout copy of the cached canonical volume (done once per identity): 8 channel groups, one per XCD
-        (EMO_LAYOUT_CG8) when the channel count allows, else channels-last"""
-        if self.sampler_layout == "cg8":
-            return ops.volume_to_cg8(canonical)
+        """channels-last copy of the cached canonical volume for the samplers (done once per identity)"""
         return ops.volume_to_channels_last(canonical)
 
     # ---- per driver batch ---------------------------------------------------------------------------
@@ -352,14 +344,14 @@ class HotPath:
         B = target_pose_embed.shape[0]
         emb = self.embed(target_pose_embed, idt_embed)
         delta_uv = self.uv_generator(emb)
-        lay = "cg8" if canonical_cl.dim() == 6 else "ndhwc"
+        lay = "ndhwc"
         aligned = torch.empty((B, self.c, self.d, self.s, self.s), device=self.device, dtype=torch.float32)
         theta3 = theta_drv[:, :3].contiguous()
         step = self.sampler_chunk if self.sampler_chunk > 0 else B
         for a in range(0, B, step):
             b = min(B, a + step)
             warped = ops.grid_sample3d(canonical_cl, delta=delta_uv[a:b], padding_mode=self.pad, in_layout=lay, out_layout=lay,
-                                       variant=self.sampler_uv_variant if lay == "ndhwc" else 0)
+                                       variant=self.sampler_uv_variant)
             ops.grid_sample3d(warped, theta=theta3[a:b], padding_mode=self.pad, in_layout=lay, out_layout="ncdhw",
                               out=aligned[a:b])
         feat = aligned.view(B, self.c * self.d, self.s, self.s)

@@ -24,8 +24,8 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     """5-D trilinear grid_sample, align_corners=False  (== F.grid_sample(vol, grid, padding_mode=...)).
 
     vol    [Nv,C,D,H,W] ('ncdhw'), [Nv,C/4,D,H,W,4] ('p4': packed channel quads, the layout of the LDS-staged tile kernels,
-           out_layout 'p4' or 'ncdhw'), [Nv,D,H,W,C] ('ndhwc') or [Nv,8,D,H,W,C/8] ('cg8': 8 channel groups, one per XCD, see
-           include/emo_hip.h EMO_LAYOUT_CG8; out_layout 'cg8' or 'ncdhw'); Nv == N or 1 (volume shared by all N samples).
+           out_layout 'p4' or 'ncdhw') or [Nv,D,H,W,C] ('ndhwc': channels-last, the driver pass's layout; out_layout 'ndhwc'
+           or 'ncdhw'); Nv == N or 1 (volume shared by all N samples).
     variant  'p4' input (always the LDS-staged tile kernels): tile_variant(...) tuning word, 0 = defaults;
              'ncdhw' -> 'ncdhw': TILE | tile_variant(...) selects the LDS-staged planar kernel instead of the direct gather.
     grid   [N,Do,Ho,Wo,3]; or None with theta [N,3,4] / [N,4,4]: the sampling grid is then the head-pose affine of
@@ -38,9 +38,9 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     if theta is not None:
         theta = theta.float().contiguous()      # e.g. torch.linalg.inv returns a column-major result
         hip.require_cuda_f32(theta)
-    layouts = {"ncdhw": hip.LAYOUT_NCDHW, "ndhwc": hip.LAYOUT_NDHWC, "cg8": hip.LAYOUT_CG8, "p4": hip.LAYOUT_P4}
+    layouts = {"ncdhw": hip.LAYOUT_NCDHW, "ndhwc": hip.LAYOUT_NDHWC, "p4": hip.LAYOUT_P4}
     if in_layout not in layouts or out_layout not in layouts:
-        raise ValueError("layouts are 'ncdhw', 'p4', 'ndhwc' or 'cg8'")
+        raise ValueError("layouts are 'ncdhw', 'ndhwc' or 'p4'")
     if in_layout == "p4":
         Nv, Q4, D, H, W, four = vol.shape
         if four != 4:
@@ -48,11 +48,6 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
         C = 4 * Q4
     elif in_layout == "ndhwc":
         Nv, D, H, W, C = vol.shape
-    elif in_layout == "cg8":
-        Nv, G8, D, H, W, CG = vol.shape
-        if G8 != 8:
-            raise ValueError("a 'cg8' volume is [N, 8, D, H, W, C/8]")
-        C = 8 * CG
     else:
         Nv, C, D, H, W = vol.shape
     lx = ly = lz = None
@@ -82,8 +77,14 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
     if Nv not in (1, N):
         raise ValueError(f"volume batch {Nv} does not match grid batch {N}")
     stride = 0 if (Nv == 1 and N > 1) else C * D * H * W
-    shape = {"ndhwc": (N, Do, Ho, Wo, C), "cg8": (N, 8, Do, Ho, Wo, C // 8), "ncdhw": (N, C, Do, Ho, Wo),
-             "p4": (N, C // 4, Do, Ho, Wo, 4)}[out_layout]
+    if (in_layout == "ncdhw" and out_layout == "ncdhw" and variant == 0 and C % 4 == 0 and C >= 16
+            and Nv * C * D * H * W >= (1 << 20)):
+        # the reference's call shape (model.grid_sample(NCDHW, grid) -> NCDHW, va.py:264-265) on a large volume: one repack
+        # to channels-last + the channels-last gather (NCDHW out) moves 51 MB in 23 us, the NCDHW gather needs 35 us
+        # (its 4-byte corner loads are bound by the vector-memory instruction rate; profiles/r3_sampler_seam.jsonl)
+        return grid_sample3d(volume_to_channels_last(vol), grid if delta is None else None, theta, padding_mode, "ndhwc",
+                             "ncdhw", 0, out, delta)
+    shape = {"ndhwc": (N, Do, Ho, Wo, C), "ncdhw": (N, C, Do, Ho, Wo), "p4": (N, C // 4, Do, Ho, Wo, 4)}[out_layout]
     if out is None:
         out = torch.empty(shape, device=vol.device, dtype=torch.float32)
     else:
@@ -161,28 +162,6 @@ def volume_from_p4(vol):
     N, Q, D, H, W, _ = vol.shape
     out = torch.empty((N, 4 * Q, D, H, W), device=vol.device, dtype=torch.float32)
     hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, 4 * Q, D * H * W, 5, hip.current_stream()),
-              "emo_volume_repack_f32")
-    return out
-
-
-def volume_to_cg8(vol):
-    """[N,C,D,H,W] -> [N,8,D,H,W,C/8]: 8 channel groups, each a channels-last sub-volume (EMO_LAYOUT_CG8)"""
-    lib = hip.load()
-    hip.require_cuda_f32(vol)
-    N, C, D, H, W = vol.shape
-    out = torch.empty((N, 8, D, H, W, C // 8), device=vol.device, dtype=torch.float32)
-    hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, C, D * H * W, 2, hip.current_stream()),
-              "emo_volume_repack_f32")
-    return out
-
-
-def volume_from_cg8(vol):
-    """[N,8,D,H,W,C/8] -> [N,C,D,H,W]"""
-    lib = hip.load()
-    hip.require_cuda_f32(vol)
-    N, G8, D, H, W, CG = vol.shape
-    out = torch.empty((N, 8 * CG, D, H, W), device=vol.device, dtype=torch.float32)
-    hip.check(lib.emo_volume_repack_f32(hip.ptr(vol), hip.ptr(out), N, 8 * CG, D * H * W, 3, hip.current_stream()),
               "emo_volume_repack_f32")
     return out
 

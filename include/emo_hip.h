@@ -40,9 +40,7 @@ extern "C" {
 /* memory layout of a 5-D volume */
 #define EMO_LAYOUT_NCDHW 0         /* the reference's layout                                    */
 #define EMO_LAYOUT_NDHWC 1         /* channels-last, internal fast path (gathers read C contiguous floats) */
-#define EMO_LAYOUT_CG8 2           /* [N][8][D][H][W][C/8]: 8 channel groups, each a channels-last sub-volume; the sampler
-                                      runs group g on XCD g so that a group's sub-volume (3.1 MB for the released 96 x 16 x 64 x 64
-                                      canonical volume) stays resident in that XCD's private 4 MiB L2.  Needs C % 32 == 0.  */
+/* 2: retired (channel-group-per-XCD layout of round 2: equal time) */
 #define EMO_LAYOUT_P4 3            /* packed-4: [N][C/4][D][H][W][4] -- a voxel's channel quad is one 16-byte slot, x-rows are
                                       contiguous: the layout of the LDS-staged sampler (one LDS-DMA lane per box voxel, ds_read_b128
                                       gathers).  Needs C % 4 == 0.  */
@@ -75,13 +73,14 @@ const char* emo_build_info(void);
  *   grid_kind  0: `grid` holds coordinates [N,Do,Ho,Wo,3].  1: `grid` holds planar deltas [N,3,Do,Ho,Wo] and the
  *         coordinate is lattice + delta -- the WarpGenerator output  warp = (identity_grid + deltas).permute(0,2,3,4,1)
  *         (networks/volumetric_avatar/warp_generator_resnet.py:178) consumed without materialising `warp`.
- *   variant    0 = default kernels; other values select alternative tunings (kept for A/B measurements).
+ *   variant    0 = default kernels.  NCDHW -> NCDHW: channels per block of the direct gather (1..C).  NDHWC input: 1 forces
+ *         row-shaped blocks where the default uses 4 x 4 x 4 output bricks (A/B of the brick shape).
  *         For the LDS-staged tile kernels (in_layout EMO_LAYOUT_P4, or NCDHW -> NCDHW with bit 30 set) it is a tuning word:
  *         bits 3..0 / 7..4 / 11..8 log2 of the output tile extents x / y / z (all 0: default), 16..12 channel units per
  *         block, 24..17 LDS per block in KiB, bit 25: 512-thread blocks.  tile voxels = threads or 2 * threads.
  *   out   [N, C, Do, Ho, Wo] or [N, Do, Ho, Wo, C] according to out_layout.
  *   vol_batch_stride  elements between consecutive volumes (0 = shared volume).
- * NDHWC paths require C % 4 == 0.  in_layout EMO_LAYOUT_CG8 (C % 32 == 0) supports out_layout CG8 and NCDHW.
+ * NDHWC paths require C % 4 == 0 and support out_layout NDHWC and NCDHW.
  * in_layout EMO_LAYOUT_P4 (C % 4 == 0) supports out_layout P4 and NCDHW: the LDS-staged kernels (csrc/gs3d_tile.h) --
  * the source box of an output tile is brought into LDS by LDS-DMA once and the 8-corner gather runs out of LDS.
  */
@@ -100,8 +99,7 @@ int emo_affine_grid3d_f32(const float* theta, const float* lin_x, const float* l
                           float* grid, int N, int Do, int Ho, int Wo, void* stream);
 
 /* Layout repack of a 5-D volume (used once per identity on the cached canonical volume, notebooks/infer.py:507
- * `self.target_latent_volume`).  to_channels_last: 0 NDHWC -> NCDHW, 1 NCDHW -> NDHWC, 2 NCDHW -> CG8, 3 CG8 -> NCDHW,
- * 4 NCDHW -> P4, 5 P4 -> NCDHW. */
+ * `self.target_latent_volume`).  to_channels_last: 0 NDHWC -> NCDHW, 1 NCDHW -> NDHWC, 4 NCDHW -> P4, 5 P4 -> NCDHW. */
 int emo_volume_repack_f32(const float* in, float* out, int N, int C, int DHW, int to_channels_last, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

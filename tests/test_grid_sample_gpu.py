@@ -40,21 +40,11 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
     if vol.shape[1] % 4 == 0:
         vcl = ops.volume_to_channels_last(vol)
         assert torch.equal(vcl.cpu(), vol_cpu.permute(0, 2, 3, 4, 1).contiguous())
-        ocl = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc")
-        res["cl"] = ops.volume_to_channels_first(ocl).cpu()
-        assert torch.equal(res["cl"], ocl.cpu().permute(0, 4, 1, 2, 3).contiguous())
-        res["cl2ncdhw"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw").cpu()
-        Do_, Ho_, Wo_ = (grid_cpu.shape[1:4] if grid_cpu is not None else vol_cpu.shape[2:])
-        bricks = (12,) if (Do_ % 4 == 0 and Ho_ % 4 == 0 and Wo_ % 4 == 0) else ()     # 4x4x4 output bricks per block
-        for var in (3, 4, 5, 6, 7) + bricks:   # block-order / voxels-per-block variants of the v2 kernels
-            o = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=var)
-            res[f"cl_var{var}"] = o.cpu().permute(0, 4, 1, 2, 3).contiguous()
-        for var in (3, 4, 5):
+        for var in (0, 1):       # default (4x4x4 output bricks where the lattice allows) and row-shaped blocks
+            ocl = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=var)
+            res[f"cl_var{var}"] = ops.volume_to_channels_first(ocl).cpu()
+            assert torch.equal(res[f"cl_var{var}"], ocl.cpu().permute(0, 4, 1, 2, 3).contiguous())
             res[f"cl2ncdhw_var{var}"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw", variant=var).cpu()
-        # variant 1 = the first-generation channels-last kernels (kept for A/B measurements)
-        ocl1 = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=1)
-        res["cl_v1"] = ocl1.cpu().permute(0, 4, 1, 2, 3).contiguous()
-        res["cl2ncdhw_v1"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw", variant=1).cpu()
     if vol.shape[1] % 4 == 0:
         # LDS-staged tile kernels: packed-4 layout [N, C/4, D, H, W, 4] (csrc/gs3d_tile.h), default + forced tunings
         vp4 = ops.volume_to_p4(vol)
@@ -68,15 +58,6 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
     if vol.shape[4] % 4 == 0:
         for tag, var in TILE_TUNINGS:
             res["ncdhw_tile" + tag] = ops.grid_sample3d(vol, grid, theta, pm, variant=ops.TILE | var).cpu()
-    if vol.shape[1] % 32 == 0:
-        # channel-group-per-XCD layout [N, 8, D, H, W, C/8]
-        vcg = ops.volume_to_cg8(vol)
-        N_, C_, D_, H_, W_ = vol_cpu.shape
-        assert torch.equal(vcg.cpu(), vol_cpu.view(N_, 8, C_ // 8, D_, H_, W_).permute(0, 1, 3, 4, 5, 2).contiguous())
-        assert torch.equal(ops.volume_from_cg8(vcg).cpu(), vol_cpu)
-        ocg = ops.grid_sample3d(vcg, grid, theta, pm, in_layout="cg8", out_layout="cg8")
-        res["cg8"] = ops.volume_from_cg8(ocg).cpu()
-        res["cg8_to_ncdhw"] = ops.grid_sample3d(vcg, grid, theta, pm, in_layout="cg8", out_layout="ncdhw").cpu()
     return res
 
 
@@ -174,14 +155,14 @@ def test_size_independent_properties_at_batch_64():
     ocl = ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ndhwc")
     assert torch.equal(ops.volume_to_channels_first(ocl), out)
     assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw"), out)
-    # variant 8: z-slice-major block order over each XCD's 8 samples (shared-volume fast path)
-    assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=8), out)
-    assert torch.equal(ops.grid_sample3d(vcl, grid[:5].contiguous(), in_layout="ndhwc", out_layout="ncdhw", variant=8), out[:5])
-    assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=9), out)
-    for var in (10, 11):
-        assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=var), out), var
-        assert torch.equal(ops.grid_sample3d(vcl, grid[:3].contiguous(), in_layout="ndhwc", out_layout="ncdhw", variant=var), out[:3]), var
-    assert torch.equal(ops.volume_to_channels_first(ops.grid_sample3d(vcl, grid[:16].contiguous(), in_layout="ndhwc", out_layout="ndhwc", variant=9)), out[:16])
+    # row-shaped blocks (variant 1): with a shared volume and N % 8 == 0 they run row-group-major over each XCD's samples;
+    # 5 samples take the plain XCD-contiguous order
+    assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=1), out)
+    assert torch.equal(ops.grid_sample3d(vcl, grid[:5].contiguous(), in_layout="ndhwc", out_layout="ncdhw", variant=1), out[:5])
+    assert torch.equal(ops.volume_to_channels_first(ops.grid_sample3d(vcl, grid[:16].contiguous(), in_layout="ndhwc", out_layout="ndhwc", variant=1)), out[:16])
+    # the LDS-staged tile kernels on the same 64-sample batch
+    vp4 = ops.volume_to_p4(vol)
+    assert torch.equal(ops.grid_sample3d(vp4, grid, in_layout="p4", out_layout="ncdhw"), out)
     zs, ys, xs = [((2 * torch.arange(n) + 1) / n - 1) for n in (D, S, S)]
     zz, yy, xx = torch.meshgrid(zs, ys, xs, indexing="ij")
     centre = torch.stack([xx, yy, zz], -1)[None].to(DEV)
@@ -212,39 +193,6 @@ def test_delta_grid_mode_equals_materialised_warp(pm):
     assert torch.equal(ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw").cpu(), ref)
     o = ops.grid_sample3d(vcl, delta=delta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ndhwc")
     assert torch.equal(o.cpu().permute(0, 4, 1, 2, 3), ref)
-
-
-@pytest.mark.parametrize("pm", PADS)
-def test_channel_group_layout_driver_pair_bit_exact(pm):
-    """the two sampler calls of the driver pass in the channel-group-per-XCD layout (EMO_LAYOUT_CG8): shared canonical
-    volume + planar deltas -> CG8 intermediate -> analytic theta -> NCDHW, against torch CPU on the materialised grids;
-    N = 5 samples (not a multiple of 8), ragged last block (Do*Ho*Wo not a multiple of 256), 32 and 96 channels"""
-    for C, D, S, N in ((32, 3, 10, 5), (96, 16, 64, 2)):
-        g = torch.Generator().manual_seed(C)
-        vol = torch.randn(1, C, D, S, S, generator=g)
-        delta = torch.tanh(torch.randn(N, 3, D, S, S, generator=g)) * 0.1
-        theta = O.get_transform_matrix(1 + 0.05 * torch.randn(N, 3, generator=g), 0.3 * torch.randn(N, 3, generator=g),
-                                       0.05 * torch.randn(N, 3, generator=g))
-        ident = O.identity_grid_3d(D, S)[..., :3].view(1, D, S, S, 3).permute(0, 4, 1, 2, 3)
-        warp = (ident + delta).permute(0, 2, 3, 4, 1)
-        ref1 = F.grid_sample(vol.expand(N, -1, -1, -1, -1), warp, padding_mode=pm, align_corners=False)
-        vcg = ops.volume_to_cg8(vol.to(DEV))
-        w = ops.grid_sample3d(vcg, delta=delta.to(DEV), padding_mode=pm, in_layout="cg8", out_layout="cg8")
-        assert w.shape == (N, 8, D, S, S, C // 8)
-        assert torch.equal(ops.volume_from_cg8(w).cpu(), ref1)
-        # second call on the per-sample intermediate: same coordinates as the channels-last kernel => identical output
-        a = ops.grid_sample3d(w, theta=theta.to(DEV), padding_mode=pm, in_layout="cg8", out_layout="ncdhw")
-        wcl = ops.volume_to_channels_last(ops.volume_from_cg8(w))
-        b = ops.grid_sample3d(wcl, theta=theta.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw")
-        assert torch.equal(a, b)
-        grid2 = ops.affine_grid3d(theta.to(DEV), (D, S, S)).cpu()
-        assert torch.equal(a.cpu(), F.grid_sample(ref1, grid2, padding_mode=pm, align_corners=False))
-
-
-def test_channel_group_layout_needs_whole_quads_per_group():
-    vol = torch.randn(1, 8, 2, 2, 2, 3, device=DEV)          # C = 24: not a multiple of 32
-    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
-        ops.grid_sample3d(vol, torch.zeros(1, 2, 2, 2, 3, device=DEV), in_layout="cg8", out_layout="cg8")
 
 
 def test_empty_batch_is_rejected():

@@ -116,7 +116,7 @@ def test_driver_pass_released_architecture_vs_oracle(S, B):
     st = {}
     delta_ref = d(ref["delta_uv"])
     from emoportraits_amd import ops
-    lay = "cg8" if ccl.dim() == 6 else "ndhwc"
+    lay = "ndhwc"
     warped = ops.grid_sample3d(ccl, delta=delta_ref, in_layout=lay, out_layout=lay)
     aligned = ops.grid_sample3d(warped, theta=d(x["th_t"]), in_layout=lay, out_layout="ncdhw")
     st["samplers"] = rel(aligned, ref["aligned"])

@@ -42,7 +42,7 @@ def main():
         theta = ops.pose_theta(*srt)
         emb = hp.embed(pose, idt)
         delta = hp.uv_generator(emb)
-        lay = "cg8" if ccl.dim() == 6 else "ndhwc"
+        lay = "ndhwc"
         warped = ops.grid_sample3d(ccl, delta=delta, in_layout=lay, out_layout=lay)
         aligned = ops.grid_sample3d(warped, theta=theta, in_layout=lay, out_layout="ncdhw")
         feat = aligned.view(B, 96 * 16, 64, 64)

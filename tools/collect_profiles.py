@@ -17,7 +17,9 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_smoke.log", f"{tag}_smoke.txt"),
                  (f"{tag}_ndhwc_pmc_sampler.json", f"{tag}_pmc_sampler_ndhwc_warp0.05.json"),
                  (f"{tag}_ndhwc_small_pmc_sampler.json", f"{tag}_pmc_sampler_ndhwc_warp0.02.json"),
-                 (f"{tag}_cg8_pmc_sampler.json", f"{tag}_pmc_sampler_cg8_warp0.05.json"),
+                 (f"{tag}_p4tile_pmc_sampler.json", f"{tag}_pmc_sampler_lds_tile_warp0.03.json"),
+                 (f"{tag}_sampler_tile.jsonl", f"{tag}_sampler_tile_sweep.jsonl"), (f"{tag}_sampler_pair.jsonl", f"{tag}_sampler_tile_pair.jsonl"),
+                 (f"{tag}_mem_ceilings.jsonl", f"{tag}_mem_ceilings.jsonl"),
                  (f"{tag}_f16_kernel_stats.csv", f"{tag}_f16_stage2_kernel_stats.csv"),
                  (f"{tag}_f16_pmc_mfma.json", f"{tag}_f16_stage2_pmc_mfma.json"),
                  (f"{tag}_f16_pmc_fetch.json", f"{tag}_f16_stage2_pmc_fetch.json"),

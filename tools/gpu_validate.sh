@@ -22,6 +22,5 @@ timeout 300 python tools/probe_embedders.py 2>&1 | grep -v amdgpu.ids > gpurun_o
 bash tools/profile_bench.sh ${TAG}
 bash tools/pmc_sampler.sh ${TAG}_ndhwc 16 0.05 ndhwc > gpurun_out/${TAG}_pmc_sampler_ndhwc.log 2>&1
 bash tools/pmc_sampler.sh ${TAG}_ndhwc_small 16 0.02 ndhwc > gpurun_out/${TAG}_pmc_sampler_ndhwc_small.log 2>&1
-bash tools/pmc_sampler.sh ${TAG}_cg8 16 0.05 cg8 > gpurun_out/${TAG}_pmc_sampler_cg8.log 2>&1
 bash tools/profile_f16.sh ${TAG}
 tail -3 gpurun_out/${TAG}_pytest.log; tail -1 gpurun_out/${TAG}_smoke.log; cut -c1-200 gpurun_out/${TAG}_bench.json
