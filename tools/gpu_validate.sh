@@ -3,9 +3,9 @@
 #   all GPU parity tests, smoke(), the bench line (N=1; R512 and R256), `python bench.py --gpus 2` on one GPU (gloo, test hook),
 #   stage-2 throughput, sampler / conv microbenchmarks, driver-pass breakdown, images-in/images-out pipeline, embedder parity +
 #   timing, rocprofv3 kernel stats + PMC passes of the bench, sampler L1/L2 counters, fp16-mode evidence.
-# usage: gpurun -- 'bash tools/gpu_validate.sh r2'   then   python tools/collect_profiles.py r2
+# usage: gpurun -- 'bash tools/gpu_validate.sh r3'   then   python tools/collect_profiles.py r3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r2}
+TAG=${1:-r3}
 mkdir -p $R/gpurun_out; cd $R
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${TAG}_pytest_full.log
 grep -a "PARITY\|passed\|failed\|Error\|FAILED" gpurun_out/${TAG}_pytest_full.log > gpurun_out/${TAG}_pytest.log
@@ -22,5 +22,6 @@ timeout 300 python tools/probe_embedders.py 2>&1 | grep -v amdgpu.ids > gpurun_o
 bash tools/profile_bench.sh ${TAG}
 bash tools/pmc_sampler.sh ${TAG}_ndhwc 16 0.05 ndhwc > gpurun_out/${TAG}_pmc_sampler_ndhwc.log 2>&1
 bash tools/pmc_sampler.sh ${TAG}_ndhwc_small 16 0.02 ndhwc > gpurun_out/${TAG}_pmc_sampler_ndhwc_small.log 2>&1
+bash tools/pmc_sampler.sh ${TAG}_p4tile 16 0.03 p4 > gpurun_out/${TAG}_pmc_sampler_p4tile.log 2>&1
 bash tools/profile_f16.sh ${TAG}
 tail -3 gpurun_out/${TAG}_pytest.log; tail -1 gpurun_out/${TAG}_smoke.log; cut -c1-200 gpurun_out/${TAG}_bench.json
