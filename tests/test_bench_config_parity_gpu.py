@@ -101,6 +101,13 @@ def test_driver_pass_R512_B16_trained_like_checkpoint_vs_oracle():
         worst["u8_same"] = min(worst["u8_same"], e["u8_same"])
     assert worst["delta_vox"] < 1.5 and worst["saturated"] < 0.05, worst      # the checkpoint is what it claims to be
     assert worst["img_abs"] <= 2e-4 and worst["batch1_abs"] <= 2e-4 and worst["u8_same"] >= 0.999, worst
+    # the opt-in fp16-operand mode (BASELINE configs[4]) on the same checkpoint, same launch plan: its stated tolerance is
+    # 2e-3 mean / 2e-2 worst pixel of the [0, 1] image (operands carry 11 significand bits, accumulation is fp32)
+    hp16 = nets.HotPath(sd, cfg, DEV, with_source=False, precision="f16")
+    img16 = hp16.driver_pass(hp16.prepare_canonical(d(x["canonical"])), d(x["idt"]), d(x["pose_t"]), d(x["th_t"]))
+    e16 = (img16 - got["img"]).abs()             # vs the exact-fp32 HIP path, which is within 1.5e-5 of the oracle (above)
+    print(f"PARITY R512 B=16 trained-like checkpoint, fp16 operands: image worst {e16.max().item():.3e} mean {e16.mean().item():.3e}")
+    assert e16.max().item() <= 2e-2 and e16.mean().item() <= 2e-3
 
 
 def test_source_pass_R512_vs_oracle():
