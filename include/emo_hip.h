@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 3
+#define EMO_ABI_VERSION 4
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
