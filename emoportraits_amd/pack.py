@@ -9,6 +9,7 @@ path.  The folding formulas restate what the reference recomputes on every forwa
 import contextlib
 import ctypes
 import functools
+import math
 
 import torch
 
@@ -177,6 +178,19 @@ def ksplit_for(blocks, nstages):
     return max(1, min(-(-_FILL_BLOCKS // blocks), nstages // 8, _MAX_KSPLIT))
 
 
+def _quantisation(nblocks, cus=256):
+    """a launch of a few blocks per CU finishes when the most loaded CU does: 640 blocks put 3 on half of the CUs and 2 on
+    the rest -- 2.5 / 3 of the machine.  Measured at batch 2 (profiles/r3_conv_microbench_b2.jsonl): 320 -> 320 @128^2 runs at
+    113 TF on the 64 x 256 tile (640 blocks) and at 130 TF on the 64 x 128 tile (1280 blocks)."""
+    if nblocks < cus or EMO_PLAN_QUANTISATION == 0:
+        return 1.0
+    per_cu = nblocks / cus
+    return per_cu / math.ceil(per_cu - 1e-9)
+
+
+EMO_PLAN_QUANTISATION = int(__import__("os").environ.get("EMO_PLAN_QUANTISATION", "1"))   # 0: A/B switch (round-2 planner)
+
+
 def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C), precision="f32"):
     """(block config, K split) of one launch: fill the 256 CUs first (by splitting K if the tile grid is small), then
     least channel padding, then the larger tile"""
@@ -188,6 +202,7 @@ def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C
         blocks = cot * max(1, n_pos_tiles * 128 // _BP[cfg])
         ks = ksplit_for(blocks, nstages)
         score = min(blocks * ks, _FILL_BLOCKS) / _FILL_BLOCKS * (cout / (cot * bm)) * _CFG_EFF[cfg] * (0.97 if ks > 1 else 1.0)
+        score *= _quantisation(blocks * ks)
         if best is None or score > best[0] + 1e-9:
             best = (score, cfg, ks)
     return best[1], best[2]

@@ -60,7 +60,7 @@ def main():
                    torch_tflops=round(flops / ms_t / 1e9, 1) if ms_t else None)
         for cfg in (() if f16_only else (0, 1, 2, 3, 4, 5)):
             bm = {0: 128, 1: 64, 2: 32, 3: 64, 4: 64, 5: 32}[cfg]
-            if cfg == 2 and cout > 96:
+            if cfg == 2 and cout > 320:
                 continue
             if cfg in (3, 4, 5) and (k != 3 or dims[-1] < 32 or (three_d and cfg == 4)):
                 continue
@@ -79,6 +79,14 @@ def main():
             msh = timeit(lambda: ops.conv_igemm(x, lh, scale, shift, relu_in=True, ups=ups, out=out))
             rec["f16_cfg3_ms"] = round(msh, 3)
             rec["f16_cfg3_tflops"] = round(flops / msh / 1e9, 1)
+        if not f16_only:       # what the planner picks for this launch (block config + K split), as the networks run it
+            la = pack.PackedConv("auto", w, None, DEV)
+            Hl_, Wl_ = odims[-2], odims[-1]
+            pos = B * math.prod(odims)
+            cfg_a, ks_a, _ = la.plan_for(max(1, -(-pos // 128)), Hl_, Wl_, ups, affine=True)
+            out = ops.conv_igemm(x, la, scale, shift, relu_in=True, ups=ups)
+            ms = timeit(lambda: ops.conv_igemm(x, la, scale, shift, relu_in=True, ups=ups, out=out))
+            rec["planner"] = dict(cfg=cfg_a, ksplit=ks_a, ms=round(ms, 3), tflops=round(flops / ms / 1e9, 1))
         rec["auto_cfg"] = pack.choose_cfg(cout)
         print(json.dumps(rec), flush=True)
     # GroupNorm statistics kernel vs torch group_norm+relu (which the conv staging makes unnecessary)

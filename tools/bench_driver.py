@@ -11,17 +11,19 @@ from emoportraits_amd import config, graphs, nets, ops, random_init  # noqa: E40
 DEV = "cuda:0"
 
 
-def timeit(fn, iters=5, warmup=2):
+def timeit(fn, iters=7, warmup=2):
+    """median of per-call HIP-event times (a mean lets one hiccup -- a lazy weight packing, a clock ramp -- leak into a stage)"""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
         fn()
-    b.record()
+        b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
 
 
 def main():
