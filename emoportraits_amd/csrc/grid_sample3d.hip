@@ -21,6 +21,24 @@
 
 #define EMO_GS3D_TILE_FLAG (1 << 30)   /* variant bit: NCDHW -> NCDHW through the LDS-staged planar kernel (gs3d_tile.h) */
 
+#ifndef EMO_GS3D_NT_STORES
+#define EMO_GS3D_NT_STORES 0   /* A/B: non-temporal stores of the channels-last sampler output.  Measured (profiles/
+                                  r3_sampler_nt_stores_ab.jsonl): the uv call itself does not change (12.8 vs 13.1 us per frame), the
+                                  rotation call that reads the intermediate back in chunks of 4 frames goes from 13.1 to 17.3 us --
+                                  the plain stores leave it in the Infinity Cache, the non-temporal ones do not.  Off. */
+#endif
+typedef float emo_f32x4 __attribute__((ext_vector_type(4)));
+#if EMO_GS3D_NT_STORES
+#define EMO_GS3D_STORE(ptr, val)                                                                                       \
+  do {                                                                                                                 \
+    const float4 v_ = (val);                                                                                           \
+    emo_f32x4 n_ = {v_.x, v_.y, v_.z, v_.w};                                                                          \
+    __builtin_nontemporal_store(n_, reinterpret_cast<emo_f32x4*>(ptr));                                               \
+  } while (0)
+#else
+#define EMO_GS3D_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace {
 
 struct Taps {
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
     const int v = item / LPV;
     const int q = item - v * LPV;
     const TapRec r = recs[v];
-    obase[item] = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
+    EMO_GS3D_STORE(&obase[item], gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u));
   }
 }
 
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_brick_kernel(
     const int v = item / LPV;
     const int q = item - v * LPV;
     const TapRec r = recs[v];
-    obase[(long)vox_of[v] * LPV + q] = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
+    EMO_GS3D_STORE(&obase[(long)vox_of[v] * LPV + q], gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u));
   }
 }
 
