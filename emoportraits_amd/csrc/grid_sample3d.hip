@@ -291,7 +291,7 @@ template <int PAD, int MODE, int VPB, int ORDER>
 __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
-    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int bps) {
+    float* __restrict__ out, int C, int D, int H, int W, int Do, int Ho, int Wo, long vol_bstride, int bps, int nt_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   TapRec* recs = reinterpret_cast<TapRec*>(smem);                 // VPB * 80 B
   float* tile = smem + VPB * (sizeof(TapRec) / 4);                 // [C][VPB + 1]
@@ -323,7 +323,12 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   for (int i = threadIdx.x; i < C * VPB; i += 256) {
     const int c = i / VPB;
     const int v = i - c * VPB;
-    if (v < nv) obase[(long)c * nvox + v] = tile[c * LD + v];
+    if (v < nv) {
+      // nt_out: the NCDHW result is streamed past the caches -- in the driver pass it is read much later (by the decoder),
+      // while the Infinity Cache is what serves the intermediate of the sampler pair (measured: pair - 5 % at chunks of 4)
+      if (nt_out) __builtin_nontemporal_store(tile[c * LD + v], &obase[(long)c * nvox + v]);
+      else obase[(long)c * nvox + v] = tile[c * LD + v];
+    }
   }
 }
 
@@ -332,14 +337,14 @@ constexpr int CL_VPB = 64;      // output voxels per block of the row-shaped ker
 template <int PAD, int MODE, int ORDER>
 int launch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                  const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
-                 long vol_bstride, bool out_cl, hipStream_t s) {
+                 long vol_bstride, bool out_cl, hipStream_t s, int nt_out = 0) {
   const int nvox = Do * Ho * Wo;
   const int bps = emo_cdiv(nvox, CL_VPB);
   const long total = (long)bps * N;
   if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
   if (ORDER == 3 && ((N & 7) || (bps % Do) || (nvox % CL_VPB) || ((bps / Do) % 8)))   // whole slices / groups, N % 8 == 0
     return launch_cl_v2<PAD, MODE, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
-                                      out_cl, s);
+                                      out_cl, s, nt_out);
   if (out_cl) {
     hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, CL_VPB, ORDER>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
                        theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
@@ -347,21 +352,24 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
     const size_t lds = CL_VPB * sizeof(TapRec) + (size_t)C * (CL_VPB + 1) * sizeof(float);
     if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, CL_VPB, ORDER>), dim3((unsigned)total), dim3(256), lds, s, vol,
-                       grid, theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
+                       grid, theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps, nt_out);
   }
   return emo_launch_status();
 }
 
-// variant of the channels-last kernels: 0 = default; 1 = row-shaped blocks forced (A/B of the brick shape).
-// Default: NDHWC output with Do, Ho, Wo multiples of 4 -> 4 x 4 x 4 output bricks per block (half the L1 fills per voxel:
-// measured - 10 ... 12 % on the uv call); otherwise 64-voxel rows, XCD-contiguous, and for a volume shared by N % 8 == 0
-// samples also row-group-major over the XCD's samples.
+// variant word of the channels-last kernels (bits): 1 = 4 x 4 x 4 output bricks per block instead of 64-voxel rows (NDHWC output,
+// Do / Ho / Wo multiples of 4): half the L1 fills per voxel, the uv call alone 11.7 instead of 12.3 us per frame -- but the
+// rotation call that reads its output back is then 0.6-0.8 us slower (its blocks walk the volume in row order), so the pair
+// is 1.3 us per frame slower: opt-in.  2 = non-temporal stores of an NCDHW output (the driver pass's rotation call).
+// Default: 64-voxel rows, XCD-contiguous, and for a volume shared by N % 8 == 0 samples also row-group-major over the XCD's
+// samples.  (profiles/r3_sampler_nt_stores_ab.jsonl, r3_sampler_nt_out_ab.jsonl)
 template <int PAD, int MODE>
 int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                    const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                    long vol_bstride, bool out_cl, int variant, hipStream_t s) {
-  if (variant != 0 && variant != 1) return EMO_ERR_BAD_ARG;
-  if (variant == 0 && out_cl && !(Do & 3) && !(Ho & 3) && !(Wo & 3)) {
+  if (variant < 0 || variant > 3) return EMO_ERR_BAD_ARG;
+  const int nt_out = (variant & 2) && !out_cl;
+  if ((variant & 1) && out_cl && !(Do & 3) && !(Ho & 3) && !(Wo & 3)) {
     const int bps = (Do * Ho * Wo) >> 6;
     const long total = (long)bps * N;
     if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
@@ -371,9 +379,9 @@ int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, cons
   }
   if (vol_bstride == 0 && N >= 8)
     return launch_cl_v2<PAD, MODE, 3>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
-                                      out_cl, s);
+                                      out_cl, s, nt_out);
   return launch_cl_v2<PAD, MODE, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
-                                    out_cl, s);
+                                    out_cl, s, nt_out);
 }
 
 // ------------------------------------------------------------------------------------------------------

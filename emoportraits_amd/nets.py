@@ -295,7 +295,11 @@ class HotPath:
         # frames per sampler launch pair: the warped intermediate of a chunk (25 MB per frame) is consumed by the second
         # call while it is still in the 256 MiB Infinity Cache (measured: 27.1 -> 23.5 us per frame for the pair at 16 frames)
         self.sampler_chunk = int(os.environ.get("EMO_SAMPLER_CHUNK", "4"))
-        self.sampler_uv_variant = int(os.environ.get("EMO_SAMPLER_UV_VARIANT", "0"))   # 1: row-shaped blocks instead of bricks (A/B)
+        self.sampler_uv_variant = int(os.environ.get("EMO_SAMPLER_UV_VARIANT", "0"))   # 1: 4x4x4 output bricks instead of rows (A/B)
+        # 2: the aligned volume goes past the caches (non-temporal stores).  Measured inconclusive: - 5 % on the pair when every
+        # launch is bracketed by events (profiles/r3_sampler_nt_out_ab.jsonl), nothing back to back or in the bench
+        # (profiles/r3_sampler_microbench.jsonl): off
+        self.sampler_rot_variant = int(os.environ.get("EMO_SAMPLER_ROT_VARIANT", "0"))
         from .pack import conv_precision
         # fp16 mode: the WarpGenerators stay exact fp32 (EMO_WARP_PRECISION=f16 overrides) -- their output is GEOMETRY (where
         # the volume is sampled): measured at R256, fp16 operands there put 2e-3 on the deltas and 2e-2 of max on the warped
@@ -353,7 +357,7 @@ class HotPath:
             warped = ops.grid_sample3d(canonical_cl, delta=delta_uv[a:b], padding_mode=self.pad, in_layout=lay, out_layout=lay,
                                        variant=self.sampler_uv_variant)
             ops.grid_sample3d(warped, theta=theta3[a:b], padding_mode=self.pad, in_layout=lay, out_layout="ncdhw",
-                              out=aligned[a:b])
+                              out=aligned[a:b], variant=self.sampler_rot_variant)
         feat = aligned.view(B, self.c * self.d, self.s, self.s)
         img, deep_f, img_f = self.decoder(feat)
         if keep:

@@ -40,10 +40,11 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
     if vol.shape[1] % 4 == 0:
         vcl = ops.volume_to_channels_last(vol)
         assert torch.equal(vcl.cpu(), vol_cpu.permute(0, 2, 3, 4, 1).contiguous())
-        for var in (0, 1):       # default (4x4x4 output bricks where the lattice allows) and row-shaped blocks
+        for var in (0, 1):       # default (64-voxel rows) and 4x4x4 output bricks where the lattice allows
             ocl = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ndhwc", variant=var)
             res[f"cl_var{var}"] = ops.volume_to_channels_first(ocl).cpu()
             assert torch.equal(res[f"cl_var{var}"], ocl.cpu().permute(0, 4, 1, 2, 3).contiguous())
+        for var in (0, 2):       # NCDHW output: plain and non-temporal stores
             res[f"cl2ncdhw_var{var}"] = ops.grid_sample3d(vcl, grid, theta, pm, in_layout="ndhwc", out_layout="ncdhw", variant=var).cpu()
     if vol.shape[1] % 4 == 0:
         # LDS-staged tile kernels: packed-4 layout [N, C/4, D, H, W, 4] (csrc/gs3d_tile.h), default + forced tunings
@@ -155,10 +156,10 @@ def test_size_independent_properties_at_batch_64():
     ocl = ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ndhwc")
     assert torch.equal(ops.volume_to_channels_first(ocl), out)
     assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw"), out)
-    # row-shaped blocks (variant 1): with a shared volume and N % 8 == 0 they run row-group-major over each XCD's samples;
-    # 5 samples take the plain XCD-contiguous order
-    assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=1), out)
-    assert torch.equal(ops.grid_sample3d(vcl, grid[:5].contiguous(), in_layout="ndhwc", out_layout="ncdhw", variant=1), out[:5])
+    # with a shared volume and N % 8 == 0 the row-shaped blocks run row-group-major over each XCD's samples; 5 samples take the
+    # plain XCD-contiguous order; variant 2: non-temporal output stores; variant 1: brick-shaped blocks
+    assert torch.equal(ops.grid_sample3d(vcl, grid, in_layout="ndhwc", out_layout="ncdhw", variant=2), out)
+    assert torch.equal(ops.grid_sample3d(vcl, grid[:5].contiguous(), in_layout="ndhwc", out_layout="ncdhw"), out[:5])
     assert torch.equal(ops.volume_to_channels_first(ops.grid_sample3d(vcl, grid[:16].contiguous(), in_layout="ndhwc", out_layout="ndhwc", variant=1)), out[:16])
     # the LDS-staged tile kernels on the same 64-sample batch
     vp4 = ops.volume_to_p4(vol)

@@ -52,11 +52,12 @@ def main():
         vol_bytes, grid_bytes = C * D * S * S * 4, D * S * S * 12
         uv_b, rot_b = vol_bytes / N + grid_bytes + vol_bytes, 2 * vol_bytes
         cases = [
-            ("uv_delta/cl bricks (default)", lambda: ops.grid_sample3d(vcl, delta=delta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), uv_b),
-            ("uv_delta/cl rows", lambda: ops.grid_sample3d(vcl, delta=delta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=1), uv_b),
-            ("uv_grid/cl bricks", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), uv_b),
+            ("uv_delta/cl rows (default)", lambda: ops.grid_sample3d(vcl, delta=delta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), uv_b),
+            ("uv_delta/cl bricks", lambda: ops.grid_sample3d(vcl, delta=delta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=1), uv_b),
+            ("uv_grid/cl rows", lambda: ops.grid_sample3d(vcl, warp, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), uv_b),
             ("rot_theta_unshared/cl2ncdhw", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc), rot_b),
-            ("rot_theta_unshared/cl bricks", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl), rot_b),
+            ("rot_theta_unshared/cl2ncdhw non-temporal out", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ncdhw", out=out_nc, variant=2), rot_b),
+            ("rot_theta_unshared/cl bricks", lambda: ops.grid_sample3d(inN_cl, theta=theta, in_layout="ndhwc", out_layout="ndhwc", out=out_cl, variant=1), rot_b),
             # the reference's call shape: NCDHW in, explicit grid, NCDHW out
             ("seam ncdhw->ncdhw/direct gather cpb8", lambda: ops.grid_sample3d(inN_nc, warp, variant=8, out=out_nc), rot_b + grid_bytes),
             ("seam ncdhw->ncdhw/default (repack + channels-last gather)", lambda: ops.grid_sample3d(inN_nc, warp, out=out_nc), rot_b + grid_bytes),
@@ -66,16 +67,17 @@ def main():
             ("copy/out_nc.copy_(inN_nc)", lambda: out_nc.copy_(inN_nc), rot_b),
         ]
 
-        def pair(chunk, uv_variant=0):
+        def pair(chunk, uv_variant=0, rot_variant=0):
             def run():
                 for a in range(0, N, chunk):
                     b = min(N, a + chunk)
                     ops.grid_sample3d(vcl, delta=delta[a:b], in_layout="ndhwc", out_layout="ndhwc", out=out_cl[a:b], variant=uv_variant)
-                    ops.grid_sample3d(out_cl[a:b], theta=theta[a:b], in_layout="ndhwc", out_layout="ncdhw", out=out_nc[a:b])
+                    ops.grid_sample3d(out_cl[a:b], theta=theta[a:b], in_layout="ndhwc", out_layout="ncdhw", out=out_nc[a:b], variant=rot_variant)
             return run
         for chunk in sorted({N, min(N, 8), min(N, 4), min(N, 2)}, reverse=True):
-            cases.append((f"pair/cl bricks+rows/chunk{chunk}", pair(chunk), uv_b + rot_b))
-            cases.append((f"pair/cl rows+rows/chunk{chunk}", pair(chunk, 1), uv_b + rot_b))
+            cases.append((f"pair/rows + rows (driver pass default)/chunk{chunk}", pair(chunk), uv_b + rot_b))
+            cases.append((f"pair/rows + rows, non-temporal out/chunk{chunk}", pair(chunk, 0, 2), uv_b + rot_b))
+            cases.append((f"pair/bricks + rows/chunk{chunk}", pair(chunk, 1, 0), uv_b + rot_b))
         for name, fn, bytes_per_sample in cases:
             med, best = timeit(fn)
             print(json.dumps(dict(N=N, case=name, ms_med=round(med, 4), ms_min=round(best, 4),

@@ -38,19 +38,19 @@ def main():
     tv = ops.tile_variant
 
     def run(kind, uvv, rotv, ev=None):
-        cl_uv_variant = 1 if kind == "cl_rows" else 0
+        cl_uv_variant = 1 if kind == "cl_bricks" else 0
         for a in range(0, N, chunk):
             b = min(N, a + chunk)
             if ev is not None:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
-            if kind in ("cl", "cl_rows"):
+            if kind in ("cl", "cl_bricks"):
                 ops.grid_sample3d(vcl, delta=delta[a:b], in_layout="ndhwc", out_layout="ndhwc", out=mid_cl[a:b], variant=cl_uv_variant)
             else:
                 ops.grid_sample3d(vp4, delta=delta[a:b], in_layout="p4", out_layout="p4", out=mid_p4[a:b], variant=uvv)
             if ev is not None:
                 e1.record()
-            if kind in ("cl", "cl_rows"):
+            if kind in ("cl", "cl_bricks"):
                 ops.grid_sample3d(mid_cl[a:b], theta=theta[a:b], in_layout="ndhwc", out_layout="ncdhw", out=out[a:b])
             else:
                 ops.grid_sample3d(mid_p4[a:b], theta=theta[a:b], in_layout="p4", out_layout="ncdhw", out=out[a:b], variant=rotv)
@@ -80,8 +80,8 @@ def main():
                               pair_frac_of_8TBps=round((uv_bytes + rot_bytes) / (t * 1e-3) / 8e12, 3),
                               uv_GBps=round(uv_bytes / (u * 1e-3) / 1e9), rot_GBps=round(rot_bytes / (r * 1e-3) / 1e9))), flush=True)
 
-    measure("channels-last pair: uv 4x4x4 bricks (default) + rot", "cl")
-    measure("channels-last pair: uv 64-voxel rows + rot", "cl_rows")
+    measure("channels-last pair: uv rows + rot (driver pass default)", "cl")
+    measure("channels-last pair: uv 4x4x4 bricks + rot", "cl_bricks")
     if "--tiles" not in sys.argv:
         return
     T = ops.TILE
