@@ -28,7 +28,17 @@
                                   the plain stores leave it in the Infinity Cache, the non-temporal ones do not.  Off. */
 #endif
 typedef float emo_f32x4 __attribute__((ext_vector_type(4)));
-#if EMO_GS3D_NT_STORES
+#ifndef EMO_GS3D_ABLATE
+#define EMO_GS3D_ABLATE 0      /* timing experiments only (results are WRONG for any value != 0): 1 no corner gathers, 2 no output
+                                  stores of the channels-last kernels, 4 no NCDHW stores of the rotation kernel (profiles/r3_sampler_ablation.jsonl) */
+#endif
+#if EMO_GS3D_ABLATE & 2
+#define EMO_GS3D_STORE(ptr, val)                                                                                       \
+  do {                                                                                                                 \
+    const float4 v_ = (val);                                                                                           \
+    if (v_.x == 12345.678f) *(ptr) = v_;                                                                               \
+  } while (0)
+#elif EMO_GS3D_NT_STORES
 #define EMO_GS3D_STORE(ptr, val)                                                                                       \
   do {                                                                                                                 \
     const float4 v_ = (val);                                                                                           \
@@ -203,9 +213,14 @@ __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const floa
 __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, const TapRec& r, unsigned row_bytes,
                                               unsigned qbyte) {
   float4 v[8];
+#if EMO_GS3D_ABLATE & 1     /* timing experiment (wrong results): no corner gathers */
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = make_float4(r.w[k], r.w[(k + 1) & 7], (float)r.off[k], (float)qbyte);
+#else
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     v[k] = *reinterpret_cast<const float4*>(vbytes + ((unsigned)r.off[k] * row_bytes + qbyte));
+#endif
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   // wave-uniform: does every lane of this wave have all 8 corners in range?
   if (__all(r.inb == 0xffu)) {
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   for (int i = threadIdx.x; i < C * VPB; i += 256) {
     const int c = i / VPB;
     const int v = i - c * VPB;
-    if (v < nv) {
+    if (v < nv && (!(EMO_GS3D_ABLATE & 4) || tile[c * LD + v] == 12345.678f)) {
       // nt_out: the NCDHW result is streamed past the caches -- in the driver pass it is read much later (by the decoder),
       // while the Infinity Cache is what serves the intermediate of the sampler pair (measured: pair - 5 % at chunks of 4)
       if (nt_out) __builtin_nontemporal_store(tile[c * LD + v], &obase[(long)c * nvox + v]);
