@@ -246,6 +246,21 @@ __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, c
   return acc;
 }
 
+// (voxel, quad) of item = threadIdx.x + 256 * k without a division per item: the runtime divisor LPV = C / 4 costs ~25 VALU
+// instructions per division, a third of an item's instruction count (the kernels' arithmetic skeleton is 40 % of their time,
+// profiles/r3_sampler_ablation.jsonl); one division per thread, then (v, q) advance by (256 / LPV, 256 % LPV) with a carry
+struct ItemWalk {
+  int v, q, dv, dq, lpv;
+  __device__ __forceinline__ ItemWalk(int tid, int LPV) : lpv(LPV) {
+    v = tid / LPV; q = tid - v * LPV;
+    dv = 256 / LPV; dq = 256 - dv * LPV;
+  }
+  __device__ __forceinline__ void next() {
+    v += dv; q += dq;
+    if (q >= lpv) { q -= lpv; ++v; }
+  }
+};
+
 // NDHWC -> NDHWC, 1-D grid of N * ceil(nvox/VPB) blocks
 template <int PAD, int MODE, int VPB, int ORDER>
 __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
@@ -264,11 +279,10 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
   const unsigned row_bytes = (unsigned)C * 4u;
   const int nitems = min(VPB, nvox - vox0) * LPV;
   float4* obase = reinterpret_cast<float4*>(out) + ((long)n * nvox + vox0) * LPV;
-  for (int item = threadIdx.x; item < nitems; item += 256) {
-    const int v = item / LPV;
-    const int q = item - v * LPV;
-    const TapRec r = recs[v];
-    EMO_GS3D_STORE(&obase[item], gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u));
+  ItemWalk w(threadIdx.x, LPV);
+  for (int item = threadIdx.x; item < nitems; item += 256, w.next()) {
+    const TapRec r = recs[w.v];
+    EMO_GS3D_STORE(&obase[item], gather_quad(vbytes, r, row_bytes, (unsigned)w.q * 16u));
   }
 }
 
@@ -293,11 +307,10 @@ __global__ __launch_bounds__(256) void gs3d_cl_brick_kernel(
   const char* vbytes = reinterpret_cast<const char*>(vol + (long)n * vol_bstride);
   const unsigned row_bytes = (unsigned)C * 4u;
   float4* obase = reinterpret_cast<float4*>(out) + (long)n * nvox * LPV;
-  for (int item = threadIdx.x; item < 64 * LPV; item += 256) {
-    const int v = item / LPV;
-    const int q = item - v * LPV;
-    const TapRec r = recs[v];
-    EMO_GS3D_STORE(&obase[(long)vox_of[v] * LPV + q], gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u));
+  ItemWalk w(threadIdx.x, LPV);
+  for (int item = threadIdx.x; item < 64 * LPV; item += 256, w.next()) {
+    const TapRec r = recs[w.v];
+    EMO_GS3D_STORE(&obase[(long)vox_of[w.v] * LPV + w.q], gather_quad(vbytes, r, row_bytes, (unsigned)w.q * 16u));
   }
 }
 
@@ -322,9 +335,9 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   const unsigned row_bytes = (unsigned)C * 4u;
   const int nv = min(VPB, nvox - vox0);
   const int nitems = nv * LPV;
-  for (int item = threadIdx.x; item < nitems; item += 256) {
-    const int v = item / LPV;
-    const int q = item - v * LPV;
+  ItemWalk w(threadIdx.x, LPV);
+  for (int item = threadIdx.x; item < nitems; item += 256, w.next()) {
+    const int v = w.v, q = w.q;
     const TapRec r = recs[v];
     const float4 acc = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
     const int c = q * 4;
