@@ -31,7 +31,11 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_conv_overhead_fit.jsonl", f"{tag}_conv_overhead_fit.jsonl"),
                  (f"{tag}_vmem_rate.jsonl", f"{tag}_vmem_rate_microbench.jsonl")):
     if os.path.exists(g + src):
-        shutil.copy(g + src, p + dst)
+        if dst.endswith(".json") and "bench" in dst:      # keep the JSON line only (gloo prints a banner to stdout)
+            lines = [l for l in open(g + src, errors="replace") if l.lstrip().startswith("{")]
+            open(p + dst, "w").writelines(lines[-1:] if lines else [])
+        else:
+            shutil.copy(g + src, p + dst)
 if os.path.exists(g + f"{tag}_pytest.log"):
     lines = [l for l in open(g + f"{tag}_pytest.log", errors="replace") if "PARITY" in l or "passed" in l or "failed" in l]
     open(p + f"{tag}_parity.txt", "w").writelines(lines)
