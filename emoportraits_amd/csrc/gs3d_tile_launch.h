@@ -85,16 +85,18 @@ int launch_tile(const float* vol, const float* grid, const float* theta, const f
   int upb = (variant >> 12) & 31, lds_kib = (variant >> 17) & 255;
   int threads = (variant >> 25) & 1 ? 512 : 256;
   if (txs + tys + tzs == 0) {
-    // default tiles (measured: DESIGN.md section 3.2): compact 4 x 8 x 8 bricks for rotations; for a warp field that
-    // stays near the identity a tile as deep as the volume, whose box is then clipped in z
-    if (MODE == MODE_THETA) { txs = 3; tys = 3; tzs = 2; }
-    else { txs = 3; tys = 2; tzs = 4; threads = 256; }
+    // default tile: 4 x 8 x 8 output voxels, one per thread -- the best of the sweeps for both calls at 16 frames per launch
+    // (profiles/r3_sampler_tile_sweep_n16.jsonl: rotation 15.6 us P4 -> P4, uv 11.6 us); larger tiles stage smaller boxes per
+    // voxel but leave too few blocks
+    txs = 3; tys = 3; tzs = 2; threads = 256;
     while (tzs > 0 && (1 << tzs) >= 2 * Do) { --tzs; ++tys; }
     while (tys > 0 && (1 << tys) >= 2 * Ho) { --tys; ++txs; }
   }
   int lv = txs + tys + tzs - (threads == 512 ? 9 : 8);                            // log2(VPT)
   if (lv < 0 || lv > 1) return EMO_ERR_BAD_ARG;
-  if (upb == 0) upb = IN_P4 ? (vol_bstride == 0 && N > 1 ? (p.units + 7) / 8 : 6) : 16;
+  // all channel units of a tile in one block: the per-block planning (taps, box, slot map: ~800 VALU + 3900 SALU instructions
+  // per wave) is the kernel's largest fixed cost (3 units per block: 43 us per frame, all 24: 23 us)
+  if (upb == 0) upb = p.units < 31 ? p.units : 31;
   if (upb > p.units) upb = p.units;
   if (lds_kib == 0) lds_kib = threads == 512 ? 80 : 40;
   if (lds_kib > 160 || lds_kib < 1) return EMO_ERR_BAD_ARG;
