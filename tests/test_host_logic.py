@@ -215,3 +215,39 @@ def test_fp16_plan_falls_back_to_fp32_where_the_fp16_kernel_cannot_run():
     assert wide.plan_for(32, 64, 64, affine=True)[2] == "f32"
     assert pack.F16_AFFINE_MAX_CIN == 1024
     assert pack.PackedConv("f", torch.zeros(64, 64, 3, 3), None, "cpu").plan_for(32, 64, 64)[2] == "f32"
+
+
+# ---- round-3 host logic ----------------------------------------------------------------------------------------------
+def test_trained_like_checkpoint_scales_only_the_head_tensors():
+    """trained_like_state_dict = random_state_dict with the image-head and warp-head gains; every other tensor identical
+    (the gains keep the predicted warp within a voxel and the sigmoid unsaturated -- the regime of a trained network)"""
+    cfg = config.hot_path_config(overrides={"image_size": 256})
+    raw = random_init.random_state_dict(cfg, seed=3, with_source=False)
+    tl = random_init.trained_like_state_dict(cfg, seed=3, with_source=False)
+    assert schema.check_state_dict(tl, cfg, with_source=False) and set(raw) == set(tl)
+    changed = sorted(k for k in raw if not torch.equal(raw[k], tl[k]))
+    assert changed, "gains had no effect"
+    assert all((".pre_head." in k or ".head." in k or "dec_img_head" in k) for k in changed), changed
+    warp = [k for k in changed if k.startswith(("xy_generator_nw", "uv_generator_nw"))]
+    assert warp and all(tl[k].abs().max() <= raw[k].abs().max() for k in warp)
+
+
+def test_tile_tuning_word_round_trips_the_header_fields():
+    """ops.tile_variant packs what gs3d_tile_launch.h unpacks: log2 tile extents, channel units per block, LDS KiB, 512 flag"""
+    from emoportraits_amd import ops
+    v = ops.tile_variant(tile=(4, 8, 8), units_per_block=24, lds_kib=96, threads=512)
+    assert (v & 15, (v >> 4) & 15, (v >> 8) & 15) == (2, 3, 3)
+    assert (v >> 12) & 31 == 24 and (v >> 17) & 255 == 96 and (v >> 25) & 1 == 1
+    assert v < ops.TILE and ops.tile_variant() == 0
+    assert (ops.tile_variant(tile=(16, 4, 4)) >> 25) & 1 == 0
+
+
+def test_planner_quantisation_term():
+    """blocks / CU rounding: 640 blocks occupy 2.5 of 3 rounds; exact multiples and sub-machine launches are not penalised"""
+    assert pack._quantisation(640) == pytest.approx(2.5 / 3)
+    assert pack._quantisation(1280) == 1.0 and pack._quantisation(256) == 1.0 and pack._quantisation(100) == 1.0
+    assert pack._quantisation(257) == pytest.approx(257 / 512)
+    # batch-2 320 -> 320 at 128^2: the planner leaves the 640-block tiling (measured 113 TF) for the 1280-block one (130 TF)
+    allowed = (pack.CFG_A, pack.CFG_B, pack.CFG_C, pack.CFG_D)
+    cfg, ks = pack.plan_launch(320, 320, 1, 3, 3, 2 * 128 * 128 // 128, allowed)
+    assert (-(-320 // pack._BM[cfg])) * (2 * 128 * 128 // pack._BP[cfg]) * ks % 256 == 0
