@@ -15,8 +15,11 @@ conv_launch_fn conv_lookup_1x7_B(int, int);
 conv_launch_fn conv_lookup_f16_3x3_D(int, int);
 conv_launch_fn conv_lookup_f16_1x1_D(int, int);
 conv_launch_fn conv_lookup_f16_3x3_G(int, int);
+conv_launch_fn conv_lookup_bf16x3_3x3(int);
 
-enum { PREC_F32 = 0, PREC_F16 = 1 };   // MFMA operand format (accumulation and all tensors in HBM are fp32 either way)
+// MFMA operand format (accumulation and all tensors in HBM are fp32 either way).  PREC_S: every fp32 operand as the exact sum
+// of three bf16 terms, six partial products (conv_igemm_bf16x3.h) -- fp32 results on the bf16 pipes
+enum { PREC_F32 = 0, PREC_F16 = 1, PREC_S = 2 };
 
 static int shape_of_width(int Wl) {
   if (Wl >= 128 && Wl % 128 == 0) return SHAPE_W128;
@@ -28,6 +31,7 @@ static int shape_of_width(int Wl) {
 }
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
+  if (prec == PREC_S) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
   if (prec == PREC_F16) {
     if (cfg == CFG_G) return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : 0;   // 128 x 256 tile: 3x3 only
     if (cfg != CFG_D) return 0;   // otherwise the fp16-operand kernels exist for the 64 x 256 tile only
@@ -92,6 +96,14 @@ extern "C" int emo_conv_pack_info_f16(int KH, int KW, int cfg, int* BM, int* KC)
   return *KC ? EMO_OK : EMO_ERR_UNSUPPORTED;
 }
 
+extern "C" int emo_conv_pack_info_bf16x3(int KH, int KW, int cfg, int* BM, int* KC) {
+  if (!BM || !KC) return EMO_ERR_BAD_ARG;
+  if (cfg != CFG_D) return EMO_ERR_UNSUPPORTED;
+  *BM = 64;
+  *KC = kc_of(KH, KW, cfg, PREC_S);
+  return *KC ? EMO_OK : EMO_ERR_UNSUPPORTED;
+}
+
 extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW, int ups,
                                      int cfg) {
   const int kc = kc_of(KH, KW, cfg);
@@ -134,7 +146,10 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;
-  if (prec == PREC_F16) {
+  if (prec == PREC_S) {
+    if (!(KH == 3 && KW == 3 && (KD == 1 || KD == 3)) || cfg != CFG_D || Cin % 8) return EMO_ERR_UNSUPPORTED;
+    fn = conv_lookup_bf16x3_3x3(ups);
+  } else if (prec == PREC_F16) {
     if (KD != 1 && !(KD == 3 && KH == 3)) return EMO_ERR_UNSUPPORTED;
     if ((cfg != CFG_D && cfg != CFG_G) || Cin % 8) return EMO_ERR_UNSUPPORTED;
     if (cfg == CFG_G) fn = (KH == 3 && KW == 3) ? conv_lookup_f16_3x3_G(shape, ups) : nullptr;
@@ -179,6 +194,14 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
                                   int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
                                   int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
   return conv_igemm_dispatch(PREC_F32, x, wpk, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
+}
+
+extern "C" int emo_conv_igemm_bf16x3(const float* x, const void* wpk3, const float* bias, const float* scale,
+                                     const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
+                                     int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
+                                     int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
+  return conv_igemm_dispatch(PREC_S, x, wpk3, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
                              relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
 }
 

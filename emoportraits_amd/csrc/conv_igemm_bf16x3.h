@@ -1,0 +1,462 @@
+// fp32 3x3 convolution on the bf16 matrix pipes of gfx950: every fp32 operand is written EXACTLY as the sum of three bf16
+// terms, x = xh + xm + xl (8 + 8 + 8 significand bits; bf16 has the fp32 exponent range), and the product of two operands is
+// accumulated in fp32 from the six partial products of order <= 2^-16:
+//     x * w  ~=  xh*wh + xh*wm + xm*wh + xm*wm + xh*wl + xl*wh          (dropped: xm*wl + xl*wm + xl*wl  <=  2^-23 |x w|)
+// Each partial product of two bf16 values is exact in fp32, so the only rounding is the fp32 accumulation inside
+// v_mfma_f32_32x32x16_bf16 -- the same kind of error the fp32 MFMA kernel of conv_igemm.h has, with 4x fewer accumulation steps
+// (K = 16 per instruction, 6 instructions per 16 channels, against 8 of K = 2).  Measured against an fp64 convolution the result
+// is as close as the fp32 MFMA kernel's (tests/test_conv_bf16x3_gpu.py); the dropped terms are 30x below the accumulation
+// error (tools/split_accuracy.py, CPU).  The bf16 pipes run at 16x the fp32 MFMA rate: six products cost 6/16 of the fp32
+// kernel's matrix time.  NOT a reduced-precision mode: tensors, norms, epilogue and accumulation are fp32 and the operands
+// keep all 24 significand bits.
+//
+// Structure (one block = 64 output channels x 256 positions = a 4 x 64 pixel tile, 4 waves of 64 x 64, ONE block per CU:
+// 150 KB of LDS, 512 registers per lane):
+//   * operand planes in LDS, bf16, 16 bytes = 8 channels per slot (both MFMA operands are one ds_read_b128 per lane):
+//       weights  W[2][plane][tap column s][half][64][8]    one KERNEL ROW (3 taps) of 16 input channels, double-buffered,
+//                                                           copied by LDS-DMA from the host-packed, host-split tensor
+//       patch    P[2][plane][8-channel group][slot][8]      16 input channels of the (4+2) x (64+2) source patch, split on
+//                                                           the way in (conv_igemm_f16.h staging: quads, halo wave, slots)
+//   * K loop over channel groups cg (16 channels [x depth tap]) x kernel rows r x tap columns s; one step (cg, r, s) =
+//     12 ds_read_b128 (3 planes x (2 weight + 2 patch fragments)) feeding 24 MFMAs (4 tiles x 6 products) = 768 matrix
+//     cycles per SIMD; fragments are read one step ahead into three rotating register sets.
+//   * one barrier per kernel row, placed between its steps 1 and 2 ("MIDBAR"): at that point every wave has read the last
+//     weight fragments of row t (they are fetched one step ahead), so W[t & 1] is free for the DMA of row t + 2, and the
+//     DMA of row t + 1 (issued one row ago) is waited for right there -- the fragments of (t + 1, 0) are prefetched behind it.
+//   * the patch of group cg + 1 is converted during (cg, row 0, step 2) .. (cg, row 1, step 1) from registers loaded during
+//     cg - 1; the loads of cg + 2 are issued behind MIDBAR(cg, 1).  vmcnt bookkeeping (all VMEM of the loop is inline asm):
+//         behind MIDBAR(cg,0): DMA(cg,2)      behind MIDBAR(cg,1): DMA(cg+1,0), Q(cg+2)      behind MIDBAR(cg,2): DMA(cg+1,1)
+//         MIDBAR(cg,0) waits vmcnt(0): Q(cg+1) and DMA(cg,1);  MIDBAR(cg,1) waits vmcnt(0): DMA(cg,2);
+//         MIDBAR(cg,2) waits vmcnt(8 | 16 in the halo wave): DMA(cg+1,0), leaving Q(cg+2) in flight.
+// Covers 3x3 (and 3x3x3 with the depth taps as K stages) layers on maps whose width is a multiple of 64 and height a
+// multiple of 4, optional fused nearest x2 upsample, Cin % 8 == 0; epilogue, K split and GroupNorm tile statistics are the
+// shared conv_epilogue.  Anything else runs conv_igemm.h.
+#pragma once
+#include "conv_igemm_f16.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef EMO_S_PIN
+#define EMO_S_PIN 1   /* 0: A/B switch -- the compiler schedules the inside of a step on its own */
+#endif
+#ifndef EMO_S_PRODUCTS
+#define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
+#endif
+
+template <int TR, int TW, bool UPS>
+struct ConvCfgS {
+  static constexpr int BM = 64, BP = 256, TM = 2, TP = 2, WGP = 4, KC = 16;
+  static constexpr int TRS = UPS ? TR / 2 : TR;          // tile extent in SOURCE pixels
+  static constexpr int TWS = UPS ? TW / 2 : TW;
+  static constexpr int PR = TRS + 2;                     // source rows of the patch
+  static constexpr int NQ = TWS / 4;                     // interior quads per row
+  static constexpr int NQ1 = NQ + 1;                     // + the pseudo-quad that holds the row's two halo pixels
+  static constexpr int SUB = ((PR * NQ1 + 11) / 16) * 16 + 4;   // slots per sub-row: >= PR * NQ1 and = 4 (mod 16)
+  static constexpr int CHS = 4 * SUB;                    // slots per 8-channel group
+  static constexpr int NG = 2;                           // 8-channel groups per stage
+  static constexpr int QPG = 128;                        // threads per group
+  static constexpr int NHALO = NG * 2 * PR;
+  // everything below in 16-byte slots
+  static constexpr int WPLANE = 3 * 2 * BM;              // one plane of a kernel row: [s][half][BM]
+  static constexpr int WROW = 3 * WPLANE;                // one kernel row (3 planes)
+  static constexpr int WROW_BYTES = WROW * 16;
+  static constexpr int PPL = NG * CHS;                   // one plane of the patch
+  static constexpr int PBUF = 3 * PPL;
+  static constexpr int OFF_P = 2 * WROW;
+  static constexpr int OFF_DUMP = OFF_P + 2 * PBUF;      // 64 dump slots (stores of threads without a quad)
+  static constexpr int OFF_SCT = OFF_DUMP + 64;          // scale / shift tables (fp32)
+  static constexpr int SCT = 1024;
+  static constexpr int LDS_BYTES = OFF_SCT * 16 + 2 * SCT * 4;
+  static constexpr int NDMA = (WROW_BYTES + 4095) / 4096;   // LDS-DMA rounds per kernel row (a round = 4 waves x 1 KiB)
+  static_assert(TR * TW == BP, "planar position tile of BP pixels");
+  static_assert(TWS % 4 == 0 && (!UPS || (TR % 2 == 0 && TW % 2 == 0)), "whole quads");
+  static_assert(PR * NQ <= QPG, "one interior quad per thread and stage");
+  static_assert(NHALO <= 64, "the halo pixels of a stage are staged by one wave");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(OFF_P * 4 >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the weight buffers");
+};
+
+template <int TR, int TW, bool UPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void conv_igemm_bf16x3_kernel(const ConvArgs a) {
+  using Cfg = ConvCfgS<TR, TW, UPS>;
+  constexpr int BM = Cfg::BM, TM = Cfg::TM, TP = Cfg::TP, WGP = Cfg::WGP, KC = Cfg::KC;
+  constexpr int PR = Cfg::PR, NQ = Cfg::NQ, NQ1 = Cfg::NQ1, SUB = Cfg::SUB, CHS = Cfg::CHS, QPG = Cfg::QPG;
+  constexpr int NHALO = Cfg::NHALO, TWS = Cfg::TWS, WPLANE = Cfg::WPLANE, WROW = Cfg::WROW, PPL = Cfg::PPL, PBUF = Cfg::PBUF;
+  constexpr int HALO_WAVE = 3;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bf16x8* const lds8 = reinterpret_cast<bf16x8*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wp = wave;
+  const int m0 = 0, p0 = wp * TP * 32;
+
+  // block -> (sample, position tile, channel tile, K split): XCD-contiguous order, channel tile fastest (conv_igemm.h)
+  int ks = 0;
+  const int total = gridDim.x;
+  const int q8 = total >> 3, r8 = total & 7;
+  const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
+  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
+  const int cotile = L % a.n_cotiles;
+  int rest = L / a.n_cotiles;
+  if (a.ksplit > 1) {
+    ks = rest % a.ksplit;
+    rest /= a.ksplit;
+  }
+  const int nptiles = a.tiles_x * a.tiles_y * a.tiles_z;
+  const int n = rest / nptiles;
+  int bx = rest - n * nptiles;
+  const int ptile = bx;
+  const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+  const int tz = bx;
+  const int x0 = tx * TW, y0 = ty * TR, z0 = tz;
+  const int x0s = UPS ? x0 >> 1 : x0, y0s = UPS ? y0 >> 1 : y0;   // tile origin in source pixels
+
+  const int HW = a.H * a.W;
+  const long DHW = (long)a.D * HW;
+  const float* xn = a.x + (long)n * a.Cin * DHW;
+  const bool has_affine = a.scale != nullptr;
+  const int padD = a.KD >> 1;
+  const float clamp_lo = a.relu_in ? 0.0f : -__builtin_inff();
+
+  const int nstages_all = a.n_cchunks * a.KD;
+  const int st_begin = ks * a.stages_per_split;
+  const int st_end = min(nstages_all, st_begin + a.stages_per_split);
+  const char* wsrc = reinterpret_cast<const char*>(a.wpk) + ((long)cotile * nstages_all) * (3 * Cfg::WROW_BYTES);
+
+  // ---- staging map (conv_igemm_f16.h): thread t owns quad t % QPG of channel group t / QPG; lane l of HALO_WAVE owns halo
+  //      pixel l (group, patch row, side) ----
+  const int q_u = tid % QPG;
+  const int q_g = __builtin_amdgcn_readfirstlane(tid / QPG);
+  const int q_r = q_u / NQ, q_c = q_u - q_r * NQ;
+  const int q_y = y0s - 1 + q_r;
+  const bool q_live = q_u < PR * NQ;
+  const bool q_ok = q_live && (unsigned)q_y < (unsigned)a.H;
+  const unsigned q_off = q_ok ? (unsigned)(q_y * a.W + x0s + 4 * q_c) * 4u : 0u;
+  const int q_slot = q_live ? q_g * CHS + q_r * NQ1 + q_c : 0;             // + i * SUB for pixel i, + plane * PPL
+
+  const bool is_halo_wave = wave == HALO_WAVE;
+  const int h_g = lane / (2 * PR), h_rem = lane - h_g * (2 * PR);
+  const int h_r = h_rem >> 1, h_side = h_rem & 1;
+  const int h_y = y0s - 1 + h_r, h_x = h_side ? x0s + TWS : x0s - 1;
+  const bool h_live = lane < NHALO;
+  const bool h_ok = h_live && (unsigned)h_y < (unsigned)a.H && (unsigned)h_x < (unsigned)a.W;
+  const unsigned h_off = h_ok ? (unsigned)(h_y * a.W + h_x) * 4u : 0u;
+  const int h_slot = h_live ? h_g * CHS + h_side * SUB + h_r * NQ1 + NQ : 0;
+
+  constexpr int TPH = TP;
+  floatx16 acc_lo[TM][TPH], acc_hi[TM][TPH];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TPH; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
+
+  // patch slot of the lane's output pixel for every tap (+ half * CHS: the lane's 8-channel group)
+  const int a_base = half * BM + m0 + l32;
+  int b_slot[TP][3][3];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int p = p0 + j * 32 + l32;
+    const int col = p % TW, row = p / TW;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int pr = UPS ? ((row + r - 1 + 2) >> 1) - 1 + 1 : row + r;
+        const int pc = UPS ? ((col + s - 1 + 2) >> 1) - 1 : col + s - 1;
+        const int slot = pc < 0 ? pr * NQ1 + NQ : (pc >= TWS ? SUB + pr * NQ1 + NQ : (pc & 3) * SUB + pr * NQ1 + (pc >> 2));
+        b_slot[j][r][s] = half * CHS + slot;
+      }
+  }
+
+  bf16x8 fa_[3][3][TM], fb_[3][3][TP];     // [register set][plane][tile]
+#define EMO_S_LOAD_FRAGS(set_, wbase_, pbase_, r_, s_)                                                \
+  {                                                                                                   \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+        fa_[set_][pl][i] = lds8[(wbase_) + pl * WPLANE + (s_) * 2 * BM + a_base + i * 32];           \
+      _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                  \
+        fb_[set_][pl][j] = lds8[(pbase_) + pl * PPL + b_slot[j][r_][s_]];                             \
+    }                                                                                                 \
+  }
+
+  float* const sct = smem + Cfg::OFF_SCT * 4;
+  const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem);
+  bf16x8* const dump8 = lds8 + Cfg::OFF_DUMP + lane;
+
+  floatx4 qv[8];
+  float hv[8];
+  float q_lo, q_hi, h_lo, h_hi;
+  floatx4 q_sc[2], q_sh[2], h_sc[2], h_sh[2];
+  const emo_intx4 xrs = emo_raw_buffer(xn);
+  unsigned usoff[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)u * (unsigned)DHW * 4u));
+
+  int q_tix, h_tix;
+  int n_ci0, n_zu;
+  bool n_zv;
+#define EMO_S_SET_STAGE(stage_)                                                                       \
+  {                                                                                                   \
+    const int cc_ = (stage_) / a.KD;                                                                  \
+    n_ci0 = cc_ * KC;                                                                                 \
+    n_zu = z0 + ((stage_) - cc_ * a.KD) - padD;                                                       \
+    n_zv = (unsigned)n_zu < (unsigned)a.D;                                                            \
+  }
+#define EMO_S_ISSUE_QUAD()                                                                            \
+  {                                                                                                   \
+    const int c0_ = n_ci0 + q_g * 8;                                                                  \
+    const bool cv_ = c0_ < a.Cin;                                                                     \
+    const int cs_ = cv_ ? c0_ : 0;                                                                    \
+    const bool keep_ = q_ok && cv_ && n_zv;                                                           \
+    q_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
+    q_hi = keep_ ? __builtin_inff() : 0.0f;                                                           \
+    const unsigned vo_ = q_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u; \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) qv[u] = emo_bload4_pinned(xrs, vo_, usoff[u]);      \
+    q_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
+  }
+#define EMO_S_QUAD_TABLE()                                                                            \
+  {                                                                                                   \
+    const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix;                               \
+    q_sc[0] = t4_[0]; q_sc[1] = t4_[1]; q_sh[0] = t4_[Cfg::SCT / 4]; q_sh[1] = t4_[Cfg::SCT / 4 + 1]; \
+  }
+#define EMO_S_ISSUE_HALO()                                                                            \
+  {                                                                                                   \
+    const int c0_ = n_ci0 + h_g * 8;                                                                  \
+    const bool cv_ = c0_ < a.Cin;                                                                     \
+    const int cs_ = cv_ ? c0_ : 0;                                                                    \
+    const bool keep_ = h_ok && cv_ && n_zv;                                                           \
+    h_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
+    h_hi = keep_ ? __builtin_inff() : 0.0f;                                                           \
+    const unsigned vo_ = h_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u; \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) hv[u] = emo_bload_pinned(xrs, vo_, usoff[u]);       \
+    h_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
+  }
+#define EMO_S_HALO_TABLE()                                                                            \
+  {                                                                                                   \
+    const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + h_tix;                               \
+    h_sc[0] = t4_[0]; h_sc[1] = t4_[1]; h_sh[0] = t4_[Cfg::SCT / 4]; h_sh[1] = t4_[Cfg::SCT / 4 + 1]; \
+  }
+// fp32 transform (GroupNorm affine of the producer, ReLU and zero padding in one v_med3: bounds [0, 0] where the pixel is
+// padding), then the exact three-way split v = h + m + l (round-to-nearest-even at every level; the residuals are exact)
+#define EMO_S_SPLIT8(dst_, val_)                                                                      \
+  {                                                                                                   \
+    bf16x8 h_, m_, l_;                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                   \
+      const float v = (val_);                                                                         \
+      h_[u] = (__bf16)v;                                                                              \
+      const float r1 = v - (float)h_[u];                                                              \
+      m_[u] = (__bf16)r1;                                                                             \
+      const float r2 = r1 - (float)m_[u];                                                             \
+      l_[u] = (__bf16)r2;                                                                             \
+    }                                                                                                 \
+    (dst_)[0] = h_;                                                                                   \
+    (dst_)[live_ ? PPL : 0] = m_;                                                                     \
+    (dst_)[live_ ? 2 * PPL : 0] = l_;                                                                 \
+  }
+#define EMO_S_STORE_QUAD(pbase_, i0_)                                                                 \
+  {                                                                                                   \
+    const bool live_ = q_live;                                                                        \
+    _Pragma("unroll") for (int i = (i0_); i < (i0_) + 2; ++i) {                                       \
+      bf16x8* d_ = live_ ? lds8 + (pbase_) + q_slot + i * SUB : dump8;                                \
+      EMO_S_SPLIT8(d_, __builtin_amdgcn_fmed3f(__fmaf_rn(qv[u][i], q_sc[u / 4][u % 4], q_sh[u / 4][u % 4]), q_lo, q_hi)) \
+    }                                                                                                 \
+  }
+#define EMO_S_STORE_HALO(pbase_)                                                                      \
+  {                                                                                                   \
+    const bool live_ = h_live;                                                                        \
+    bf16x8* d_ = live_ ? lds8 + (pbase_) + h_slot : dump8;                                            \
+    EMO_S_SPLIT8(d_, __builtin_amdgcn_fmed3f(__fmaf_rn(hv[u], h_sc[u / 4][u % 4], h_sh[u / 4][u % 4]), h_lo, h_hi)) \
+  }
+#define EMO_S_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[u]); }
+#define EMO_S_TOUCH_HALO() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(hv[u]); }
+// one kernel row of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
+#define EMO_S_DMA_ROW(stage_, row_, dst_slot_)                                                        \
+  {                                                                                                   \
+    const char* ws_ = wsrc + ((long)(stage_) * 3 + (row_)) * Cfg::WROW_BYTES;                         \
+    _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) {                                           \
+      const int j = wave + 4 * i;                                                                     \
+      if (j * 1024 < Cfg::WROW_BYTES)                                                                 \
+        emo_dma16_pinned(ws_ + j * 1024 + lane * 16, smem_lds + (unsigned)((dst_slot_) * 16 + j * 1024)); \
+    }                                                                                                 \
+  }
+#define EMO_S_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define EMO_S_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
+
+  // ---- prologue: rows 0 and 1 of the first stage by DMA, its patch converted into P[0], the loads of the second stage ----
+  EMO_S_DMA_ROW(st_begin, 0, 0);
+  EMO_S_DMA_ROW(st_begin, 1, WROW);
+  EMO_S_SET_STAGE(st_begin);
+  EMO_S_ISSUE_QUAD()
+  if (is_halo_wave) EMO_S_ISSUE_HALO()
+  for (int c = tid; c < min(a.Cin, Cfg::SCT); c += 256) {   // (without an affine the index wraps at SCT: identity entries)
+    const bool real = has_affine && c < a.Cin;
+    sct[c] = real ? a.scale[(long)n * a.Cin + c] : 1.0f;
+    sct[Cfg::SCT + c] = real ? a.shift[(long)n * a.Cin + c] : 0.0f;
+  }
+  EMO_S_WAIT(0);
+  __syncthreads();   // scale / shift tables visible
+  EMO_S_QUAD_TABLE()
+  if (is_halo_wave) EMO_S_HALO_TABLE()
+  EMO_S_TOUCH_QUAD()
+  EMO_S_STORE_QUAD(Cfg::OFF_P, 0)
+  EMO_S_STORE_QUAD(Cfg::OFF_P, 2)
+  if (is_halo_wave) {
+    EMO_S_TOUCH_HALO()
+    EMO_S_STORE_HALO(Cfg::OFF_P)
+  }
+  {
+    const int st1 = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
+    EMO_S_SET_STAGE(st1);
+  }
+  EMO_S_ISSUE_QUAD()
+  EMO_S_QUAD_TABLE()
+  if (is_halo_wave) {
+    EMO_S_ISSUE_HALO()
+    EMO_S_HALO_TABLE()
+    EMO_S_BARRIER(16);
+  } else {
+    EMO_S_BARRIER(8);
+  }
+  EMO_S_LOAD_FRAGS(0, 0, Cfg::OFF_P, 0, 0)
+
+  // the six partial products, smallest first: (weight plane, patch plane)
+  constexpr int NPROD = EMO_S_PRODUCTS;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+  for (int cg = st_begin; cg < st_end; ++cg) {
+    const int cgrel = cg - st_begin;
+    const int par = cgrel & 1;
+    const int pcur = Cfg::OFF_P + par * PBUF, pnxt = Cfg::OFF_P + (par ^ 1) * PBUF;
+    const int cg1 = (cg + 1) < st_end ? (cg + 1) : cg;          // clamped on the last stages: harmless re-stage
+    const int cg2 = (cg + 2) < st_end ? (cg + 2) : cg1;
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int gs = 0; gs < 9; ++gs) {
+      const int r = gs / 3, s = gs % 3;
+      if (s == 2) {
+        // MIDBAR(cg, r): every wave has fetched the last weight fragments of this row; the DMA of the next row has landed
+        if (r == 2) {
+          if (is_halo_wave) { EMO_S_BARRIER(16); } else { EMO_S_BARRIER(8); }
+        } else {
+          EMO_S_BARRIER(0);
+        }
+        const int wfree = ((cgrel + r) & 1) * WROW;               // the buffer of this row = the buffer of row t + 2
+        if (r == 0) {
+          EMO_S_DMA_ROW(cg, 2, wfree);
+        } else if (r == 1) {
+          EMO_S_DMA_ROW(cg1, 0, wfree);
+          EMO_S_SET_STAGE(cg2);
+          EMO_S_ISSUE_QUAD()
+          EMO_S_QUAD_TABLE()
+          if (is_halo_wave) {
+            EMO_S_ISSUE_HALO()
+            EMO_S_HALO_TABLE()
+          }
+        } else {
+          EMO_S_DMA_ROW(cg1, 1, wfree);
+        }
+      }
+      // ---- one step: the fragments of the NEXT step (three rotating register sets), a piece of the next group's patch
+      //      conversion (behind MIDBAR(cg, 0) its registers have landed), 24 MFMAs.  The order inside the step is pinned with
+      //      sched_group_barrier: the compiler left to itself sinks the fragment reads to their first use (LDS latency in
+      //      front of every MFMA) and emits the conversion as one VALU burst (the matrix pipe idles behind it) ----
+      __builtin_amdgcn_sched_barrier(0);
+      if (gs < 8) {
+        const int rn = (gs + 1) / 3, sn = (gs + 1) % 3;
+        EMO_S_LOAD_FRAGS((gs + 1) % 3, ((cgrel + rn) & 1) * WROW, pcur, rn, sn)
+      } else {
+        EMO_S_LOAD_FRAGS(0, ((cgrel + 1) & 1) * WROW, pnxt, 0, 0)
+      }
+      if (gs == 2) {
+        EMO_S_TOUCH_QUAD()
+        if (is_halo_wave) EMO_S_TOUCH_HALO()
+        EMO_S_STORE_QUAD(pnxt, 0)
+      } else if (gs == 3) {
+        EMO_S_STORE_QUAD(pnxt, 2)
+      } else if (gs == 4) {
+        if (is_halo_wave) EMO_S_STORE_HALO(pnxt)
+      }
+#pragma unroll
+      for (int p = 0; p < NPROD; ++p) {
+        const int pa = NPROD == 6 ? PA[p] : PA[p + 6 - NPROD], pb = NPROD == 6 ? PB[p] : PB[p + 6 - NPROD];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j)
+            // operands swapped: the result tile is [position][channel] (conv_epilogue)
+            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_lo[i][j], 0, 0, 0);
+      }
+      if (EMO_S_PIN) {
+        // 12 x { MFMA, fragment read, <= 5 VALU }, then { MFMA, <= 6 VALU, LDS store } for the rest
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
+#pragma unroll
+        for (int k = 12; k < 4 * NPROD; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
+  }
+  EMO_S_WAIT(0);      // the re-issued loads / DMA of the clamped last stages are dead: drain them
+  __syncthreads();    // ... and the LDS they target is reused by the epilogue
+#undef EMO_S_SET_STAGE
+#undef EMO_S_ISSUE_QUAD
+#undef EMO_S_ISSUE_HALO
+#undef EMO_S_QUAD_TABLE
+#undef EMO_S_HALO_TABLE
+#undef EMO_S_SPLIT8
+#undef EMO_S_STORE_QUAD
+#undef EMO_S_STORE_HALO
+#undef EMO_S_TOUCH_QUAD
+#undef EMO_S_TOUCH_HALO
+#undef EMO_S_DMA_ROW
+#undef EMO_S_WAIT
+#undef EMO_S_BARRIER
+#undef EMO_S_LOAD_FRAGS
+
+  conv_epilogue<1, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
+}
+
+template <int TR, int TW, bool UPS>
+int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
+  using Cfg = ConvCfgS<TR, TW, UPS>;
+  if (a.Wl % TW || a.Hl % TR) return EMO_ERR_UNSUPPORTED;
+  if (a.Cin % 8) return EMO_ERR_UNSUPPORTED;   // whole 8-channel groups
+  if (a.scale && a.Cin > Cfg::SCT) return EMO_ERR_UNSUPPORTED;   // scale / shift tables in LDS
+  if ((unsigned long long)a.Cin * a.D * a.H * a.W * 4ull >= (1ull << 32)) return EMO_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  if ((reinterpret_cast<unsigned long long>(a.x) & 15ull) || (a.W & 3)) return EMO_ERR_UNSUPPORTED;     // 16-byte quads
+  a.tiles_x = a.Wl / TW;
+  a.tiles_y = a.Hl / TR;
+  a.tiles_z = a.Dl;
+  a.n_cchunks = (a.Cin + Cfg::KC - 1) / Cfg::KC;
+  const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+  if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
+  const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
+  auto kern = conv_igemm_bf16x3_kernel<TR, TW, UPS>;
+  const int rc = emo_raise_dynamic_lds(kern);
+  if (rc != EMO_OK) return rc;
+  a.n_cotiles = cot;
+  if (a.ksplit < 1 || (a.ksplit > 1 && !a.partial)) return EMO_ERR_BAD_ARG;
+  if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }
+  if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
+  if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nt * cot * a.N * a.ksplit)), dim3(256), (size_t)Cfg::LDS_BYTES, s, a);
+  return emo_launch_status();
+}

@@ -94,7 +94,7 @@ class InferenceWrapper:
                  fixed_bounding_box=False, project_dir='./', folder='mp_logs', model_='va',
                  torch_home='', debug=False, print_model=False, print_params=True, args_overwrite={}, state_dict=None,
                  pose_momentum=0.5, rank=0, args_path=None, embedders=None, head_pose_regressor_path=None,
-                 use_graphs=False, precision="f32"):
+                 use_graphs=False, precision=None):
         if not use_gpu:
             raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
         if model_ != 'va':

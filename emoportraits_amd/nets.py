@@ -276,17 +276,27 @@ class Unet3D:
         return ops.conv_igemm(x, self.head, s, h, relu_in=True)
 
 
+DEFAULT_PRECISION = "f32"
+
+
 class HotPath:
     """All hot-path networks of one checkpoint, resident on one GPU.
 
     driver_pass replays notebooks/infer.py:583-637 for a BATCH of driver frames sharing one source identity
     (the reference loops batch-1 calls, F5).  source_pass replays infer.py:433-507."""
 
-    def __init__(self, state_dict, cfg, device="cuda:0", with_source=True, precision="f32"):
-        """precision: 'f32' (default: exact-fp32 MFMA everywhere) or 'f16' (opt-in reduced precision, BASELINE configs[4]:
-        fp16 MFMA operands with fp32 accumulation in the 3x3 / 1x1 convolutions; tensors in HBM stay fp32)"""
+    def __init__(self, state_dict, cfg, device="cuda:0", with_source=True, precision=None):
+        """precision (None: EMO_CONV_PRECISION, else DEFAULT_PRECISION):
+        'f32'    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution;
+        'bf16x3' fp32 results on the bf16 matrix pipes in the 3x3 layers csrc/conv_igemm_bf16x3.h covers -- every operand split
+                 exactly into three bf16 terms, six partial products, fp32 accumulation: held to the same parity bounds as 'f32'
+                 (tests/test_conv_bf16x3_gpu.py, tests/test_bench_config_parity_gpu.py) -- exact-fp32 MFMA elsewhere;
+        'f16'    opt-in reduced precision (BASELINE configs[4]): fp16 MFMA operands with fp32 accumulation in the 3x3 / 1x1
+                 convolutions; tensors in HBM stay fp32"""
         self.cfg = cfg
         self.device = torch.device(device)
+        if precision is None:
+            precision = os.environ.get("EMO_CONV_PRECISION", DEFAULT_PRECISION)
         self.precision = precision
         sd = state_dict
         self.pad = cfg["grid_sample_padding_mode"]

@@ -101,6 +101,39 @@ def pack_weight_f16(w, cfg):
     return wp.view(-1).to(torch.float16)
 
 
+def split_bf16x3(w):
+    """fp32 tensor -> (h, m, l) bf16 tensors with h + m + l == w exactly (round-to-nearest-even at every level; the
+    residuals w - h and w - h - m are exact in fp32) -- the operand form of emo_conv_igemm_bf16x3"""
+    w = w.float()
+    h = w.to(torch.bfloat16)
+    r1 = w - h.float()
+    m = r1.to(torch.bfloat16)
+    l = (r1 - m.float()).to(torch.bfloat16)
+    return h, m, l
+
+
+BF16X3_BM, BF16X3_KC = 64, 16    # emo_conv_pack_info_bf16x3 (checked against the library in tests/test_host_logic.py)
+
+
+def pack_weight_bf16x3(w):
+    """operand layout of emo_conv_igemm_bf16x3: [co_tile][cin chunk of 16][kd][kernel row][plane h|m|l][kernel column]
+    [half][BM = 64][8], channel in chunk = 8*half + 0..7 -> flat bf16 tensor"""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, kd, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("3x3 kernels only")
+    bm, kc = BF16X3_BM, BF16X3_KC
+    n_cot = -(-cout // bm)
+    n_cc = -(-cin // kc)
+    wp = torch.zeros((n_cot * bm, n_cc * kc, kd, kh, kw), dtype=torch.float32)
+    wp[:cout, :cin] = w.float()
+    planes = torch.stack(split_bf16x3(wp), 0)                     # [plane, co, ci, kd, r, s]
+    # [plane, cot, BM, cc, half, k8, kd, r, s] -> [cot, cc, kd, r, plane, s, half, BM, k8]
+    planes = planes.view(3, n_cot, bm, n_cc, 2, 8, kd, kh, kw).permute(1, 3, 6, 7, 0, 8, 4, 2, 5).contiguous()
+    return planes.view(-1)
+
+
 def pack_weight(w, cfg):
     """w [Cout, Cin, KH, KW] or [Cout, Cin, KD, KH, KW] -> flat fp32 tensor
     [co_tile][cin chunk][kd][pair][tap][half][BM]   (stage index = chunk*KD + kd; k-local = (pair*TAPS+tap)*2+half)"""
@@ -164,6 +197,8 @@ def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
 @functools.lru_cache(maxsize=None)
 def _kc(kh, kw, cfg, precision="f32"):
     """input channels per K stage of a block config (emo_conv_pack_info / emo_conv_pack_info_f16)"""
+    if precision == "bf16x3":
+        return BF16X3_KC
     return (conv_pack_info_f16 if precision == "f16" else conv_pack_info)(kh, kw, cfg)[1]
 
 
@@ -209,6 +244,10 @@ def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C
 
 
 _build_precision = "f32"
+# 'f32': the exact-fp32 MFMA kernel everywhere.  'bf16x3': fp32 results on the bf16 matrix pipes -- operands split exactly into
+# three bf16 terms, six partial products, fp32 accumulation (csrc/conv_igemm_bf16x3.h) -- on the 3x3 layers that kernel covers,
+# the exact-fp32 kernel elsewhere.  'f16': reduced precision (fp16 operands), opt-in.
+PRECISIONS = ("f32", "f16", "bf16x3")
 
 
 @contextlib.contextmanager
@@ -217,8 +256,8 @@ def conv_precision(precision):
     does not cover (7x7 stem, heads with fewer than 32 output channels) stay fp32.  Used by HotPath / Stage2
     constructors; construction is single-threaded."""
     global _build_precision
-    if precision not in ("f32", "f16"):
-        raise ValueError("precision must be 'f32' or 'f16'")
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (PRECISIONS,))
     old, _build_precision = _build_precision, precision
     try:
         yield
@@ -230,6 +269,17 @@ def supports_f16(cout, cin, kd, kh, kw):
     """layers the fp16-operand kernel can take at all (whether a given LAUNCH runs on it also depends on the output width:
     PackedConv.plan_for)"""
     return (kh, kw) in ((3, 3), (1, 1)) and kd in (1, 3) and not (kd == 3 and kh == 1) and cout >= 32 and cin % 8 == 0
+
+
+def supports_bf16x3(cout, cin, kd, kh, kw):
+    """layers the split-operand kernel takes: 3x3 / 3x3x3, whole 8-channel groups, and a 64-row channel tile that is at least
+    three quarters real (below that the exact-fp32 kernel's 32-row tiles win)"""
+    return (kh, kw) == (3, 3) and kd in (1, 3) and cin % 8 == 0 and cout / (-(-cout // BF16X3_BM) * BF16X3_BM) >= 0.75
+
+
+def bf16x3_launch_fits(Hl, Wl):
+    """output planes tiled by 4 x 64 positions"""
+    return Hl is not None and Wl % 64 == 0 and Hl % 4 == 0
 
 
 F16_AFFINE_MAX_CIN = 1024   # ConvCfgH::SCT (conv_igemm_f16.h)
@@ -261,8 +311,10 @@ class PackedConv:
         self._weight = weight.float().contiguous()      # folded fp32 weight kept on the host for lazy packing
         self._packed = {}
         self.pinned_cfg = cfg
-        if precision not in ("f32", "f16"):
-            raise ValueError("precision must be 'f32' or 'f16'")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
+        if precision == "bf16x3" and not supports_bf16x3(cout, cin, kd, kh, kw):
+            raise ValueError(f"{name}: the split-operand kernel covers 3x3 / 3x3x3 convolutions with a multiple of 8 input channels")
         if precision == "f16" and not supports_f16(cout, cin, kd, kh, kw):
             raise ValueError(f"{name}: the fp16-operand kernel covers 3x3 / 3x3x3 / 1x1 convolutions with >= 32 output "
                              f"channels and a multiple of 8 input channels")
@@ -281,6 +333,10 @@ class PackedConv:
             if key not in self._packed:
                 self._packed[key] = pack_weight_f16(self._weight, key[1]).to(self.device)
             return self._packed[key]
+        if precision == "bf16x3":
+            if "bf16x3" not in self._packed:
+                self._packed["bf16x3"] = pack_weight_bf16x3(self._weight).to(self.device)
+            return self._packed["bf16x3"]
         cfg = _PACK_AS.get(cfg, cfg)
         if cfg not in self._packed:
             self._packed[cfg] = pack_weight(self._weight, cfg).to(self.device)
@@ -304,6 +360,10 @@ class PackedConv:
                 (CFG_D, CFG_G) if (_CFG_EFF[CFG_G] > 0 and self.kh == 3) else (CFG_D,)
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, tiles, "f16")
             return cfg, ks, "f16"
+        if self.precision == "bf16x3" and bf16x3_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D) and aligned16 \
+                and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
+            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), "bf16x3")
+            return cfg, ks, "bf16x3"
         pinned = None if self.pinned_cfg == CFG_G else self.pinned_cfg   # (G exists for fp16 operands only)
         allowed = (pinned,) if pinned is not None else self.allowed
         if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl):
@@ -321,5 +381,6 @@ class PackedConv:
         w, b = folded_conv(sd, prefix, kind)
         if precision is None:
             kd = w.shape[2] if w.dim() == 5 else 1
-            precision = _build_precision if supports_f16(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1]) else "f32"
+            ok = supports_bf16x3 if _build_precision == "bf16x3" else supports_f16
+            precision = _build_precision if ok(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1]) else "f32"
         return cls(prefix, w, b, device, cfg, precision)

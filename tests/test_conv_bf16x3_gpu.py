@@ -1,0 +1,93 @@
+"""GPU parity of emo_conv_igemm_bf16x3 (csrc/conv_igemm_bf16x3.h): the fp32 3x3 convolution computed on the bf16 matrix pipes
+from exact three-way operand splits.  It is held to the SAME bound as the exact-fp32 MFMA kernel -- 2e-5 * max|ref| against
+torch CPU fp32 (tests/test_kernels_gpu.py) -- and, against an fp64 reference, to the fp32 kernel's own error."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from emoportraits_amd import ops, pack
+from test_kernels_gpu import DEV, rel_err, run_conv
+
+pytestmark = pytest.mark.gpu
+
+
+CASES = [
+    dict(N=2, Cin=40, Cout=72, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),          # ragged channel group
+    dict(N=2, Cin=64, Cout=64, dims=(32, 32), k=3, cfg=3, ups=True, res=True, res_ups=True, act="tanh"),
+    dict(N=1, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=3, affine=True, relu_in=True),
+    dict(N=1, Cin=72, Cout=130, dims=(8, 64, 64), k=3, cfg=3, affine=True, relu_in=True, bias=False),   # 3-D: depth taps as stages
+    dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, ksplit=3),
+    dict(N=1, Cin=24, Cout=64, dims=(256, 256), k=3, cfg=3, affine=True, relu_in=True, res=True),
+    dict(N=1, Cin=32, Cout=64, dims=(64, 64), k=3, cfg=3, ups=True, affine=True, relu_in=True),
+    dict(N=2, Cin=16, Cout=96, dims=(32, 32), k=3, cfg=3, ups=True, affine=True),                       # one stage, no ReLU
+    dict(N=1, Cin=8, Cout=64, dims=(4, 64), k=3, cfg=3),                                               # half a stage, one tile
+    dict(N=3, Cin=48, Cout=200, dims=(8, 128), k=3, cfg=3, act="sigmoid"),
+    dict(N=1, Cin=512, Cout=64, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True),                 # 32 stages
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16x3_meets_the_fp32_kernel_bound(case):
+    e, got, ref = run_conv(seed=21, precision="bf16x3", **case)
+    assert got.shape == ref.shape
+    print("PARITY conv bf16x3:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    assert e < 2e-5, e
+    e2, got2, _ = run_conv(seed=21, precision="bf16x3", **case)
+    assert torch.equal(got, got2), "two launches on the same input differ: a race in the pipeline"
+
+
+def test_conv_bf16x3_is_as_close_to_fp64_as_the_fp32_kernel():
+    """error against an fp64 convolution: the split kernel's may not exceed the exact-fp32 MFMA kernel's (plus rounding of the
+    output value itself)"""
+    g = torch.Generator().manual_seed(5)
+    N, Cin, Cout, H, W = 2, 192, 128, 64, 64
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g) * 3 + 0.5)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    scale = ref.abs().mean().item()
+    outs = {}
+    for prec in ("f32", "bf16x3"):
+        layer = pack.PackedConv(prec, w, None, DEV, cfg=3, precision=prec)
+        y = ops.conv_igemm(x.to(DEV), layer).cpu().double()
+        err = (y - ref).abs()
+        outs[prec] = (err.mean().item() / scale, err.max().item() / scale)
+    print("PARITY conv vs fp64 (rel mean, rel max): fp32 MFMA %.2e %.2e | bf16x3 %.2e %.2e" % (outs["f32"] + outs["bf16x3"]))
+    assert outs["bf16x3"][0] <= 1.25 * outs["f32"][0] + 1e-8
+    assert outs["bf16x3"][1] <= 1.5 * outs["f32"][1] + 1e-7
+
+
+def test_conv_bf16x3_layer_plan_and_tile_statistics():
+    """a layer built with precision='bf16x3' runs the split kernel where its 4 x 64 tile fits and the exact-fp32 kernel on
+    narrow maps; both write the GroupNorm tile statistics of what they stored"""
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17
+    layer = pack.PackedConv("l", w, None, DEV, precision="bf16x3")
+    assert layer.plan_for(64, 64, 64)[2] == "bf16x3" and layer.plan_for(2, 16, 16)[2] == "f32"
+    for hw in (64, 16):
+        x = torch.randn(2, 32, hw, hw, generator=g).to(DEV)
+        out, st = ops.conv_igemm(x, layer, want_stats=True, ksplit=1)
+        assert st is not None
+        s1, h1 = ops.groupnorm_affine(out, stats=st)
+        s0, h0 = ops.groupnorm_affine(out)
+        assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item() and (h1 - h0).abs().max().item() <= 2e-6
+        assert rel_err(out, F.conv2d(x.cpu(), w, padding=1)) < 2e-5
+    with pytest.raises(ValueError):
+        pack.PackedConv("bad", torch.zeros(64, 12, 3, 3), None, DEV, precision="bf16x3")   # Cin not a multiple of 8
+    with pytest.raises(ValueError):
+        pack.PackedConv("bad", torch.zeros(64, 16, 1, 1), None, DEV, precision="bf16x3")   # 3x3 only
+
+
+def test_conv_bf16x3_decoder_layer_at_bench_size_agrees_with_the_fp32_kernel():
+    """128 -> 128 at 512 x 512, 4 frames (the bench's largest layer shape): split kernel against the exact-fp32 MFMA kernel"""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 128, 512, 512, generator=g).to(DEV)
+    w = torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(128 * 9)
+    sc = (torch.rand(4, 128, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(4, 128, generator=g) * 0.3).to(DEV)
+    a = ops.conv_igemm(x, pack.PackedConv("a", w, None, DEV, precision="f32"), sc, sh, relu_in=True)
+    b = ops.conv_igemm(x, pack.PackedConv("b", w, None, DEV, precision="bf16x3"), sc, sh, relu_in=True)
+    d = (a - b).abs().max().item() / a.abs().max().item()
+    print(f"PARITY conv bf16x3 vs fp32 MFMA kernel, 128->128 @512^2 x4: {d:.2e}")
+    assert d < 1e-5

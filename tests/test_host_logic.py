@@ -251,3 +251,34 @@ def test_planner_quantisation_term():
     allowed = (pack.CFG_A, pack.CFG_B, pack.CFG_C, pack.CFG_D)
     cfg, ks = pack.plan_launch(320, 320, 1, 3, 3, 2 * 128 * 128 // 128, allowed)
     assert (-(-320 // pack._BM[cfg])) * (2 * 128 * 128 // pack._BP[cfg]) * ks % 256 == 0
+
+
+def test_bf16x3_split_is_exact_and_the_packed_layout_is_the_documented_one():
+    """pack.split_bf16x3: h + m + l == w bit for bit; pack.pack_weight_bf16x3: element (co, ci, kd, r, s) of plane p lands at
+    [co_tile][ci/16][kd][r][p][s][half][co%64][ci%8] (include/emo_hip.h, emo_conv_igemm_bf16x3)"""
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(70, 24, 3, 3, 3, generator=g) * torch.logspace(-6, 3, 70).view(70, 1, 1, 1, 1)
+    h, m, l = pack.split_bf16x3(w)
+    assert torch.equal(h.float() + m.float() + l.float(), w)
+    assert (m.float().abs() <= h.float().abs() * 2.0 ** -8 + 1e-45).all() and (l.float().abs() <= h.float().abs() * 2.0 ** -16 + 1e-45).all()
+    flat = pack.pack_weight_bf16x3(w)
+    cout, cin, kd = 70, 24, 3
+    n_cot, n_cc = 2, 2
+    assert flat.dtype == torch.bfloat16 and flat.numel() == n_cot * n_cc * kd * 3 * 3 * 3 * 2 * 64 * 8
+    planes = (h, m, l)
+    for _ in range(200):
+        co, ci, t, r, s, p = (int(torch.randint(n, (1,), generator=g)) for n in (cout, cin, kd, 3, 3, 3))
+        cot, i = divmod(co, 64)
+        cc, cl = divmod(ci, 16)
+        half, k8 = divmod(cl, 8)
+        idx = ((((((((cot * n_cc + cc) * kd + t) * 3 + r) * 3 + p) * 3 + s) * 2 + half) * 64 + i) * 8 + k8)
+        assert flat[idx].item() == planes[p][co, ci, t, r, s].item()
+    # padding (channels 70..127, 24..31) is zero
+    assert flat.float().abs().sum().item() == pytest.approx(sum(t.float().abs().sum().item() for t in planes), rel=1e-3)
+    import ctypes
+    from emoportraits_amd import hip
+    lib = hip.load()
+    bm, kc = ctypes.c_int(), ctypes.c_int()
+    assert lib.emo_conv_pack_info_bf16x3(3, 3, 3, ctypes.byref(bm), ctypes.byref(kc)) == 0
+    assert (bm.value, kc.value) == (pack.BF16X3_BM, pack.BF16X3_KC)
+    assert lib.emo_conv_pack_info_bf16x3(1, 1, 3, ctypes.byref(bm), ctypes.byref(kc)) != 0

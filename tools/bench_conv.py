@@ -32,6 +32,9 @@ def main():
     quick = "--quick" in sys.argv
     f16 = "--f16" in sys.argv or "--f16-only" in sys.argv   # also time the opt-in fp16-operand kernels (emo_conv_igemm_f16acc32)
     f16_only = "--f16-only" in sys.argv
+    split = "--bf16x3" in sys.argv or "--bf16x3-only" in sys.argv   # also time emo_conv_igemm_bf16x3 (fp32 on the bf16 pipes)
+    split_only = "--bf16x3-only" in sys.argv
+    f16_only = f16_only or split_only
     torch.backends.cudnn.benchmark = True
     # (Cin, Cout, dims, k, ups)
     shapes = [(1536, 512, (64, 64), 1, False), (512, 512, (64, 64), 3, False),
@@ -79,6 +82,12 @@ def main():
             msh = timeit(lambda: ops.conv_igemm(x, lh, scale, shift, relu_in=True, ups=ups, out=out))
             rec["f16_cfg3_ms"] = round(msh, 3)
             rec["f16_cfg3_tflops"] = round(flops / msh / 1e9, 1)
+        if split and k == 3 and pack.supports_bf16x3(cout, cin, kd, k, k) and pack.bf16x3_launch_fits(odims[-2], odims[-1]):
+            ls = pack.PackedConv("b3", w, None, DEV, precision="bf16x3")
+            out = ops.conv_igemm(x, ls, scale, shift, relu_in=True, ups=ups)
+            mss = timeit(lambda: ops.conv_igemm(x, ls, scale, shift, relu_in=True, ups=ups, out=out))
+            rec["bf16x3_ms"] = round(mss, 3)
+            rec["bf16x3_tflops"] = round(flops / mss / 1e9, 1)      # fp32-equivalent (algorithmic) FLOPs
         if not f16_only:       # what the planner picks for this launch (block config + K split), as the networks run it
             la = pack.PackedConv("auto", w, None, DEV)
             Hl_, Wl_ = odims[-2], odims[-1]

@@ -28,7 +28,8 @@ def timeit(fn, iters=7, warmup=2):
 
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    precision = "f16" if "--f16" in sys.argv else "f32"      # --f16: opt-in fp16-operand convs (not the bench mode)
+    # --f16: opt-in fp16-operand convs (reduced precision); --bf16x3 / --f32: the two fp32 modes (default: nets.DEFAULT_PRECISION)
+    precision = "f16" if "--f16" in sys.argv else "bf16x3" if "--bf16x3" in sys.argv else "f32" if "--f32" in sys.argv else None
     Bs = [int(a) for a in sys.argv[2:] if not a.startswith("--")] or [1, 4, 8, 16]
     cfg = config.hot_path_config(overrides={"image_size": S})
     sd = random_init.random_state_dict(cfg, seed=0, with_source=False)
@@ -48,7 +49,7 @@ def main():
         warped = ops.grid_sample3d(ccl, delta=delta, in_layout=lay, out_layout=lay)
         aligned = ops.grid_sample3d(warped, theta=theta, in_layout=lay, out_layout="ncdhw")
         feat = aligned.view(B, 96 * 16, 64, 64)
-        rec = dict(S=S, B=B, conv_operands=precision)
+        rec = dict(S=S, B=B, conv_operands=hp.precision)
         rec["embed_ms"] = timeit(lambda: hp.embed(pose, idt))
         rec["warpgen_ms"] = timeit(lambda: hp.uv_generator(emb))
         rec["sampler_uv_ms"] = timeit(lambda: ops.grid_sample3d(ccl, delta=delta, in_layout=lay, out_layout=lay))
