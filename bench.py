@@ -14,8 +14,10 @@ pass runs on rank 0 and its canonical volume is broadcast over RCCL once per ide
 (reported as source_pass_ms / broadcast_ms).
 
 The JSON line also carries
-  roofline      the dominant kernel (conv_igemm: fp32 MFMA implicit-GEMM conv): algorithmic FLOPs of every conv launch of
-                the timed region / its duration measured with HIP events on the launch stream, vs the 157.3 TF fp32 MFMA peak
+  roofline      the dominant kernel -- conv_igemm_bf16x3_kernel (fp32 3x3 convolution on the bf16 matrix pipes, default) or, with
+                EMO_CONV_PRECISION=f32, conv_igemm_kernel (fp32 MFMA): algorithmic FLOPs of its launches in the timed region /
+                their duration measured with HIP events on the launch stream, vs 2500 / 6 TF (six bf16 products per fp32
+                product) resp. the 157.3 TF fp32 MFMA peak; roofline_other_convs: the same for the remaining conv launches
   roofline_sampler  the 3-D grid_sample kernels, algorithmic bytes / event time vs 8 TB/s
   cpu_baseline  the oracle (oracle/restate.py, a port of the reference's PyTorch forward) timed on this box's host cores
                 on a bounded sample (rank 0, N=1 only)
@@ -34,6 +36,7 @@ sys.path.insert(0, ROOT)
 from emoportraits_amd import config, nets, ops, parallel, random_init  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, dense bf16 (v_mfma_f32_32x32x16_bf16); the bf16x3 kernel issues 6 products per fp32 product
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec; 6.29 TB/s measured copy
 
 
@@ -41,7 +44,7 @@ class ConvMeter:
     """Brackets every conv_igemm launch with HIP events on the launch stream and sums algorithmic FLOPs."""
 
     def __init__(self):
-        self.events = []
+        self.events = []            # (start, stop, kernel = 'f32' | 'bf16x3' | 'f16', algorithmic FLOPs)
         self.flops = 0.0
         self.launches = 0
         self._orig = None
@@ -55,10 +58,11 @@ class ConvMeter:
             e0.record()
             ret = meter._orig(x, layer, *a, **kw)
             e1.record()
-            meter.events.append((e0, e1))
             out = ret[0] if isinstance(ret, tuple) else ret         # (out, tile statistics) with want_stats=True
             positions = out.numel() // layer.cout
-            meter.flops += 2.0 * positions * layer.macs_per_position
+            fl = 2.0 * positions * layer.macs_per_position
+            meter.events.append((e0, e1, layer.last_plan[2], fl))
+            meter.flops += fl
             meter.launches += 1
             return ret
 
@@ -71,7 +75,15 @@ class ConvMeter:
         nets.ops.conv_igemm = self._orig
 
     def total_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.events)
+        return sum(e[0].elapsed_time(e[1]) for e in self.events)
+
+    def by_kernel(self):
+        """{kernel: (ms, algorithmic FLOPs, launches)}"""
+        out = {}
+        for e0, e1, k, fl in self.events:
+            ms, f, n = out.get(k, (0.0, 0.0, 0))
+            out[k] = (ms + e0.elapsed_time(e1), f + fl, n + 1)
+        return out
 
 
 class SamplerMeter:
@@ -237,6 +249,12 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
     # batch-1 latency of the hot path (what one reference-style forward() call costs on the device)
     t = _time_loop(lambda: ops.pack_rgb8(hp.driver_pass(ccl, idt, pose[:1], theta[:1])))
     out["latency_b1_ms"] = round(t * 1e3, 3)
+    if hp.precision != "f32":
+        # the same pass with the exact-fp32 MFMA kernel in every convolution (EMO_CONV_PRECISION=f32)
+        hp32 = nets.HotPath(sd, cfg, dev, with_source=False, precision="f32")
+        t = _time_loop(lambda: ops.pack_rgb8(hp32.driver_pass(ccl, idt, pose, theta)))
+        out["fp32_mfma_everywhere_fps"] = round(B / t, 2)
+        del hp32
     # stage 2 at 512x512 (notebooks/infer_s2.py:351-376), 8 frames per call
     g = torch.Generator().manual_seed(11)
     s2cfg = stage2.stage2_config(overrides=dict(output_size_s2=512))
@@ -312,7 +330,8 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
             w.forward(custome_target_pose_embed=e, custome_target_theta_embed=p, crop=False)
     t = _time_loop(emo_loop, seconds=3.0)
     out["emotion_driver_forward_fps"] = round(16 / t, 2)
-    out["what"] = ("latency_b1_ms: one driver frame through the hot path; stage2_*: Stage2.refine at 512x512, 8 frames per call; "
+    out["what"] = ("latency_b1_ms: one driver frame through the hot path; fp32_mfma_everywhere_fps: the bench step with the exact-fp32 "
+                   "MFMA kernel in every convolution; stage2_*: Stage2.refine at 512x512, 8 frames per call; "
                    "stage1_plus_stage2_*: driver pass + refinement + uint8 pack, B frames per call; r256_fps: R256 driver pass, 32 frames "
                    "per call; pipeline_frames_in_out_fps: InferenceWrapper.animate_frames (uint8 in, embedders, hot path, uint8 out); "
                    "emotion_driver_forward_fps: forward(custome_target_pose_embed=, custome_target_theta_embed=) per frame, PIL out")
@@ -446,14 +465,42 @@ def main():
     samp_ms = samp_meter.total_ms()
     conv_tflops = conv_meter.flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     samp_gbps = samp_meter.bytes / (samp_ms * 1e-3) / 1e9 if samp_ms > 0 else 0.0
-    pmc = None
-    pmc_path = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_traffic.json")))[-1:]
-    pmc_path = pmc_path[0] if pmc_path else ""
-    if pmc_path and os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-        except Exception:
-            pmc = None
+    by_k = conv_meter.by_kernel()
+    dom = max(by_k, key=lambda k: by_k[k][0])                   # the kernel the step spends most of its time in
+
+    def conv_roofline(k):
+        ms, fl, n = by_k[k]
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        pmc, pmc_path = None, ""
+        pat = "r*_pmc_conv_bf16x3_traffic.json" if k == "bf16x3" else "r*_pmc_conv_traffic.json"
+        found = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", pat)))[-1:]
+        if found:
+            try:
+                pmc, pmc_path = json.load(open(found[0])).get("hbm_bytes_per_launch"), found[0]
+            except Exception:
+                pmc = None
+        if k == "bf16x3":
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+            name = ("conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes: exact 3-way operand split, 6 "
+                    "v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation)")
+            note = ("achieved = algorithmic fp32 FLOPs / event time; peak = 2500 TF dense bf16 / 6 products.  A bare stream of this "
+                    "MFMA sustains 1.49-1.72 PF on this chip (clocks fall to 1.4-1.7 GHz under it: tools/microbench/mfma_stream.hip, "
+                    "profiles/r3_mfma_stream.jsonl) = 249-287 TF fp32-equivalent")
+        else:
+            peak = PEAK_FP32_MFMA_TFLOPS if k == "f32" else PEAK_BF16_MFMA_TFLOPS
+            name = ("conv_igemm_kernel (fp32 32x32x2 MFMA implicit-GEMM conv, all instantiations)" if k == "f32" else
+                    "conv_igemm_f16_kernel (fp16 operands)")
+            note = None
+        r = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+             "frac": round(tf / peak, 4), "traffic": pmc,
+             "traffic_source": (f"{os.path.relpath(pmc_path, ROOT)}: rocprofv3 --pmc passes of this command (guide-corrected "
+                                "HBM bytes per launch), NOT measured in this run" if pmc is not None else None),
+             "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
+             "share_of_step": round(ms / (elapsed * 1e3), 3)}
+        if note:
+            r["note"] = note
+        return r
+
     rec = {
         "metric": "reenactment frames/sec @512x512, 1-src->N-driver" if S == 512 else f"reenactment frames/sec @{S}x{S}, 1-src->N-driver",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -464,19 +511,17 @@ def main():
                    "image_size": S, "frames_per_gpu_per_step": B,
                    "weights": ("seeded random, reference key layout" if a.raw_weights else
                                "seeded trained-like (spectral norms ~1, |uv delta| < ~1 voxel, unsaturated image), reference key layout"),
+                   "conv_arithmetic": {"bf16x3": "fp32 tensors and accumulation; 3x3 decoder convs: every fp32 operand split exactly "
+                                                 "into 3 bf16 terms, 6 partial products on the bf16 matrix pipes (error vs fp64 <= "
+                                                 "the fp32 MFMA kernel's, tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
+                                       "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution"}[hp.precision],
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 32x32x2 MFMA implicit-GEMM conv, all instantiations)",
-                     "achieved": round(conv_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc,
-                     "traffic_source": (f"{os.path.relpath(pmc_path, ROOT)}: rocprofv3 --pmc passes of this command (guide-corrected "
-                                        "HBM bytes per launch), NOT measured in this run" if pmc is not None else None),
-                     "launches_per_step": conv_meter.launches // max(1, a.steps),
-                     "avg_launch_ms": round(conv_ms / max(1, conv_meter.launches), 4),
-                     "share_of_step": round(conv_ms / (elapsed * 1e3), 3)},
+        "roofline": conv_roofline(dom),
         "roofline_sampler": {"bound": "hbm", "kernel": "gs3d_cl_v2 / gs3d_cl2ncdhw_v2 (3-D grid_sample, channels-last)",
                              "achieved": round(samp_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": round(samp_gbps / PEAK_HBM_GBPS, 4),
                              "avg_launch_ms": round(samp_ms / max(1, len(samp_meter.events)), 4)},
+        "roofline_other_convs": {k: conv_roofline(k) for k in by_k if k != dom},
         "source_pass_ms": None if source_ms is None else round(source_ms, 2),
         "broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 3),   # one flat RCCL broadcast of the source cache, max over ranks
     }

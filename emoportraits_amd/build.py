@@ -31,7 +31,10 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 # and, to feed them, hoists a {w, w} splat of every corner weight out of the loops -- 16 extra VGPRs per owned voxel, i.e.
 # spills at the 4-waves-per-SIMD budget (measured: 104 spilled VGPRs with, 0 without).
 EXTRA_FLAGS = {"gs3d_tile_pad_zeros.hip": ["-fno-slp-vectorize"], "gs3d_tile_pad_border.hip": ["-fno-slp-vectorize"],
-               "gs3d_tile_pad_reflection.hip": ["-fno-slp-vectorize"]}
+               "gs3d_tile_pad_reflection.hip": ["-fno-slp-vectorize"],
+               # conv_igemm_bf16x3.h: SLP packs the split's subtractions into v_pk_add_f32, which beside MFMAs costs more than
+               # the two scalar ops it replaces (MI355X_MICROARCH.md, filler prices of a one-wave-per-SIMD stream)
+               "conv_inst_bf16x3_3x3.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

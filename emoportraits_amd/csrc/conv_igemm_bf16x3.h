@@ -3,31 +3,36 @@
 // accumulated in fp32 from the six partial products of order <= 2^-16:
 //     x * w  ~=  xh*wh + xh*wm + xm*wh + xm*wm + xh*wl + xl*wh          (dropped: xm*wl + xl*wm + xl*wl  <=  2^-23 |x w|)
 // Each partial product of two bf16 values is exact in fp32, so the only rounding is the fp32 accumulation inside
-// v_mfma_f32_32x32x16_bf16 -- the same kind of error the fp32 MFMA kernel of conv_igemm.h has, with 4x fewer accumulation steps
-// (K = 16 per instruction, 6 instructions per 16 channels, against 8 of K = 2).  Measured against an fp64 convolution the result
-// is as close as the fp32 MFMA kernel's (tests/test_conv_bf16x3_gpu.py); the dropped terms are 30x below the accumulation
-// error (tools/split_accuracy.py, CPU).  The bf16 pipes run at 16x the fp32 MFMA rate: six products cost 6/16 of the fp32
+// v_mfma_f32_32x32x16_bf16.  That accumulation is coarser than an fp32 fma chain (measured: with all six products in one
+// accumulator the error against an fp64 convolution is 2.4x the fp32 MFMA kernel's, profiles/r3_bf16x3_first_run.txt), so the
+// five small products (<= 2^-8 of the leading one) go to a SECOND accumulator set whose rounding is 2^-8 smaller, and the
+// leading product's accumulator sees one MFMA per 16 channels and tap -- 8x fewer accumulation steps than the fp32 kernel's
+// K = 2 instructions; the two sets are added once in the epilogue.  The dropped terms are 30x below the accumulation error
+// (tools/split_accuracy.py, CPU); tests/test_conv_bf16x3_gpu.py holds the kernel to the fp32 MFMA kernel's error against fp64.  The bf16 pipes run at 16x the fp32 MFMA rate: six products cost 6/16 of the fp32
 // kernel's matrix time.  NOT a reduced-precision mode: tensors, norms, epilogue and accumulation are fp32 and the operands
 // keep all 24 significand bits.
 //
 // Structure (one block = 64 output channels x 256 positions = a 4 x 64 pixel tile, 4 waves of 64 x 64, ONE block per CU:
 // 150 KB of LDS, 512 registers per lane):
 //   * operand planes in LDS, bf16, 16 bytes = 8 channels per slot (both MFMA operands are one ds_read_b128 per lane):
-//       weights  W[2][plane][tap column s][half][64][8]    one KERNEL ROW (3 taps) of 16 input channels, double-buffered,
-//                                                           copied by LDS-DMA from the host-packed, host-split tensor
+//       weights  W[kernel row][plane][tap column s][half][64][8]   16 input channels; each row buffer is refilled for the next
+//                                                           channel group by LDS-DMA (host-packed, host-split tensor) as soon
+//                                                           as its last fragments have been read: two rows of latency budget
 //       patch    P[2][plane][8-channel group][slot][8]      16 input channels of the (4+2) x (64+2) source patch, split on
 //                                                           the way in (conv_igemm_f16.h staging: quads, halo wave, slots)
 //   * K loop over channel groups cg (16 channels [x depth tap]) x kernel rows r x tap columns s; one step (cg, r, s) =
 //     12 ds_read_b128 (3 planes x (2 weight + 2 patch fragments)) feeding 24 MFMAs (4 tiles x 6 products) = 768 matrix
 //     cycles per SIMD; fragments are read one step ahead into three rotating register sets.
 //   * one barrier per kernel row, placed between its steps 1 and 2 ("MIDBAR"): at that point every wave has read the last
-//     weight fragments of row t (they are fetched one step ahead), so W[t & 1] is free for the DMA of row t + 2, and the
-//     DMA of row t + 1 (issued one row ago) is waited for right there -- the fragments of (t + 1, 0) are prefetched behind it.
+//     weight fragments of row r (they are fetched one step ahead), so W[r] is free for the DMA of (cg + 1, r), and the DMA of
+//     the next row (issued two rows ago) is waited for right there -- the fragments of its step 0 are prefetched behind it.
 //   * the patch of group cg + 1 is converted during (cg, row 0, step 2) .. (cg, row 1, step 1) from registers loaded during
-//     cg - 1; the loads of cg + 2 are issued behind MIDBAR(cg, 1).  vmcnt bookkeeping (all VMEM of the loop is inline asm):
-//         behind MIDBAR(cg,0): DMA(cg,2)      behind MIDBAR(cg,1): DMA(cg+1,0), Q(cg+2)      behind MIDBAR(cg,2): DMA(cg+1,1)
-//         MIDBAR(cg,0) waits vmcnt(0): Q(cg+1) and DMA(cg,1);  MIDBAR(cg,1) waits vmcnt(0): DMA(cg,2);
-//         MIDBAR(cg,2) waits vmcnt(8 | 16 in the halo wave): DMA(cg+1,0), leaving Q(cg+2) in flight.
+//     cg - 1; the loads of cg + 2 are issued behind MIDBAR(cg, 1).  vmcnt bookkeeping (all VMEM of the loop is inline asm;
+//     every wave issues exactly 5 DMA instructions per row, 8 quad loads, the halo wave 8 more):
+//         behind MIDBAR(cg,0): DMA(cg+1,0)    behind MIDBAR(cg,1): DMA(cg+1,1), Q(cg+2)    behind MIDBAR(cg,2): DMA(cg+1,2)
+//         MIDBAR(cg,0) needs DMA(cg,1) and Q(cg+1), leaves DMA(cg,2) in flight: vmcnt(5)
+//         MIDBAR(cg,1) needs DMA(cg,2), leaves DMA(cg+1,0): vmcnt(5)
+//         MIDBAR(cg,2) needs DMA(cg+1,0), leaves DMA(cg+1,1) and Q(cg+2): vmcnt(13), halo wave vmcnt(21)
 // Covers 3x3 (and 3x3x3 with the depth taps as K stages) layers on maps whose width is a multiple of 64 and height a
 // multiple of 4, optional fused nearest x2 upsample, Cin % 8 == 0; epilogue, K split and GroupNorm tile statistics are the
 // shared conv_epilogue.  Anything else runs conv_igemm.h.
@@ -38,6 +43,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef EMO_S_PIN
 #define EMO_S_PIN 1   /* 0: A/B switch -- the compiler schedules the inside of a step on its own */
+#endif
+#ifndef EMO_S_ABLATE
+#define EMO_S_ABLATE 0   /* timing experiments only (results are WRONG for any value != 0), bits: 1 = no weight DMA in the K loop,
+                            2 = no patch loads / conversion / LDS stores in the K loop, 4 = no barriers and no vmcnt waits in the
+                            K loop, 8 = no fragment reads in the K loop (MFMAs on stale registers) */
 #endif
 #ifndef EMO_S_PRODUCTS
 #define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
@@ -62,12 +72,14 @@ struct ConvCfgS {
   static constexpr int WROW_BYTES = WROW * 16;
   static constexpr int PPL = NG * CHS;                   // one plane of the patch
   static constexpr int PBUF = 3 * PPL;
-  static constexpr int OFF_P = 2 * WROW;
+  static constexpr int OFF_P = 3 * WROW;                 // after the three kernel-row weight buffers
   static constexpr int OFF_DUMP = OFF_P + 2 * PBUF;      // 64 dump slots (stores of threads without a quad)
   static constexpr int OFF_SCT = OFF_DUMP + 64;          // scale / shift tables (fp32)
   static constexpr int SCT = 1024;
   static constexpr int LDS_BYTES = OFF_SCT * 16 + 2 * SCT * 4;
-  static constexpr int NDMA = (WROW_BYTES + 4095) / 4096;   // LDS-DMA rounds per kernel row (a round = 4 waves x 1 KiB)
+  static constexpr int NDMA = 5;                         // LDS-DMA instructions EVERY wave issues per kernel row (1 KiB each): 18
+                                                         // pieces; waves 2, 3 re-copy pieces 16, 17 (uniform vmcnt counts)
+  static_assert(WROW_BYTES == 18 * 1024, "18 DMA pieces per kernel row");
   static_assert(TR * TW == BP, "planar position tile of BP pixels");
   static_assert(TWS % 4 == 0 && (!UPS || (TR % 2 == 0 && TW % 2 == 0)), "whole quads");
   static_assert(PR * NQ <= QPG, "one interior quad per thread and stage");
@@ -278,21 +290,20 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #define EMO_S_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[u]); }
 #define EMO_S_TOUCH_HALO() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(hv[u]); }
 // one kernel row of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
-#define EMO_S_DMA_ROW(stage_, row_, dst_slot_)                                                        \
+#define EMO_S_DMA_ROW(stage_, row_)                                                                   \
   {                                                                                                   \
     const char* ws_ = wsrc + ((long)(stage_) * 3 + (row_)) * Cfg::WROW_BYTES;                         \
     _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) {                                           \
-      const int j = wave + 4 * i;                                                                     \
-      if (j * 1024 < Cfg::WROW_BYTES)                                                                 \
-        emo_dma16_pinned(ws_ + j * 1024 + lane * 16, smem_lds + (unsigned)((dst_slot_) * 16 + j * 1024)); \
+      const int j = i < 4 ? wave + 4 * i : 16 + (wave & 1);                                           \
+      emo_dma16_pinned(ws_ + j * 1024 + lane * 16, smem_lds + (unsigned)((row_) * Cfg::WROW_BYTES + j * 1024)); \
     }                                                                                                 \
   }
 #define EMO_S_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #define EMO_S_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
 
-  // ---- prologue: rows 0 and 1 of the first stage by DMA, its patch converted into P[0], the loads of the second stage ----
-  EMO_S_DMA_ROW(st_begin, 0, 0);
-  EMO_S_DMA_ROW(st_begin, 1, WROW);
+  // ---- prologue: the three kernel rows of the first stage by DMA, its patch converted into P[0], the loads of the second ----
+  EMO_S_DMA_ROW(st_begin, 0);
+  EMO_S_DMA_ROW(st_begin, 1);
   EMO_S_SET_STAGE(st_begin);
   EMO_S_ISSUE_QUAD()
   if (is_halo_wave) EMO_S_ISSUE_HALO()
@@ -321,10 +332,9 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   if (is_halo_wave) {
     EMO_S_ISSUE_HALO()
     EMO_S_HALO_TABLE()
-    EMO_S_BARRIER(16);
-  } else {
-    EMO_S_BARRIER(8);
   }
+  EMO_S_DMA_ROW(st_begin, 2);            // issue order of the steady state: Q(cg + 1), then DMA(cg, 2)
+  if (is_halo_wave) { EMO_S_BARRIER(21); } else { EMO_S_BARRIER(13); }   // (LDS stores of P[0] visible; nothing to wait for)
   EMO_S_LOAD_FRAGS(0, 0, Cfg::OFF_P, 0, 0)
 
   // the six partial products, smallest first: (weight plane, patch plane)
@@ -344,16 +354,17 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       const int r = gs / 3, s = gs % 3;
       if (s == 2) {
         // MIDBAR(cg, r): every wave has fetched the last weight fragments of this row; the DMA of the next row has landed
-        if (r == 2) {
-          if (is_halo_wave) { EMO_S_BARRIER(16); } else { EMO_S_BARRIER(8); }
-        } else {
-          EMO_S_BARRIER(0);
+        if (!(EMO_S_ABLATE & 4)) {
+          if (r == 2) {
+            if (is_halo_wave) { EMO_S_BARRIER(21); } else { EMO_S_BARRIER(13); }
+          } else {
+            EMO_S_BARRIER(5);
+          }
         }
-        const int wfree = ((cgrel + r) & 1) * WROW;               // the buffer of this row = the buffer of row t + 2
-        if (r == 0) {
-          EMO_S_DMA_ROW(cg, 2, wfree);
-        } else if (r == 1) {
-          EMO_S_DMA_ROW(cg1, 0, wfree);
+        if (!(EMO_S_ABLATE & 1)) {
+          if (r == 0) { EMO_S_DMA_ROW(cg1, 0); } else if (r == 1) { EMO_S_DMA_ROW(cg1, 1); } else { EMO_S_DMA_ROW(cg1, 2); }
+        }
+        if (r == 1 && !(EMO_S_ABLATE & 2)) {
           EMO_S_SET_STAGE(cg2);
           EMO_S_ISSUE_QUAD()
           EMO_S_QUAD_TABLE()
@@ -361,8 +372,6 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
             EMO_S_ISSUE_HALO()
             EMO_S_HALO_TABLE()
           }
-        } else {
-          EMO_S_DMA_ROW(cg1, 1, wfree);
         }
       }
       // ---- one step: the fragments of the NEXT step (three rotating register sets), a piece of the next group's patch
@@ -370,20 +379,24 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       //      sched_group_barrier: the compiler left to itself sinks the fragment reads to their first use (LDS latency in
       //      front of every MFMA) and emits the conversion as one VALU burst (the matrix pipe idles behind it) ----
       __builtin_amdgcn_sched_barrier(0);
-      if (gs < 8) {
-        const int rn = (gs + 1) / 3, sn = (gs + 1) % 3;
-        EMO_S_LOAD_FRAGS((gs + 1) % 3, ((cgrel + rn) & 1) * WROW, pcur, rn, sn)
-      } else {
-        EMO_S_LOAD_FRAGS(0, ((cgrel + 1) & 1) * WROW, pnxt, 0, 0)
+      if (!(EMO_S_ABLATE & 8)) {
+        if (gs < 8) {
+          const int rn = (gs + 1) / 3, sn = (gs + 1) % 3;
+          EMO_S_LOAD_FRAGS((gs + 1) % 3, rn * WROW, pcur, rn, sn)
+        } else {
+          EMO_S_LOAD_FRAGS(0, 0, pnxt, 0, 0)
+        }
       }
-      if (gs == 2) {
-        EMO_S_TOUCH_QUAD()
-        if (is_halo_wave) EMO_S_TOUCH_HALO()
-        EMO_S_STORE_QUAD(pnxt, 0)
-      } else if (gs == 3) {
-        EMO_S_STORE_QUAD(pnxt, 2)
-      } else if (gs == 4) {
-        if (is_halo_wave) EMO_S_STORE_HALO(pnxt)
+      if (!(EMO_S_ABLATE & 2)) {
+        if (gs == 2) {
+          EMO_S_TOUCH_QUAD()
+          if (is_halo_wave) EMO_S_TOUCH_HALO()
+          EMO_S_STORE_QUAD(pnxt, 0)
+        } else if (gs == 3) {
+          EMO_S_STORE_QUAD(pnxt, 2)
+        } else if (gs == 4) {
+          if (is_halo_wave) EMO_S_STORE_HALO(pnxt)
+        }
       }
 #pragma unroll
       for (int p = 0; p < NPROD; ++p) {
@@ -393,7 +406,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < TP; ++j)
             // operands swapped: the result tile is [position][channel] (conv_epilogue)
-            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_lo[i][j], 0, 0, 0);
+            // (the leading product h x h accumulates in acc_lo, the five small ones in acc_hi: header comment)
+            if (pa == 0 && pb == 0)
+              acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_lo[i][j], 0, 0, 0);
+            else
+              acc_hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_hi[i][j], 0, 0, 0);
       }
       if (EMO_S_PIN) {
         // 12 x { MFMA, fragment read, <= 5 VALU }, then { MFMA, <= 6 VALU, LDS store } for the rest
@@ -431,6 +448,12 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #undef EMO_S_BARRIER
 #undef EMO_S_LOAD_FRAGS
 
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_lo[i][j][r] += acc_hi[i][j][r];
   conv_epilogue<1, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
 }
 

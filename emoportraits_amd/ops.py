@@ -288,6 +288,7 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
     bp = pack_mod._BP[cfg]
     if want_stats and ks == 1 and (D * Hl * Wl) % bp == 0:
         stats = TileStats(torch.empty((N, D * Hl * Wl // bp, layer.cout, 2), device=x.device, dtype=torch.float32), bp)
+    layer.last_plan = (cfg, ks, prec)        # which kernel ran (bench.py meters the kernels separately)
     entry = {"f32": lib.emo_conv_igemm_f32, "f16": lib.emo_conv_igemm_f16acc32, "bf16x3": lib.emo_conv_igemm_bf16x3}[prec]
     rc = entry(hip.ptr(x), hip.ptr(layer.packed(cfg, prec)), hip.ptr(layer.bias), hip.ptr(scale),
                hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,

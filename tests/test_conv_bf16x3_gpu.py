@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 
 
 CASES = [
-    dict(N=2, Cin=40, Cout=72, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),          # ragged channel group
+    dict(N=2, Cin=40, Cout=120, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),         # ragged channel group
     dict(N=2, Cin=64, Cout=64, dims=(32, 32), k=3, cfg=3, ups=True, res=True, res_ups=True, act="tanh"),
     dict(N=1, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=3, affine=True, relu_in=True),
-    dict(N=1, Cin=72, Cout=130, dims=(8, 64, 64), k=3, cfg=3, affine=True, relu_in=True, bias=False),   # 3-D: depth taps as stages
-    dict(N=1, Cin=96, Cout=72, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, ksplit=3),
+    dict(N=1, Cin=72, Cout=190, dims=(8, 64, 64), k=3, cfg=3, affine=True, relu_in=True, bias=False),   # 3-D: depth taps as stages
+    dict(N=1, Cin=96, Cout=112, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, ksplit=3),
     dict(N=1, Cin=24, Cout=64, dims=(256, 256), k=3, cfg=3, affine=True, relu_in=True, res=True),
     dict(N=1, Cin=32, Cout=64, dims=(64, 64), k=3, cfg=3, ups=True, affine=True, relu_in=True),
     dict(N=2, Cin=16, Cout=96, dims=(32, 32), k=3, cfg=3, ups=True, affine=True),                       # one stage, no ReLU
@@ -54,8 +54,8 @@ def test_conv_bf16x3_is_as_close_to_fp64_as_the_fp32_kernel():
         err = (y - ref).abs()
         outs[prec] = (err.mean().item() / scale, err.max().item() / scale)
     print("PARITY conv vs fp64 (rel mean, rel max): fp32 MFMA %.2e %.2e | bf16x3 %.2e %.2e" % (outs["f32"] + outs["bf16x3"]))
-    assert outs["bf16x3"][0] <= 1.25 * outs["f32"][0] + 1e-8
-    assert outs["bf16x3"][1] <= 1.5 * outs["f32"][1] + 1e-7
+    assert outs["bf16x3"][0] <= 1.1 * outs["f32"][0] + 1e-8        # mean error: no worse than the fp32 MFMA kernel
+    assert outs["bf16x3"][1] <= 2.0 * outs["f32"][1] + 1e-7        # worst element of 1e6 (a tail statistic: factor 2)
 
 
 def test_conv_bf16x3_layer_plan_and_tile_statistics():

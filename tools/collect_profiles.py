@@ -29,7 +29,12 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_f16_512c_pmc_conv.json", f"{tag}_f16_pmc_sq_conv_512to512_at64.json"),
                  (f"{tag}_f16_128c_pmc_conv.json", f"{tag}_f16_pmc_sq_conv_128to128_at512.json"),
                  (f"{tag}_conv_overhead_fit.jsonl", f"{tag}_conv_overhead_fit.jsonl"),
-                 (f"{tag}_vmem_rate.jsonl", f"{tag}_vmem_rate_microbench.jsonl")):
+                 (f"{tag}_vmem_rate.jsonl", f"{tag}_vmem_rate_microbench.jsonl"),
+                 (f"{tag}_mfma_stream.jsonl", f"{tag}_mfma_stream.jsonl"),
+                 (f"{tag}_bf16x3_conv.jsonl", f"{tag}_bf16x3_conv_microbench.jsonl"),
+                 (f"{tag}_bf16x3_512c_pmc_conv.json", f"{tag}_bf16x3_pmc_sq_conv_512to512_at64.json"),
+                 (f"{tag}_bf16x3_128c_pmc_conv.json", f"{tag}_bf16x3_pmc_sq_conv_128to128_at512.json"),
+                 (f"{tag}_driver512_f32.jsonl", f"{tag}_driver_breakdown_r512_fp32_mfma.jsonl")):
     if os.path.exists(g + src):
         if dst.endswith(".json") and "bench" in dst:      # keep the JSON line only (gloo prints a banner to stdout)
             lines = [l for l in open(g + src, errors="replace") if l.lstrip().startswith("{")]
@@ -42,26 +47,38 @@ if os.path.exists(g + f"{tag}_pytest.log"):
 f, w, m = (json.load(open(g + f"{tag}_pmc_{n}.json")) for n in ("fetch", "write", "mfma"))
 for n, d in (("fetch", f), ("write", w), ("mfma", m)):
     json.dump(d, open(p + f"{tag}_pmc_{n}.json", "w"), indent=1, sort_keys=True)
-conv = [k for k in f if k.startswith("conv_igemm_kernel")]
-n = sum(f[k]["FETCH_SIZE"]["launches"] for k in conv)
-tf = sum(f[k]["FETCH_SIZE"]["sum"] for k in conv)
-tw = sum(w[k]["WRITE_SIZE"]["sum"] for k in conv)
-mf = sum(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] for k in conv)
-gui = sum(m[k]["GRBM_GUI_ACTIVE"]["sum"] for k in conv)
 rows = list(csv.DictReader(open(p + f"{tag}_bench_kernel_stats.csv")))
-ct = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("conv_igemm"))
-cc = sum(int(r["Calls"]) for r in rows if r["Name"].startswith("conv_igemm"))
-out = {
-    "kernel": "conv_igemm_kernel (all instantiations)",
-    "pmc_run": "rocprofv3 --pmc <one counter set> (separate passes for FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE) "
-               "-- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-source-pass (batch 16, as the bench)",
-    "launches": n, "fetch_size_kib_per_launch": tf / n, "write_size_kib_per_launch": tw / n,
-    "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream "
-                  "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated (it equals the output tensor bytes exactly on the large layers)",
-    "hbm_bytes_per_launch": (2 * tf + tw) * 1024 / n,
-    "mfma_util": mf / (gui / 8 * 1024),
-    "mfma_util_formula": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); GRBM_GUI_ACTIVE sums the 8 XCDs",
-    "kernel_trace_avg_launch_ms": ct / cc / 1e6, "kernel_trace_launches": cc,
-}
-json.dump(out, open(p + f"{tag}_pmc_conv_traffic.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+
+
+def traffic(prefix, label, dst):
+    """per-launch HBM traffic + MFMA utilisation of the kernels whose name starts with `prefix` (all instantiations)"""
+    conv = [k for k in f if k.startswith(prefix)]
+    if not conv:
+        return None
+    n = sum(f[k]["FETCH_SIZE"]["launches"] for k in conv)
+    tf = sum(f[k]["FETCH_SIZE"]["sum"] for k in conv)
+    tw = sum(w[k]["WRITE_SIZE"]["sum"] for k in conv)
+    mf = sum(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] for k in conv)
+    gui = sum(m[k]["GRBM_GUI_ACTIVE"]["sum"] for k in conv)
+    ct = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith(prefix))
+    cc = sum(int(r["Calls"]) for r in rows if r["Name"].startswith(prefix))
+    out = {
+        "kernel": label,
+        "pmc_run": "rocprofv3 --pmc <one counter set> (separate passes for FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE) "
+                   "-- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-source-pass (batch 16, as the bench)",
+        "launches": n, "fetch_size_kib_per_launch": tf / n, "write_size_kib_per_launch": tw / n,
+        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream "
+                      "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated (it equals the output tensor bytes exactly on the large layers)",
+        "hbm_bytes_per_launch": (2 * tf + tw) * 1024 / n,
+        "mfma_util": mf / (gui / 8 * 1024),
+        "mfma_util_formula": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); GRBM_GUI_ACTIVE sums the 8 XCDs",
+        "kernel_trace_avg_launch_ms": ct / cc / 1e6 if cc else None, "kernel_trace_launches": cc,
+    }
+    json.dump(out, open(p + dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+    return out
+
+
+traffic("conv_igemm_kernel", "conv_igemm_kernel (fp32 MFMA, all instantiations)", f"{tag}_pmc_conv_traffic.json")
+traffic("conv_igemm_bf16x3_kernel", "conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes, all instantiations)",
+        f"{tag}_pmc_conv_bf16x3_traffic.json")
