@@ -15,7 +15,7 @@ conv_launch_fn conv_lookup_1x7_B(int, int);
 conv_launch_fn conv_lookup_f16_3x3_D(int, int);
 conv_launch_fn conv_lookup_f16_1x1_D(int, int);
 conv_launch_fn conv_lookup_f16_3x3_G(int, int);
-conv_launch_fn conv_lookup_bf16x3_3x3(int);
+conv_launch_fn conv_lookup_bf16x3_3x3(int, int);
 
 // MFMA operand format (accumulation and all tensors in HBM are fp32 either way).  PREC_S: every fp32 operand as the exact sum
 // of three bf16 terms, six partial products (conv_igemm_bf16x3.h) -- fp32 results on the bf16 pipes
@@ -142,13 +142,13 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   a.Dl = D; a.Hl = ups ? 2 * H : H; a.Wl = ups ? 2 * W : W;
   a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
   a.gn_stats = gn_stats;
-  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0;
+  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0;
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;
   if (prec == PREC_S) {
     if (!(KH == 3 && KW == 3 && (KD == 1 || KD == 3)) || cfg != CFG_D || Cin % 8) return EMO_ERR_UNSUPPORTED;
-    fn = conv_lookup_bf16x3_3x3(ups);
+    fn = conv_lookup_bf16x3_3x3(a.Wl, ups);
   } else if (prec == PREC_F16) {
     if (KD != 1 && !(KD == 3 && KH == 3)) return EMO_ERR_UNSUPPORTED;
     if ((cfg != CFG_D && cfg != CFG_G) || Cin % 8) return EMO_ERR_UNSUPPORTED;

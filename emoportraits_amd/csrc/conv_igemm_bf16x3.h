@@ -37,6 +37,7 @@
 // multiple of 4, optional fused nearest x2 upsample, Cin % 8 == 0; epilogue, K split and GroupNorm tile statistics are the
 // shared conv_epilogue.  Anything else runs conv_igemm.h.
 #pragma once
+#include <cstdlib>
 #include "conv_igemm_f16.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -107,12 +108,20 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const int wp = wave;
   const int m0 = 0, p0 = wp * TP * 32;
 
-  // block -> (sample, position tile, channel tile, K split): XCD-contiguous order, channel tile fastest (conv_igemm.h)
+  // work item -> (sample, position tile, channel tile, K split): XCD-contiguous order, channel tile fastest (conv_igemm.h).
+  // A block walks the work items of its XCD's contiguous range with a stride: gridDim.x == n_work (default) is one item per
+  // block; EMO_CONV_BF16X3_PERSISTENT=1 launches min(n_work, CUs) persistent blocks instead.  Measured (profiles/
+  // r3_bf16x3_persistent_ab.txt): +-2 % on six decoder shapes -- the launch of the next workgroup is not what the 12 us of
+  // per-block fixed cost are made of -- and 2.7x SLOWER on one (512 -> 320 with upsample: the CUs of a persistent grid stay in
+  // lock step and ask L2 for the same weight rows at the same moment); parity-tested, off.
+  const int q8 = a.n_work >> 3, r8 = a.n_work & 7;
+  const int xcd = blockIdx.x & 7;
+  const int n_mine = q8 + (xcd < r8 ? 1 : 0);
+  const int l_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int l_stride = (gridDim.x + 7) >> 3;
+  for (int idx8 = blockIdx.x >> 3; idx8 < n_mine; idx8 += l_stride) {
   int ks = 0;
-  const int total = gridDim.x;
-  const int q8 = total >> 3, r8 = total & 7;
-  const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
-  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
+  const int L = l_base + idx8;
   const int cotile = L % a.n_cotiles;
   int rest = L / a.n_cotiles;
   if (a.ksplit > 1) {
@@ -455,6 +464,8 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_lo[i][j][r] += acc_hi[i][j][r];
   conv_epilogue<1, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
+  __syncthreads();    // the next work item's prologue overwrites the LDS the epilogue exchanged its statistics through
+  }
 }
 
 template <int TR, int TW, bool UPS>
@@ -475,11 +486,19 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   auto kern = conv_igemm_bf16x3_kernel<TR, TW, UPS>;
   const int rc = emo_raise_dynamic_lds(kern);
   if (rc != EMO_OK) return rc;
+  static const int persistent = [] { const char* e = getenv("EMO_CONV_BF16X3_PERSISTENT"); return e ? atoi(e) : 0; }();
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
   a.n_cotiles = cot;
   if (a.ksplit < 1 || (a.ksplit > 1 && !a.partial)) return EMO_ERR_BAD_ARG;
   if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }
   if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
   if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nt * cot * a.N * a.ksplit)), dim3(256), (size_t)Cfg::LDS_BYTES, s, a);
+  a.n_work = (int)(nt * cot * a.N * a.ksplit);
+  const int grid = persistent && a.n_work > ncu ? ncu : a.n_work;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)Cfg::LDS_BYTES, s, a);
   return emo_launch_status();
 }

@@ -277,9 +277,9 @@ def supports_bf16x3(cout, cin, kd, kh, kw):
     return (kh, kw) == (3, 3) and kd in (1, 3) and cin % 8 == 0 and cout / (-(-cout // BF16X3_BM) * BF16X3_BM) >= 0.75
 
 
-def bf16x3_launch_fits(Hl, Wl):
-    """output planes tiled by 4 x 64 positions"""
-    return Hl is not None and Wl % 64 == 0 and Hl % 4 == 0
+def bf16x3_launch_fits(Hl, Wl, ups=False):
+    """output planes tiled by 4 x 64 positions, or (32-wide maps, no fused upsample) 8 x 32"""
+    return Hl is not None and ((Wl % 64 == 0 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0 and not ups))
 
 
 F16_AFFINE_MAX_CIN = 1024   # ConvCfgH::SCT (conv_igemm_f16.h)
@@ -360,7 +360,7 @@ class PackedConv:
                 (CFG_D, CFG_G) if (_CFG_EFF[CFG_G] > 0 and self.kh == 3) else (CFG_D,)
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, tiles, "f16")
             return cfg, ks, "f16"
-        if self.precision == "bf16x3" and bf16x3_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D) and aligned16 \
+        if self.precision == "bf16x3" and bf16x3_launch_fits(Hl, Wl, ups) and self.pinned_cfg in (None, CFG_D) and aligned16 \
                 and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), "bf16x3")
             return cfg, ks, "bf16x3"

@@ -25,6 +25,9 @@ CASES = [
     dict(N=1, Cin=8, Cout=64, dims=(4, 64), k=3, cfg=3),                                               # half a stage, one tile
     dict(N=3, Cin=48, Cout=200, dims=(8, 128), k=3, cfg=3, act="sigmoid"),
     dict(N=1, Cin=512, Cout=64, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True),                 # 32 stages
+    dict(N=2, Cin=128, Cout=64, dims=(16, 32, 32), k=3, cfg=3, affine=True, relu_in=True, res=True),   # 8 x 32 tiles, 3-D
+    dict(N=1, Cin=24, Cout=120, dims=(8, 32), k=3, cfg=3, bias=False),                                 # 8 x 32, one tile per plane
+    dict(N=6, Cin=64, Cout=320, dims=(64, 128), k=3, cfg=3, affine=True, relu_in=True),                # 960 tiles: persistent blocks
 ]
 
 

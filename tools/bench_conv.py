@@ -82,7 +82,7 @@ def main():
             msh = timeit(lambda: ops.conv_igemm(x, lh, scale, shift, relu_in=True, ups=ups, out=out))
             rec["f16_cfg3_ms"] = round(msh, 3)
             rec["f16_cfg3_tflops"] = round(flops / msh / 1e9, 1)
-        if split and k == 3 and pack.supports_bf16x3(cout, cin, kd, k, k) and pack.bf16x3_launch_fits(odims[-2], odims[-1]):
+        if split and k == 3 and pack.supports_bf16x3(cout, cin, kd, k, k) and pack.bf16x3_launch_fits(odims[-2], odims[-1], ups):
             ls = pack.PackedConv("b3", w, None, DEV, precision="bf16x3")
             out = ops.conv_igemm(x, ls, scale, shift, relu_in=True, ups=ups)
             mss = timeit(lambda: ops.conv_igemm(x, ls, scale, shift, relu_in=True, ups=ups, out=out))
