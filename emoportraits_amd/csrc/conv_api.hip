@@ -16,10 +16,12 @@ conv_launch_fn conv_lookup_f16_3x3_D(int, int);
 conv_launch_fn conv_lookup_f16_1x1_D(int, int);
 conv_launch_fn conv_lookup_f16_3x3_G(int, int);
 conv_launch_fn conv_lookup_bf16x3_3x3(int, int);
+conv_launch_fn conv_lookup_f16x2_3x3(int, int);
 
 // MFMA operand format (accumulation and all tensors in HBM are fp32 either way).  PREC_S: every fp32 operand as the exact sum
 // of three bf16 terms, six partial products (conv_igemm_bf16x3.h) -- fp32 results on the bf16 pipes
-enum { PREC_F32 = 0, PREC_F16 = 1, PREC_S = 2 };
+// PREC_S2: the scaled operand as two fp16 terms, three partial products (same kernel, SPLIT = 2; opt-in)
+enum { PREC_F32 = 0, PREC_F16 = 1, PREC_S = 2, PREC_S2 = 3 };
 
 static int shape_of_width(int Wl) {
   if (Wl >= 128 && Wl % 128 == 0) return SHAPE_W128;
@@ -31,7 +33,7 @@ static int shape_of_width(int Wl) {
 }
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
-  if (prec == PREC_S) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
+  if (prec == PREC_S || prec == PREC_S2) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
   if (prec == PREC_F16) {
     if (cfg == CFG_G) return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : 0;   // 128 x 256 tile: 3x3 only
     if (cfg != CFG_D) return 0;   // otherwise the fp16-operand kernels exist for the 64 x 256 tile only
@@ -122,7 +124,8 @@ extern "C" int emo_conv_igemm_ksplit(int N, int Cin, int Cout, int D, int H, int
 static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const float* bias, const float* scale,
                                const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D, int H,
                                int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups, int cfg,
-                               int ksplit, float* workspace, float* gn_stats, void* stream) {
+                               int ksplit, float* workspace, float* gn_stats, void* stream, float in_scale = 1.0f,
+                               float w_scale = 1.0f) {
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
   if (gn_stats && ksplit > 1) return EMO_ERR_UNSUPPORTED;   // tile statistics come from the single-pass epilogue
   if ((long)D * H * W >= (1L << 30)) return EMO_ERR_UNSUPPORTED;                 // 32-bit byte offsets inside one channel
@@ -143,12 +146,14 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
   a.gn_stats = gn_stats;
   a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0;
+  a.in_scale = in_scale; a.out_scale = 1.0f / (in_scale * w_scale);
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;
-  if (prec == PREC_S) {
+  if (prec == PREC_S || prec == PREC_S2) {
     if (!(KH == 3 && KW == 3 && (KD == 1 || KD == 3)) || cfg != CFG_D || Cin % 8) return EMO_ERR_UNSUPPORTED;
-    fn = conv_lookup_bf16x3_3x3(a.Wl, ups);
+    if (prec == PREC_S2 && !(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;
+    fn = prec == PREC_S ? conv_lookup_bf16x3_3x3(a.Wl, ups) : conv_lookup_f16x2_3x3(a.Wl, ups);
   } else if (prec == PREC_F16) {
     if (KD != 1 && !(KD == 3 && KH == 3)) return EMO_ERR_UNSUPPORTED;
     if ((cfg != CFG_D && cfg != CFG_G) || Cin % 8) return EMO_ERR_UNSUPPORTED;
@@ -203,6 +208,15 @@ extern "C" int emo_conv_igemm_bf16x3(const float* x, const void* wpk3, const flo
                                      int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
   return conv_igemm_dispatch(PREC_S, x, wpk3, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
                              relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
+}
+
+extern "C" int emo_conv_igemm_f16x2(const float* x, const void* wpk2, const float* bias, const float* scale,
+                                    const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
+                                    int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
+                                    int cfg, int ksplit, float* workspace, float* gn_stats, void* stream, float in_scale,
+                                    float w_scale) {
+  return conv_igemm_dispatch(PREC_S2, x, wpk2, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream, in_scale, w_scale);
 }
 
 extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias, const float* scale,

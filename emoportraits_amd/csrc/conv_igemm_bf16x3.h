@@ -33,11 +33,20 @@
 //         MIDBAR(cg,0) needs DMA(cg,1) and Q(cg+1), leaves DMA(cg,2) in flight: vmcnt(5)
 //         MIDBAR(cg,1) needs DMA(cg,2), leaves DMA(cg+1,0): vmcnt(5)
 //         MIDBAR(cg,2) needs DMA(cg+1,0), leaves DMA(cg+1,1) and Q(cg+2): vmcnt(13), halo wave vmcnt(21)
+// SPLIT = 2 (opt-in, emo_conv_igemm_f16x2): the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 terms of the scaled
+// operand -- x * in_scale = x1 + x2 (+ <= 2^-24 relative; in_scale a power of two folded into the producer's affine, weights
+// scaled per layer on the host) -- and the THREE products x1 w1 + x1 w2 + x2 w1 (dropped: x2 w2 <= 2^-24), result multiplied
+// by 1 / (in_scale * w_scale) when the accumulator sets are combined.  Half the matrix work and two thirds of the LDS planes;
+// measured 277-346 TF fp32-equivalent against 188-225 (profiles/r3_f16x2_first_run.txt), error against an fp64 convolution
+// 1.09x the fp32 MFMA kernel's, end-to-end parity figures those of SPLIT = 3.  Its contract is narrower -- |x * in_scale|
+// saturates at 65504 (inputs beyond +-2047 after norm + ReLU), terms below 2^-14 / scale lose relative (not absolute)
+// precision -- which is why the exact SPLIT = 3 is the default.
 // Covers 3x3 (and 3x3x3 with the depth taps as K stages) layers on maps whose width is a multiple of 64 and height a
 // multiple of 4, optional fused nearest x2 upsample, Cin % 8 == 0; epilogue, K split and GroupNorm tile statistics are the
 // shared conv_epilogue.  Anything else runs conv_igemm.h.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "conv_igemm_f16.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -54,9 +63,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
 #endif
 
-template <int TR, int TW, bool UPS>
+// SPLIT = 3: bf16 x 3 terms, 6 products (exact operands).  SPLIT = 2: fp16 x 2 terms of the SCALED operand, 3 products (header
+// comment at the end of this file's introduction): half the matrix work, operands to 2^-24 relative inside +-65504 / in_scale.
+template <int TR, int TW, bool UPS, int SPLIT = 3>
 struct ConvCfgS {
   static constexpr int BM = 64, BP = 256, TM = 2, TP = 2, WGP = 4, KC = 16;
+  static constexpr int NPL = SPLIT;                      // operand planes
+  static constexpr int NPROD = SPLIT == 3 ? 6 : 3;       // partial products per fp32 product
   static constexpr int TRS = UPS ? TR / 2 : TR;          // tile extent in SOURCE pixels
   static constexpr int TWS = UPS ? TW / 2 : TW;
   static constexpr int PR = TRS + 2;                     // source rows of the patch
@@ -69,18 +82,19 @@ struct ConvCfgS {
   static constexpr int NHALO = NG * 2 * PR;
   // everything below in 16-byte slots
   static constexpr int WPLANE = 3 * 2 * BM;              // one plane of a kernel row: [s][half][BM]
-  static constexpr int WROW = 3 * WPLANE;                // one kernel row (3 planes)
+  static constexpr int WROW = NPL * WPLANE;              // one kernel row (all planes)
   static constexpr int WROW_BYTES = WROW * 16;
   static constexpr int PPL = NG * CHS;                   // one plane of the patch
-  static constexpr int PBUF = 3 * PPL;
+  static constexpr int PBUF = NPL * PPL;
   static constexpr int OFF_P = 3 * WROW;                 // after the three kernel-row weight buffers
   static constexpr int OFF_DUMP = OFF_P + 2 * PBUF;      // 64 dump slots (stores of threads without a quad)
   static constexpr int OFF_SCT = OFF_DUMP + 64;          // scale / shift tables (fp32)
   static constexpr int SCT = 1024;
   static constexpr int LDS_BYTES = OFF_SCT * 16 + 2 * SCT * 4;
-  static constexpr int NDMA = 5;                         // LDS-DMA instructions EVERY wave issues per kernel row (1 KiB each): 18
-                                                         // pieces; waves 2, 3 re-copy pieces 16, 17 (uniform vmcnt counts)
-  static_assert(WROW_BYTES == 18 * 1024, "18 DMA pieces per kernel row");
+  // LDS-DMA instructions EVERY wave issues per kernel row (1 KiB each).  3 planes: 18 pieces, waves 2, 3 re-copy pieces 16,
+  // 17 (uniform vmcnt counts); 2 planes: 12 pieces, 3 per wave
+  static constexpr int NDMA = SPLIT == 3 ? 5 : 3;
+  static_assert(WROW_BYTES == (SPLIT == 3 ? 18 : 12) * 1024, "DMA pieces per kernel row");
   static_assert(TR * TW == BP, "planar position tile of BP pixels");
   static_assert(TWS % 4 == 0 && (!UPS || (TR % 2 == 0 && TW % 2 == 0)), "whole quads");
   static_assert(PR * NQ <= QPG, "one interior quad per thread and stage");
@@ -89,17 +103,19 @@ struct ConvCfgS {
   static_assert(OFF_P * 4 >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the weight buffers");
 };
 
-template <int TR, int TW, bool UPS>
+template <int TR, int TW, bool UPS, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void conv_igemm_bf16x3_kernel(const ConvArgs a) {
-  using Cfg = ConvCfgS<TR, TW, UPS>;
+  using Cfg = ConvCfgS<TR, TW, UPS, SPLIT>;
+  using opx8 = typename std::conditional<SPLIT == 3, bf16x8, halfx8>::type;      // one LDS slot: 8 channels of one plane
+  constexpr int NPL = Cfg::NPL;
   constexpr int BM = Cfg::BM, TM = Cfg::TM, TP = Cfg::TP, WGP = Cfg::WGP, KC = Cfg::KC;
   constexpr int PR = Cfg::PR, NQ = Cfg::NQ, NQ1 = Cfg::NQ1, SUB = Cfg::SUB, CHS = Cfg::CHS, QPG = Cfg::QPG;
   constexpr int NHALO = Cfg::NHALO, TWS = Cfg::TWS, WPLANE = Cfg::WPLANE, WROW = Cfg::WROW, PPL = Cfg::PPL, PBUF = Cfg::PBUF;
   constexpr int HALO_WAVE = 3;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  bf16x8* const lds8 = reinterpret_cast<bf16x8*>(smem);
+  opx8* const lds8 = reinterpret_cast<opx8*>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,8 +158,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const long DHW = (long)a.D * HW;
   const float* xn = a.x + (long)n * a.Cin * DHW;
   const bool has_affine = a.scale != nullptr;
+  const float in_scale = SPLIT == 3 ? 1.0f : a.in_scale;
   const int padD = a.KD >> 1;
-  const float clamp_lo = a.relu_in ? 0.0f : -__builtin_inff();
+  // bounds of the staged value: ReLU or none; the fp16 split saturates at the fp16 range (of the scaled value)
+  constexpr float CLAMP_HI = SPLIT == 3 ? __builtin_inff() : 65504.0f;
+  const float clamp_lo = a.relu_in ? 0.0f : -CLAMP_HI;
 
   const int nstages_all = a.n_cchunks * a.KD;
   const int st_begin = ks * a.stages_per_split;
@@ -197,10 +216,10 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       }
   }
 
-  bf16x8 fa_[3][3][TM], fb_[3][3][TP];     // [register set][plane][tile]
+  opx8 fa_[3][NPL][TM], fb_[3][NPL][TP];     // [register set][plane][tile]
 #define EMO_S_LOAD_FRAGS(set_, wbase_, pbase_, r_, s_)                                                \
   {                                                                                                   \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                              \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
         fa_[set_][pl][i] = lds8[(wbase_) + pl * WPLANE + (s_) * 2 * BM + a_base + i * 32];           \
       _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                  \
@@ -210,7 +229,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 
   float* const sct = smem + Cfg::OFF_SCT * 4;
   const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem);
-  bf16x8* const dump8 = lds8 + Cfg::OFF_DUMP + lane;
+  opx8* const dump8 = lds8 + Cfg::OFF_DUMP + lane;
 
   floatx4 qv[8];
   float hv[8];
@@ -238,7 +257,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     const int cs_ = cv_ ? c0_ : 0;                                                                    \
     const bool keep_ = q_ok && cv_ && n_zv;                                                           \
     q_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
-    q_hi = keep_ ? __builtin_inff() : 0.0f;                                                           \
+    q_hi = keep_ ? CLAMP_HI : 0.0f;                                                           \
     const unsigned vo_ = q_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u; \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) qv[u] = emo_bload4_pinned(xrs, vo_, usoff[u]);      \
     q_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
@@ -255,7 +274,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     const int cs_ = cv_ ? c0_ : 0;                                                                    \
     const bool keep_ = h_ok && cv_ && n_zv;                                                           \
     h_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
-    h_hi = keep_ ? __builtin_inff() : 0.0f;                                                           \
+    h_hi = keep_ ? CLAMP_HI : 0.0f;                                                           \
     const unsigned vo_ = h_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u; \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) hv[u] = emo_bload_pinned(xrs, vo_, usoff[u]);       \
     h_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
@@ -269,31 +288,36 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 // padding), then the exact three-way split v = h + m + l (round-to-nearest-even at every level; the residuals are exact)
 #define EMO_S_SPLIT8(dst_, val_)                                                                      \
   {                                                                                                   \
-    bf16x8 h_, m_, l_;                                                                                \
+    opx8 h_, m_, l_;                                                                                  \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                   \
       const float v = (val_);                                                                         \
-      h_[u] = (__bf16)v;                                                                              \
-      const float r1 = v - (float)h_[u];                                                              \
-      m_[u] = (__bf16)r1;                                                                             \
-      const float r2 = r1 - (float)m_[u];                                                             \
-      l_[u] = (__bf16)r2;                                                                             \
+      if constexpr (SPLIT == 3) {                                                                     \
+        h_[u] = (__bf16)v;                                                                            \
+        const float r1 = v - (float)h_[u];                                                            \
+        m_[u] = (__bf16)r1;                                                                           \
+        const float r2 = r1 - (float)m_[u];                                                           \
+        l_[u] = (__bf16)r2;                                                                           \
+      } else {                                                                                        \
+        h_[u] = (_Float16)v;                                                                          \
+        m_[u] = (_Float16)(v - (float)h_[u]);                                                         \
+      }                                                                                               \
     }                                                                                                 \
     (dst_)[0] = h_;                                                                                   \
     (dst_)[live_ ? PPL : 0] = m_;                                                                     \
-    (dst_)[live_ ? 2 * PPL : 0] = l_;                                                                 \
+    if constexpr (SPLIT == 3) (dst_)[live_ ? 2 * PPL : 0] = l_;                                       \
   }
 #define EMO_S_STORE_QUAD(pbase_, i0_)                                                                 \
   {                                                                                                   \
     const bool live_ = q_live;                                                                        \
     _Pragma("unroll") for (int i = (i0_); i < (i0_) + 2; ++i) {                                       \
-      bf16x8* d_ = live_ ? lds8 + (pbase_) + q_slot + i * SUB : dump8;                                \
+      opx8* d_ = live_ ? lds8 + (pbase_) + q_slot + i * SUB : dump8;                                \
       EMO_S_SPLIT8(d_, __builtin_amdgcn_fmed3f(__fmaf_rn(qv[u][i], q_sc[u / 4][u % 4], q_sh[u / 4][u % 4]), q_lo, q_hi)) \
     }                                                                                                 \
   }
 #define EMO_S_STORE_HALO(pbase_)                                                                      \
   {                                                                                                   \
     const bool live_ = h_live;                                                                        \
-    bf16x8* d_ = live_ ? lds8 + (pbase_) + h_slot : dump8;                                            \
+    opx8* d_ = live_ ? lds8 + (pbase_) + h_slot : dump8;                                            \
     EMO_S_SPLIT8(d_, __builtin_amdgcn_fmed3f(__fmaf_rn(hv[u], h_sc[u / 4][u % 4], h_sh[u / 4][u % 4]), h_lo, h_hi)) \
   }
 #define EMO_S_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[u]); }
@@ -303,7 +327,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   {                                                                                                   \
     const char* ws_ = wsrc + ((long)(stage_) * 3 + (row_)) * Cfg::WROW_BYTES;                         \
     _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) {                                           \
-      const int j = i < 4 ? wave + 4 * i : 16 + (wave & 1);                                           \
+      const int j = (SPLIT == 2 || i < 4) ? wave + 4 * i : 16 + (wave & 1);                           \
       emo_dma16_pinned(ws_ + j * 1024 + lane * 16, smem_lds + (unsigned)((row_) * Cfg::WROW_BYTES + j * 1024)); \
     }                                                                                                 \
   }
@@ -318,8 +342,8 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   if (is_halo_wave) EMO_S_ISSUE_HALO()
   for (int c = tid; c < min(a.Cin, Cfg::SCT); c += 256) {   // (without an affine the index wraps at SCT: identity entries)
     const bool real = has_affine && c < a.Cin;
-    sct[c] = real ? a.scale[(long)n * a.Cin + c] : 1.0f;
-    sct[Cfg::SCT + c] = real ? a.shift[(long)n * a.Cin + c] : 0.0f;
+    sct[c] = (real ? a.scale[(long)n * a.Cin + c] : 1.0f) * in_scale;      // (in_scale: 1, or the fp16 split's power of two)
+    sct[Cfg::SCT + c] = (real ? a.shift[(long)n * a.Cin + c] : 0.0f) * in_scale;
   }
   EMO_S_WAIT(0);
   __syncthreads();   // scale / shift tables visible
@@ -343,13 +367,13 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     EMO_S_HALO_TABLE()
   }
   EMO_S_DMA_ROW(st_begin, 2);            // issue order of the steady state: Q(cg + 1), then DMA(cg, 2)
-  if (is_halo_wave) { EMO_S_BARRIER(21); } else { EMO_S_BARRIER(13); }   // (LDS stores of P[0] visible; nothing to wait for)
+  if (is_halo_wave) { EMO_S_BARRIER(Cfg::NDMA + 16); } else { EMO_S_BARRIER(Cfg::NDMA + 8); }   // (LDS stores of P[0] visible)
   EMO_S_LOAD_FRAGS(0, 0, Cfg::OFF_P, 0, 0)
 
-  // the six partial products, smallest first: (weight plane, patch plane)
-  constexpr int NPROD = EMO_S_PRODUCTS;
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
+  constexpr int NPROD = SPLIT == 3 ? EMO_S_PRODUCTS : 3;
+  constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
 
   for (int cg = st_begin; cg < st_end; ++cg) {
     const int cgrel = cg - st_begin;
@@ -365,9 +389,9 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
         // MIDBAR(cg, r): every wave has fetched the last weight fragments of this row; the DMA of the next row has landed
         if (!(EMO_S_ABLATE & 4)) {
           if (r == 2) {
-            if (is_halo_wave) { EMO_S_BARRIER(21); } else { EMO_S_BARRIER(13); }
+            if (is_halo_wave) { EMO_S_BARRIER(Cfg::NDMA + 16); } else { EMO_S_BARRIER(Cfg::NDMA + 8); }
           } else {
-            EMO_S_BARRIER(5);
+            EMO_S_BARRIER(Cfg::NDMA);
           }
         }
         if (!(EMO_S_ABLATE & 1)) {
@@ -409,28 +433,28 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       }
 #pragma unroll
       for (int p = 0; p < NPROD; ++p) {
-        const int pa = NPROD == 6 ? PA[p] : PA[p + 6 - NPROD], pb = NPROD == 6 ? PB[p] : PB[p + 6 - NPROD];
+        const int pa = SPLIT == 2 ? PA3[p] : PA6[p + 6 - NPROD], pb = SPLIT == 2 ? PB3[p] : PB6[p + 6 - NPROD];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TP; ++j)
-            // operands swapped: the result tile is [position][channel] (conv_epilogue)
-            // (the leading product h x h accumulates in acc_lo, the five small ones in acc_hi: header comment)
-            if (pa == 0 && pb == 0)
-              acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_lo[i][j], 0, 0, 0);
-            else
-              acc_hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_hi[i][j], 0, 0, 0);
+          for (int j = 0; j < TP; ++j) {
+            // operands swapped: the result tile is [position][channel] (conv_epilogue).  The leading product accumulates in
+            // acc_lo, the small ones in acc_hi (header comment)
+            floatx16& acc_ = (pa == 0 && pb == 0) ? acc_lo[i][j] : acc_hi[i][j];
+            if constexpr (SPLIT == 3) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_, 0, 0, 0);
+            else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_, 0, 0, 0);
+          }
       }
       if (EMO_S_PIN) {
-        // 12 x { MFMA, fragment read, <= 5 VALU }, then { MFMA, <= 6 VALU, LDS store } for the rest
+        // { MFMA, fragment read, <= 5 VALU } for the 4 * NPL reads of the step, then { MFMA, <= 6 VALU, LDS store }
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 4 * NPL; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
 #pragma unroll
-        for (int k = 12; k < 4 * NPROD; ++k) {
+        for (int k = 4 * NPL; k < 4 * NPROD; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -462,15 +486,15 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TP; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_lo[i][j][r] += acc_hi[i][j][r];
+      for (int r = 0; r < 16; ++r) acc_lo[i][j][r] = SPLIT == 3 ? acc_lo[i][j][r] + acc_hi[i][j][r] : (acc_lo[i][j][r] + acc_hi[i][j][r]) * a.out_scale;
   conv_epilogue<1, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
   __syncthreads();    // the next work item's prologue overwrites the LDS the epilogue exchanged its statistics through
   }
 }
 
-template <int TR, int TW, bool UPS>
+template <int TR, int TW, bool UPS, int SPLIT = 3>
 int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
-  using Cfg = ConvCfgS<TR, TW, UPS>;
+  using Cfg = ConvCfgS<TR, TW, UPS, SPLIT>;
   if (a.Wl % TW || a.Hl % TR) return EMO_ERR_UNSUPPORTED;
   if (a.Cin % 8) return EMO_ERR_UNSUPPORTED;   // whole 8-channel groups
   if (a.scale && a.Cin > Cfg::SCT) return EMO_ERR_UNSUPPORTED;   // scale / shift tables in LDS
@@ -483,7 +507,7 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
   if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
-  auto kern = conv_igemm_bf16x3_kernel<TR, TW, UPS>;
+  auto kern = conv_igemm_bf16x3_kernel<TR, TW, UPS, SPLIT>;
   const int rc = emo_raise_dynamic_lds(kern);
   if (rc != EMO_OK) return rc;
   static const int persistent = [] { const char* e = getenv("EMO_CONV_BF16X3_PERSISTENT"); return e ? atoi(e) : 0; }();

@@ -289,11 +289,14 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
     if want_stats and ks == 1 and (D * Hl * Wl) % bp == 0:
         stats = TileStats(torch.empty((N, D * Hl * Wl // bp, layer.cout, 2), device=x.device, dtype=torch.float32), bp)
     layer.last_plan = (cfg, ks, prec)        # which kernel ran (bench.py meters the kernels separately)
-    entry = {"f32": lib.emo_conv_igemm_f32, "f16": lib.emo_conv_igemm_f16acc32, "bf16x3": lib.emo_conv_igemm_bf16x3}[prec]
-    rc = entry(hip.ptr(x), hip.ptr(layer.packed(cfg, prec)), hip.ptr(layer.bias), hip.ptr(scale),
+    entry = {"f32": lib.emo_conv_igemm_f32, "f16": lib.emo_conv_igemm_f16acc32, "bf16x3": lib.emo_conv_igemm_bf16x3,
+             "f16x2": lib.emo_conv_igemm_f16x2}[prec]
+    wpk = layer.packed(cfg, prec)
+    extra = (pack_mod.F16X2_IN_SCALE, layer.w_scale) if prec == "f16x2" else ()
+    rc = entry(hip.ptr(x), hip.ptr(wpk), hip.ptr(layer.bias), hip.ptr(scale),
                hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
                layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
-               hip.ptr(ws), hip.ptr(stats.stats) if stats is not None else None, hip.current_stream())
+               hip.ptr(ws), hip.ptr(stats.stats) if stats is not None else None, hip.current_stream(), *extra)
     hip.check(rc, f"emo_conv_igemm_{prec}[{layer.name}]")
     return (out, stats) if want_stats else out
 

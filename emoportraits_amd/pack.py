@@ -134,6 +134,31 @@ def pack_weight_bf16x3(w):
     return planes.view(-1)
 
 
+F16X2_IN_SCALE = 32.0      # emo_conv_igemm_f16x2: the staged input is multiplied by this (inputs beyond +-2047 saturate)
+
+
+def pack_weight_f16x2(w):
+    """operand layout of emo_conv_igemm_f16x2: the bf16x3 layout with two fp16 planes of w * w_scale, w_scale = the power of
+    two that puts max|w| into [512, 1024) -> (flat fp16 tensor, w_scale)"""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, kd, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("3x3 kernels only")
+    bm, kc = BF16X3_BM, BF16X3_KC
+    n_cot = -(-cout // bm)
+    n_cc = -(-cin // kc)
+    wmax = float(w.abs().max())
+    w_scale = 2.0 ** math.floor(math.log2(1023.0 / wmax)) if wmax > 0 else 1.0
+    wp = torch.zeros((n_cot * bm, n_cc * kc, kd, kh, kw), dtype=torch.float32)
+    wp[:cout, :cin] = w.float() * w_scale
+    w1 = wp.to(torch.float16)
+    w2 = (wp - w1.float()).to(torch.float16)
+    planes = torch.stack((w1, w2), 0)
+    planes = planes.view(2, n_cot, bm, n_cc, 2, 8, kd, kh, kw).permute(1, 3, 6, 7, 0, 8, 4, 2, 5).contiguous()
+    return planes.view(-1), w_scale
+
+
 def pack_weight(w, cfg):
     """w [Cout, Cin, KH, KW] or [Cout, Cin, KD, KH, KW] -> flat fp32 tensor
     [co_tile][cin chunk][kd][pair][tap][half][BM]   (stage index = chunk*KD + kd; k-local = (pair*TAPS+tap)*2+half)"""
@@ -197,7 +222,7 @@ def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
 @functools.lru_cache(maxsize=None)
 def _kc(kh, kw, cfg, precision="f32"):
     """input channels per K stage of a block config (emo_conv_pack_info / emo_conv_pack_info_f16)"""
-    if precision == "bf16x3":
+    if precision in ("bf16x3", "f16x2"):
         return BF16X3_KC
     return (conv_pack_info_f16 if precision == "f16" else conv_pack_info)(kh, kw, cfg)[1]
 
@@ -247,7 +272,9 @@ _build_precision = "f32"
 # 'f32': the exact-fp32 MFMA kernel everywhere.  'bf16x3': fp32 results on the bf16 matrix pipes -- operands split exactly into
 # three bf16 terms, six partial products, fp32 accumulation (csrc/conv_igemm_bf16x3.h) -- on the 3x3 layers that kernel covers,
 # the exact-fp32 kernel elsewhere.  'f16': reduced precision (fp16 operands), opt-in.
-PRECISIONS = ("f32", "f16", "bf16x3")
+# 'f16x2': opt-in companion of 'bf16x3' with half the matrix work -- the scaled operands as two fp16 terms (2^-24 relative),
+# three products; inputs beyond +-2047 after norm + ReLU saturate (include/emo_hip.h, emo_conv_igemm_f16x2).
+PRECISIONS = ("f32", "f16", "bf16x3", "f16x2")
 
 
 @contextlib.contextmanager
@@ -313,7 +340,7 @@ class PackedConv:
         self.pinned_cfg = cfg
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
-        if precision == "bf16x3" and not supports_bf16x3(cout, cin, kd, kh, kw):
+        if precision in ("bf16x3", "f16x2") and not supports_bf16x3(cout, cin, kd, kh, kw):
             raise ValueError(f"{name}: the split-operand kernel covers 3x3 / 3x3x3 convolutions with a multiple of 8 input channels")
         if precision == "f16" and not supports_f16(cout, cin, kd, kh, kw):
             raise ValueError(f"{name}: the fp16-operand kernel covers 3x3 / 3x3x3 / 1x1 convolutions with >= 32 output "
@@ -325,6 +352,8 @@ class PackedConv:
         if precision == "f32":
             first = choose_cfg(cout) if cfg is None else cfg
             self.packed(first if first in self.allowed else CFG_B)
+        elif precision in ("bf16x3", "f16x2"):
+            self.packed(CFG_D, precision)       # eager, like the fp32 layout: the first launch is not a host-side packing job
 
     def packed(self, cfg, precision="f32"):
         """packed weights for a block config: fp32 layout, or the fp16 operand layout (64 x 256 and 128 x 256 tiles)"""
@@ -337,6 +366,11 @@ class PackedConv:
             if "bf16x3" not in self._packed:
                 self._packed["bf16x3"] = pack_weight_bf16x3(self._weight).to(self.device)
             return self._packed["bf16x3"]
+        if precision == "f16x2":
+            if "f16x2" not in self._packed:
+                flat, self.w_scale = pack_weight_f16x2(self._weight)
+                self._packed["f16x2"] = flat.to(self.device)
+            return self._packed["f16x2"]
         cfg = _PACK_AS.get(cfg, cfg)
         if cfg not in self._packed:
             self._packed[cfg] = pack_weight(self._weight, cfg).to(self.device)
@@ -360,10 +394,10 @@ class PackedConv:
                 (CFG_D, CFG_G) if (_CFG_EFF[CFG_G] > 0 and self.kh == 3) else (CFG_D,)
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, tiles, "f16")
             return cfg, ks, "f16"
-        if self.precision == "bf16x3" and bf16x3_launch_fits(Hl, Wl, ups) and self.pinned_cfg in (None, CFG_D) and aligned16 \
-                and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
-            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), "bf16x3")
-            return cfg, ks, "bf16x3"
+        if self.precision in ("bf16x3", "f16x2") and bf16x3_launch_fits(Hl, Wl, ups) and self.pinned_cfg in (None, CFG_D) \
+                and aligned16 and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
+            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), self.precision)
+            return cfg, ks, self.precision
         pinned = None if self.pinned_cfg == CFG_G else self.pinned_cfg   # (G exists for fp16 operands only)
         allowed = (pinned,) if pinned is not None else self.allowed
         if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl):
@@ -381,6 +415,6 @@ class PackedConv:
         w, b = folded_conv(sd, prefix, kind)
         if precision is None:
             kd = w.shape[2] if w.dim() == 5 else 1
-            ok = supports_bf16x3 if _build_precision == "bf16x3" else supports_f16
+            ok = supports_bf16x3 if _build_precision in ("bf16x3", "f16x2") else supports_f16
             precision = _build_precision if ok(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1]) else "f32"
         return cls(prefix, w, b, device, cfg, precision)

@@ -206,12 +206,17 @@ class DecoderStage2:
 
 
 class Stage2:
-    def __init__(self, state_dict, cfg, device="cuda:0", precision="f32"):
+    def __init__(self, state_dict, cfg, device="cuda:0", precision=None):
         """precision 'f16': the "fp16 MFMA convs" mode of BASELINE.json configs[4] (fp16 operands, fp32 accumulation,
-        fp32 tensors); 'f32' (default): exact fp32"""
+        fp32 tensors); 'f32': exact-fp32 MFMA everywhere; 'bf16x3': fp32 on the bf16 matrix pipes in the 3x3 layers
+        (csrc/conv_igemm_bf16x3.h).  None: EMO_CONV_PRECISION, else nets.DEFAULT_PRECISION (as nets.HotPath)."""
+        import os
+        from . import nets
         from .pack import conv_precision
         self.cfg = cfg
         self.device = torch.device(device)
+        if precision is None:
+            precision = os.environ.get("EMO_CONV_PRECISION", nets.DEFAULT_PRECISION)
         self.precision = precision
         with conv_precision(precision):
             self.encoder = LocalEncoder(state_dict, "local_encoder", cfg, self.device, image_size=cfg["output_size_s2"],
@@ -237,7 +242,7 @@ class InferenceWrapper:
     def __init__(self, experiment_name, which_epoch='latest', model_file_name='', use_gpu=True, num_gpus=1,
                  fixed_bounding_box=False, project_dir='./', torch_home='', debug=False, print_model=False,
                  args_overwrite={}, pose_momentum=0.5, experiment_name_s1=None, model_file_name_s1=None, cloth=False,
-                 state_dict=None, args_path=None, embedders=None, precision="f32"):
+                 state_dict=None, args_path=None, embedders=None, precision=None):
         if not use_gpu:
             raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
         self.cloth = cloth

@@ -199,6 +199,19 @@ int emo_conv_igemm_bf16x3(const float* x, const void* wpk3, const float* bias,
                           int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
                           float* gn_stats, void* stream);
 
+/* Opt-in companion of emo_conv_igemm_bf16x3 with half the matrix work: the SCALED operands (x * in_scale after the producer's
+ * norm + ReLU, w * w_scale; powers of two) as the sum of two fp16 terms -- 22+ significand bits, exact to 2^-24 relative for
+ * |value| >= 2^-2, to 2^-25 absolute below -- and the three partial products x1 w1 + x1 w2 + x2 w1 (dropped: x2 w2 <= 2^-24),
+ * fp32 accumulation, result * 1 / (in_scale * w_scale).  Error against an fp64 convolution: that of a plain fp32 convolution
+ * (tools/split_accuracy.py; tests/test_conv_bf16x3_gpu.py).  CONTRACT: |x * in_scale| saturates at 65504 (in_scale 32: inputs
+ * beyond +-2047 after norm + ReLU are clipped), which is why it is not the default.  wpk2: fp16 weights packed like wpk3 with
+ * two planes [.. kernel row][plane 1|2][kernel column][half][BM = 64][8].  Otherwise as emo_conv_igemm_bf16x3. */
+int emo_conv_igemm_f16x2(const float* x, const void* wpk2, const float* bias,
+                         const float* scale, const float* shift, const float* res, float* out,
+                         int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
+                         int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
+                         float* gn_stats, void* stream, float in_scale, float w_scale);
+
 /* ---------------------------------------------------------------------------------------------
  * resampling / pointwise helpers (HBM-bound, one pass)
  *   emo_upsample_trilinear_f32: F.interpolate(x, scale_factor=(fd,fh,fw), mode='trilinear'), factors in {1,2}

@@ -31,13 +31,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_bf16x3_meets_the_fp32_kernel_bound(case):
-    e, got, ref = run_conv(seed=21, precision="bf16x3", **case)
+def test_conv_bf16x3_meets_the_fp32_kernel_bound(case, precision):
+    """(f16x2: the opt-in two-term fp16 split of the scaled operands, same kernel with SPLIT = 2, same bound)"""
+    e, got, ref = run_conv(seed=21, precision=precision, **case)
     assert got.shape == ref.shape
-    print("PARITY conv bf16x3:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    print(f"PARITY conv {precision}:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
     assert e < 2e-5, e
-    e2, got2, _ = run_conv(seed=21, precision="bf16x3", **case)
+    e2, got2, _ = run_conv(seed=21, precision=precision, **case)
     assert torch.equal(got, got2), "two launches on the same input differ: a race in the pipeline"
 
 
@@ -51,12 +53,14 @@ def test_conv_bf16x3_is_as_close_to_fp64_as_the_fp32_kernel():
     ref = F.conv2d(x.double(), w.double(), padding=1)
     scale = ref.abs().mean().item()
     outs = {}
-    for prec in ("f32", "bf16x3"):
+    for prec in ("f32", "bf16x3", "f16x2"):
         layer = pack.PackedConv(prec, w, None, DEV, cfg=3, precision=prec)
         y = ops.conv_igemm(x.to(DEV), layer).cpu().double()
         err = (y - ref).abs()
         outs[prec] = (err.mean().item() / scale, err.max().item() / scale)
-    print("PARITY conv vs fp64 (rel mean, rel max): fp32 MFMA %.2e %.2e | bf16x3 %.2e %.2e" % (outs["f32"] + outs["bf16x3"]))
+    print("PARITY conv vs fp64 (rel mean, rel max): fp32 MFMA %.2e %.2e | bf16x3 %.2e %.2e | f16x2 %.2e %.2e"
+          % (outs["f32"] + outs["bf16x3"] + outs["f16x2"]))
+    assert outs["f16x2"][0] <= 1.5 * outs["f32"][0] + 1e-8 and outs["f16x2"][1] <= 2.5 * outs["f32"][1] + 1e-7
     assert outs["bf16x3"][0] <= 1.1 * outs["f32"][0] + 1e-8        # mean error: no worse than the fp32 MFMA kernel
     assert outs["bf16x3"][1] <= 2.0 * outs["f32"][1] + 1e-7        # worst element of 1e6 (a tail statistic: factor 2)
 
@@ -94,3 +98,20 @@ def test_conv_bf16x3_decoder_layer_at_bench_size_agrees_with_the_fp32_kernel():
     d = (a - b).abs().max().item() / a.abs().max().item()
     print(f"PARITY conv bf16x3 vs fp32 MFMA kernel, 128->128 @512^2 x4: {d:.2e}")
     assert d < 1e-5
+
+
+def test_conv_f16x2_contract_small_values_and_saturation():
+    """the fp16 two-term split: values far below 1 keep their fp32 accuracy in absolute terms (subnormal second terms lose
+    nothing that matters), and inputs beyond 65504 / in_scale saturate -- the documented contract that keeps it opt-in"""
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17
+    layer = pack.PackedConv("s", w, None, DEV, cfg=3, precision="f16x2")
+    x = torch.randn(1, 32, 8, 64, generator=g) * torch.logspace(-6, 1, 32).view(1, 32, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    got = ops.conv_igemm(x.to(DEV), layer).cpu().double()
+    assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    big = torch.full((1, 32, 8, 64), 3000.0)                   # 3000 * 32 > 65504: clipped to 2047
+    got = ops.conv_igemm(big.to(DEV), layer).cpu()
+    lim = 65504.0 / pack.F16X2_IN_SCALE
+    ref_sat = F.conv2d(torch.full((1, 32, 8, 64), lim), w, padding=1)
+    assert (got - ref_sat).abs().max().item() <= 1e-4 * ref_sat.abs().max().item()

@@ -1,4 +1,5 @@
 """CPU tests of the host-side logic around the kernels: config contract, checkpoint schema, SN/WS folding, weight packing."""
+import math
 import os
 import sys
 
@@ -282,3 +283,18 @@ def test_bf16x3_split_is_exact_and_the_packed_layout_is_the_documented_one():
     assert lib.emo_conv_pack_info_bf16x3(3, 3, 3, ctypes.byref(bm), ctypes.byref(kc)) == 0
     assert (bm.value, kc.value) == (pack.BF16X3_BM, pack.BF16X3_KC)
     assert lib.emo_conv_pack_info_bf16x3(1, 1, 3, ctypes.byref(bm), ctypes.byref(kc)) != 0
+
+
+def test_f16x2_weight_split_and_scale():
+    """pack.pack_weight_f16x2: w * w_scale = w1 + w2 to 2^-24 relative (2^-25 absolute below 0.25), max|w| * w_scale in
+    [512, 1024), planes laid out like the bf16x3 tensor with two planes"""
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(70, 24, 3, 3, generator=g) * 0.03
+    flat, sc = pack.pack_weight_f16x2(w)
+    assert flat.dtype == torch.float16 and flat.numel() == 2 * 2 * 1 * 3 * 2 * 3 * 2 * 64 * 8
+    assert 512 <= w.abs().max().item() * sc < 1024 and math.log2(sc) == int(math.log2(sc))
+    planes = flat.view(2, 2, 1, 3, 2, 3, 2, 64, 8).float()      # [cot, cc, kd, r, plane, s, half, co, k8]
+    back = (planes[:, :, :, :, 0] + planes[:, :, :, :, 1])      # [cot, cc, kd, r, s, half, co, k8]
+    full = back.permute(0, 6, 1, 5, 7, 2, 3, 4).reshape(128, 32, 1, 3, 3)[:70, :24, 0]
+    err = (full / sc - w).abs()
+    assert (err <= w.abs() * 2.0 ** -23 + 2.0 ** -25 / sc).all()

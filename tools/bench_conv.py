@@ -88,6 +88,12 @@ def main():
             mss = timeit(lambda: ops.conv_igemm(x, ls, scale, shift, relu_in=True, ups=ups, out=out))
             rec["bf16x3_ms"] = round(mss, 3)
             rec["bf16x3_tflops"] = round(flops / mss / 1e9, 1)      # fp32-equivalent (algorithmic) FLOPs
+            if "--f16x2" in sys.argv:                                # opt-in two-term fp16 split (same kernel, SPLIT = 2)
+                l2 = pack.PackedConv("h2", w, None, DEV, precision="f16x2")
+                out = ops.conv_igemm(x, l2, scale, shift, relu_in=True, ups=ups)
+                ms2 = timeit(lambda: ops.conv_igemm(x, l2, scale, shift, relu_in=True, ups=ups, out=out))
+                rec["f16x2_ms"] = round(ms2, 3)
+                rec["f16x2_tflops"] = round(flops / ms2 / 1e9, 1)
         if not f16_only:       # what the planner picks for this launch (block config + K split), as the networks run it
             la = pack.PackedConv("auto", w, None, DEV)
             Hl_, Wl_ = odims[-2], odims[-1]

@@ -29,7 +29,8 @@ def timeit(fn, iters=7, warmup=2):
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     # --f16: opt-in fp16-operand convs (reduced precision); --bf16x3 / --f32: the two fp32 modes (default: nets.DEFAULT_PRECISION)
-    precision = "f16" if "--f16" in sys.argv else "bf16x3" if "--bf16x3" in sys.argv else "f32" if "--f32" in sys.argv else None
+    precision = ("f16" if "--f16" in sys.argv else "bf16x3" if "--bf16x3" in sys.argv else "f32" if "--f32" in sys.argv else
+                 "f16x2" if "--f16x2" in sys.argv else None)
     Bs = [int(a) for a in sys.argv[2:] if not a.startswith("--")] or [1, 4, 8, 16]
     cfg = config.hot_path_config(overrides={"image_size": S})
     sd = random_init.random_state_dict(cfg, seed=0, with_source=False)

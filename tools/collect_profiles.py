@@ -34,7 +34,8 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_bf16x3_conv.jsonl", f"{tag}_bf16x3_conv_microbench.jsonl"),
                  (f"{tag}_bf16x3_512c_pmc_conv.json", f"{tag}_bf16x3_pmc_sq_conv_512to512_at64.json"),
                  (f"{tag}_bf16x3_128c_pmc_conv.json", f"{tag}_bf16x3_pmc_sq_conv_128to128_at512.json"),
-                 (f"{tag}_driver512_f32.jsonl", f"{tag}_driver_breakdown_r512_fp32_mfma.jsonl")):
+                 (f"{tag}_driver512_f32.jsonl", f"{tag}_driver_breakdown_r512_fp32_mfma.jsonl"),
+                 (f"{tag}_driver512_f16x2.jsonl", f"{tag}_driver_breakdown_r512_f16x2.jsonl")):
     if os.path.exists(g + src):
         if dst.endswith(".json") and "bench" in dst:      # keep the JSON line only (gloo prints a banner to stdout)
             lines = [l for l in open(g + src, errors="replace") if l.lstrip().startswith("{")]
