@@ -33,7 +33,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from emoportraits_amd import config, nets, ops, parallel, random_init  # noqa: E402
+from emoportraits_amd import config, graphs, nets, ops, parallel, random_init  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, dense bf16 (v_mfma_f32_32x32x16_bf16); the bf16x3 kernel issues 6 products per fp32 product
@@ -221,10 +221,21 @@ def cpu_baseline(cfg, sd, inputs):
                 reference_classes=ref)
 
 
-def _time_loop(fn, seconds=2.0, min_iters=3, max_iters=200):
-    """median wall time of fn() (device-synchronised), bounded to about `seconds`"""
+def _time_loop(fn, seconds=2.0, min_iters=3, max_iters=200, graph=True):
+    """median wall time of fn() (device-synchronised), bounded to about `seconds`; fn (device tensors in its closure, a device
+    tensor out) is replayed from a hipGraph when it can be captured -- the host cannot enqueue ~150 launches as fast as the GPU
+    runs them in the faster modes"""
     fn()
     torch.cuda.synchronize()
+    if graph:
+        try:
+            dummy = torch.zeros(1, device="cuda")
+            eager = fn
+            gf = graphs.Graphed(lambda d: eager(), warmup=1, clone_outputs=False)
+            gf(dummy)
+            fn = lambda: gf(dummy)
+        except Exception:
+            torch.cuda.synchronize()
     ts, t_end = [], time.perf_counter() + seconds
     while len(ts) < min_iters or (time.perf_counter() < t_end and len(ts) < max_iters):
         t0 = time.perf_counter()
@@ -375,6 +386,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--raw-weights", action="store_true", help="plain seeded initialisation instead of the trained-like checkpoint")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (extras)")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay of the step")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -447,23 +459,56 @@ def main():
     srt = [t.to(dev) for t in (1 + 0.05 * torch.randn(B, 3, generator=gd), 0.3 * torch.randn(B, 3, generator=gd),
                               0.05 * torch.randn(B, 3, generator=gd))]
 
-    def step():
-        theta = ops.pose_theta(*srt)                                        # a3
-        img = hp.driver_pass(ccl, idt, pose, theta)                         # a4, a5, a1 x2 (+a2), a9
+    def step_fn(pose_, s0, s1, s2):
+        theta = ops.pose_theta(s0, s1, s2)                                  # a3
+        img = hp.driver_pass(ccl, idt, pose_, theta)                        # a4, a5, a1 x2 (+a2), a9
         return ops.pack_rgb8(img)                                           # a11 (device-side uint8 packing)
+
+    # The step is ~150 launches; the host needs 60-90 ms to enqueue them (ctypes call + output allocation each), which the GPU
+    # now outruns.  The timed region therefore replays the step from a hipGraph (one launch per step; graphs.Graphed, the same
+    # mechanism as InferenceWrapper(use_graphs=True)); --no-graph times the eager launches instead.
+    step_launch = "eager"
+    step = lambda: step_fn(pose, *srt)
+    if not a.no_graph:
+        try:
+            gstep = graphs.Graphed(step_fn, warmup=1, clone_outputs=False)
+            gstep(pose, *srt)
+            step = lambda: gstep(pose, *srt)
+            step_launch = "hipgraph"
+        except Exception as e:                                              # capture is an optimisation, never a requirement
+            sys.stderr.write(f"bench: hipGraph capture failed ({e!r}); timing eager launches\n")
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
-    conv_meter, samp_meter = ConvMeter(), SamplerMeter(frames_per_step=B)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    with conv_meter, samp_meter:
-        for _ in range(a.steps):
-            out = step()
+    for _ in range(a.steps):
+        out = step()
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+
+    # the same K steps once more, launched eagerly with HIP events around every conv / sampler launch: the per-kernel figures.
+    # An event interval is a kernel's duration only while the host is AHEAD of the GPU (otherwise it contains the wait for the
+    # launch), so each metered step is enqueued behind two graph replays of the step: ~170 ms of real work during which the host
+    # enqueues the ~150 eager launches, at the clocks of a sustained run.
+    conv_meter, samp_meter = ConvMeter(), SamplerMeter(frames_per_step=B)
+    torch.cuda.synchronize()
+    spans = []
+    for _ in range(a.steps):
+        if step_launch == "hipgraph":
+            step()
+            step()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        with conv_meter, samp_meter:
+            out = step_fn(pose, *srt)
+        s1.record()
+        spans.append((s0, s1))
+    torch.cuda.synchronize()
+    elapsed_metered = sum(x.elapsed_time(y) for x, y in spans) * 1e-3
 
     if rank != 0:
         return
@@ -504,7 +549,7 @@ def main():
              "traffic_source": (f"{os.path.relpath(pmc_path, ROOT)}: rocprofv3 --pmc passes of this command (guide-corrected "
                                 "HBM bytes per launch), NOT measured in this run" if pmc is not None else None),
              "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
-             "share_of_step": round(ms / (elapsed * 1e3), 3)}
+             "share_of_step": round(ms / (elapsed_metered * 1e3), 3)}
         if note:
             r["note"] = note
         return r
@@ -523,6 +568,10 @@ def main():
                                                  "into 3 bf16 terms, 6 partial products on the bf16 matrix pipes (error vs fp64 <= "
                                                  "the fp32 MFMA kernel's, tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
                                        "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution"}[hp.precision],
+                   "step_launch": step_launch,
+                   "metered_pass": (f"roofline figures: the same {a.steps} steps launched eagerly with HIP events around every conv / "
+                                    f"sampler launch, each behind two graph replays so that the host is ahead of the GPU; "
+                                    f"{elapsed_metered / a.steps * 1e3:.2f} ms of GPU time per metered step"),
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
         "roofline": conv_roofline(dom),
         "roofline_sampler": {"bound": "hbm", "kernel": "gs3d_cl_v2 / gs3d_cl2ncdhw_v2 (3-D grid_sample, channels-last)",
