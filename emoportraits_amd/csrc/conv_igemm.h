@@ -74,8 +74,8 @@ struct ConvArgs {
   int n_cotiles;       // ceil(Cout / BM)
   float in_scale, out_scale;   // conv_igemm_bf16x3.h, fp16 two-term split only: power of two applied to the staged input, and
                        // 1 / (in_scale * weight scale) applied to the accumulators before the epilogue
-  int n_work;          // conv_igemm_bf16x3.h only: output tiles x K splits of the launch (its blocks are persistent: a block walks
-                       // the tiles of its XCD with a stride, gridDim.x <= n_work)
+  int n_work;          // conv_igemm_bf16x3.h only: output tiles x K splits of the launch (a block walks the tiles of its
+                       // XCD with a stride; gridDim.x == n_work unless EMO_CONV_BF16X3_PERSISTENT=1)
   int ksplit;          // >= 1: the (channel chunk x depth tap) stages are divided over ksplit blocks per output tile
   int stages_per_split;
   float* partial;      // ksplit > 1: raw partial sums [ksplit][N][Cout][Dl][Hl][Wl]; bias / residual / activation are
