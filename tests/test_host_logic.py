@@ -298,3 +298,33 @@ def test_f16x2_weight_split_and_scale():
     full = back.permute(0, 6, 1, 5, 7, 2, 3, 4).reshape(128, 32, 1, 3, 3)[:70, :24, 0]
     err = (full / sc - w).abs()
     assert (err <= w.abs() * 2.0 ** -23 + 2.0 ** -25 / sc).all()
+
+
+def test_split_convolution_arithmetic_on_the_cpu():
+    """the claims csrc/conv_igemm_bf16x3.h makes about its arithmetic, checked without a GPU (tools/split_accuracy.py): products
+    of bf16 terms are exact in fp32; the six-product bf16 split is closer to an fp64 convolution than an fp32 convolution is;
+    three bf16 products are not (2^-16); the three-product fp16 split of the scaled operands is at the fp32 convolution's level"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    x = torch.relu(torch.randn(1, 64, 24, 24, generator=g) * 3 + 0.5)
+    w = torch.randn(32, 64, 3, 3, generator=g) / (64 * 9) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    scale = ref.abs().mean()
+    err = lambda y: ((y.double() - ref).abs().mean() / scale).item()
+    xs = [t.float() for t in pack.split_bf16x3(x)]
+    ws = [t.float() for t in pack.split_bf16x3(w)]
+    a, b = xs[1][0, 0, 0, :8], ws[0][0, 0, 0, :3]
+    assert torch.equal((a[:3] * b).double(), a[:3].double() * b.double())                 # 8 x 8 significand bits fit fp32
+    c64 = lambda p, q: F.conv2d(p.double(), q.double(), padding=1)
+    six = sum(c64(xs[i], ws[j]) for i, j in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)))
+    three = sum(c64(xs[i], ws[j]) for i, j in ((1, 0), (0, 1), (0, 0)))
+    e32 = err(F.conv2d(x, w, padding=1))
+    assert err(six) < 0.2 * e32 and err(three) > 5 * e32
+    sx = pack.F16X2_IN_SCALE
+    flat, sw = pack.pack_weight_f16x2(w)
+    x1 = (x * sx).to(torch.float16).float()
+    x2 = (x * sx - x1).to(torch.float16).float()
+    w1 = (w * sw).to(torch.float16).float()
+    w2 = (w * sw - w1).to(torch.float16).float()
+    f16x2 = (c64(x1, w1) + c64(x1, w2) + c64(x2, w1)) / (sx * sw)
+    assert err(f16x2) < e32
