@@ -44,7 +44,9 @@ class Graphed:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: only this thread's calls are checked against the capture -- other threads of the process (the RCCL
+        # watchdog of a multi-GPU run, the pinned-memory copier of animate_frames) may touch the runtime meanwhile
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = self.fn(*static_in)
         outs, rebuild = _flatten(out)
         return static_in, graph, outs, rebuild

@@ -142,3 +142,9 @@ def max_over_ranks(value, device=None):
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+def shutdown():
+    """destroy the process group this process initialised (RCCL communicators are released in order, not at interpreter exit)"""
+    if dist.is_initialized():
+        dist.destroy_process_group()
