@@ -8,7 +8,8 @@
 // five small products (<= 2^-8 of the leading one) go to a SECOND accumulator set whose rounding is 2^-8 smaller, and the
 // leading product's accumulator sees one MFMA per 16 channels and tap -- 8x fewer accumulation steps than the fp32 kernel's
 // K = 2 instructions; the two sets are added once in the epilogue.  The dropped terms are 30x below the accumulation error
-// (tools/split_accuracy.py, CPU); tests/test_conv_bf16x3_gpu.py holds the kernel to the fp32 MFMA kernel's error against fp64.  The bf16 pipes run at 16x the fp32 MFMA rate: six products cost 6/16 of the fp32
+// (tools/split_accuracy.py, CPU); tests/test_conv_bf16x3_gpu.py holds the kernel to the fp32 MFMA kernel's error against
+// fp64 (measured 1.7e-7 against 2.3e-7).  The bf16 pipes run at 16x the fp32 MFMA rate: six products cost 6/16 of the fp32
 // kernel's matrix time.  NOT a reduced-precision mode: tensors, norms, epilogue and accumulation are fp32 and the operands
 // keep all 24 significand bits.
 //
@@ -37,12 +38,12 @@
 // operand -- x * in_scale = x1 + x2 (+ <= 2^-24 relative; in_scale a power of two folded into the producer's affine, weights
 // scaled per layer on the host) -- and the THREE products x1 w1 + x1 w2 + x2 w1 (dropped: x2 w2 <= 2^-24), result multiplied
 // by 1 / (in_scale * w_scale) when the accumulator sets are combined.  Half the matrix work and two thirds of the LDS planes;
-// measured 277-346 TF fp32-equivalent against 188-225 (profiles/r3_f16x2_first_run.txt), error against an fp64 convolution
+// measured 279-359 TF fp32-equivalent against 189-226 (profiles/r3_conv_microbench.jsonl), error against an fp64 convolution
 // 1.09x the fp32 MFMA kernel's, end-to-end parity figures those of SPLIT = 3.  Its contract is narrower -- |x * in_scale|
 // saturates at 65504 (inputs beyond +-2047 after norm + ReLU), terms below 2^-14 / scale lose relative (not absolute)
 // precision -- which is why the exact SPLIT = 3 is the default.
 // Covers 3x3 (and 3x3x3 with the depth taps as K stages) layers on maps whose width is a multiple of 64 and height a
-// multiple of 4, optional fused nearest x2 upsample, Cin % 8 == 0; epilogue, K split and GroupNorm tile statistics are the
+// multiple of 4 (4 x 64 pixel tiles; 8 x 32 on 32-wide maps), optional fused nearest x2 upsample, Cin % 8 == 0; epilogue, K split and GroupNorm tile statistics are the
 // shared conv_epilogue.  Anything else runs conv_igemm.h.
 #pragma once
 #include <cstdlib>
@@ -57,7 +58,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef EMO_S_ABLATE
 #define EMO_S_ABLATE 0   /* timing experiments only (results are WRONG for any value != 0), bits: 1 = no weight DMA in the K loop,
                             2 = no patch loads / conversion / LDS stores in the K loop, 4 = no barriers and no vmcnt waits in the
-                            K loop, 8 = no fragment reads in the K loop (MFMAs on stale registers) */
+                            K loop, 8 = no fragment reads in the K loop (MFMAs on stale registers).  Bits 2 and 4 break the rule
+                            that nothing reuses the destination of an in-flight pinned load (the compiler sees them as dead):
+                            those builds fault on the GPU; bits 1 and 8 are safe */
 #endif
 #ifndef EMO_S_PRODUCTS
 #define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
