@@ -223,8 +223,7 @@ def cpu_baseline(cfg, sd, inputs):
 
 def _time_loop(fn, seconds=2.0, min_iters=3, max_iters=200, graph=True):
     """median wall time of fn() (device-synchronised), bounded to about `seconds`; fn (device tensors in its closure, a device
-    tensor out) is replayed from a hipGraph when it can be captured -- the host cannot enqueue ~150 launches as fast as the GPU
-    runs them in the faster modes"""
+    tensor out) is replayed from a hipGraph when it can be captured -- no launch gaps, as in the timed region of the headline"""
     fn()
     torch.cuda.synchronize()
     if graph:
@@ -464,9 +463,10 @@ def main():
         img = hp.driver_pass(ccl, idt, pose_, theta)                        # a4, a5, a1 x2 (+a2), a9
         return ops.pack_rgb8(img)                                           # a11 (device-side uint8 packing)
 
-    # The step is ~150 launches; the host needs 60-90 ms to enqueue them (ctypes call + output allocation each), which the GPU
-    # now outruns.  The timed region therefore replays the step from a hipGraph (one launch per step; graphs.Graphed, the same
-    # mechanism as InferenceWrapper(use_graphs=True)); --no-graph times the eager launches instead.
+    # The step is ~150 launches.  Launched eagerly they leave the GPU idle for 2-6 ms of an 85 ms step (gaps between dependent
+    # launches; measured 175.8-183.8 frames/s eager against 190.4-192.7 replayed, same kernels, same 84.8 ms of kernel time), so
+    # the timed region replays the step from a hipGraph (one launch per step; graphs.Graphed, the same mechanism as
+    # InferenceWrapper(use_graphs=True)); --no-graph times the eager launches instead.
     step_launch = "eager"
     step = lambda: step_fn(pose, *srt)
     if not a.no_graph:
@@ -492,8 +492,9 @@ def main():
 
     # the same K steps once more, launched eagerly with HIP events around every conv / sampler launch: the per-kernel figures.
     # An event interval is a kernel's duration only while the host is AHEAD of the GPU (otherwise it contains the wait for the
-    # launch), so each metered step is enqueued behind two graph replays of the step: ~170 ms of real work during which the host
-    # enqueues the ~150 eager launches, at the clocks of a sustained run.
+    # launch -- and the first eager step after the capture allocates its intermediates afresh: the warm-up ran on the capture's
+    # side stream, whose cached blocks the launch stream cannot reuse), so each metered step is enqueued behind two graph replays
+    # of the step: ~170 ms of real work during which the host enqueues the eager launches, at the clocks of a sustained run.
     conv_meter, samp_meter = ConvMeter(), SamplerMeter(frames_per_step=B)
     torch.cuda.synchronize()
     spans = []
