@@ -328,3 +328,29 @@ def test_split_convolution_arithmetic_on_the_cpu():
     w2 = (w * sw - w1).to(torch.float16).float()
     f16x2 = (c64(x1, w1) + c64(x1, w2) + c64(x2, w1)) / (sx * sw)
     assert err(f16x2) < e32
+
+
+@pytest.mark.parametrize("mode,expect", [(None, {"emo_conv_igemm_bf16x3": 26, "emo_conv_igemm_f32": 16}),
+                                          ("f32", {"emo_conv_igemm_f32": 42}),
+                                          ("f16x2", {"emo_conv_igemm_f16x2": 26, "emo_conv_igemm_f32": 16})])
+def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect):
+    """the host side of the released R512 driver pass without a GPU (tools/host_overhead.py: every kernel entry point of the
+    library returns at once): the launch plan sends the 26 3x3 layers the split kernel covers to it in the default mode, the
+    1x1 / narrow 3-D / head convolutions to the fp32 MFMA kernel, and the whole pass is 95 C-ABI calls"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import host_overhead
+    from emoportraits_amd import nets
+    monkeypatch.delenv("EMO_CONV_PRECISION", raising=False)
+    stub = host_overhead.install_stub(monkeypatch.setattr)
+    cfg = config.hot_path_config(overrides={"image_size": 512})
+    sd = random_init.trained_like_state_dict(cfg, seed=0, with_source=False)
+    hp = nets.HotPath(sd, cfg, "cpu", with_source=False, precision=mode)
+    assert hp.precision == (mode or nets.DEFAULT_PRECISION) and nets.DEFAULT_PRECISION == "bf16x3"
+    B = 16
+    ccl = hp.prepare_canonical(torch.empty(1, 96, 16, 64, 64))
+    stub.calls.clear()
+    img = hp.driver_pass(ccl, torch.randn(1, 512, 4, 4), torch.randn(B, 128), torch.eye(4)[None].repeat(B, 1, 1).contiguous())
+    assert tuple(img.shape) == (B, 3, 512, 512)
+    convs = {k: v for k, v in stub.calls.items() if k.startswith("emo_conv_igemm")}
+    assert convs == expect, convs
+    assert sum(stub.calls.values()) == 95, dict(stub.calls)
