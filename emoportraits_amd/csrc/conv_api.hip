@@ -66,7 +66,8 @@ extern "C" int emo_conv_tile_positions(int cfg) {
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const float* __restrict__ partial,
                                                                    const float* __restrict__ bias, const float* res,
                                                                    float* out, long total, int ksplit, int Cout, int Dl,
-                                                                   int Hl, int Wl, int act, int res_ups) {
+                                                                   int Hl, int Wl, int act, int res_ups, const int* run_if) {
+  if (run_if != nullptr && *run_if == 0) return;   // second half of a guarded fallback launch (ConvArgs::run_if)
   const long ovol = (long)Dl * Hl * Wl;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     float v = partial[i];
@@ -125,7 +126,7 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
                                const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D, int H,
                                int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups, int cfg,
                                int ksplit, float* workspace, float* gn_stats, void* stream, float in_scale = 1.0f,
-                               float w_scale = 1.0f) {
+                               float w_scale = 1.0f, int* sat_flag = nullptr, const int* run_if = nullptr) {
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
   if (gn_stats && ksplit > 1) return EMO_ERR_UNSUPPORTED;   // tile statistics come from the single-pass epilogue
   if ((long)D * H * W >= (1L << 30)) return EMO_ERR_UNSUPPORTED;                 // 32-bit byte offsets inside one channel
@@ -147,6 +148,7 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   a.gn_stats = gn_stats;
   a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0;
   a.in_scale = in_scale; a.out_scale = 1.0f / (in_scale * w_scale);
+  a.sat_flag = sat_flag; a.run_if = run_if; a.stagger_window = 0;
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;
@@ -190,7 +192,7 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   long blocks = (total + 255) / 256;
   if (blocks > 262144) blocks = 262144;
   hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, workspace, bias,
-                     res, out, total, a.ksplit, Cout, a.Dl, a.Hl, a.Wl, act, res_ups);
+                     res, out, total, a.ksplit, Cout, a.Dl, a.Hl, a.Wl, act, res_ups, run_if);
   return emo_launch_status();
 }
 
@@ -205,18 +207,20 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
 extern "C" int emo_conv_igemm_bf16x3(const float* x, const void* wpk3, const float* bias, const float* scale,
                                      const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
                                      int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
-                                     int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
+                                     int cfg, int ksplit, float* workspace, float* gn_stats, void* stream,
+                                     const int* run_if) {
   return conv_igemm_dispatch(PREC_S, x, wpk3, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
-                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream, 1.0f, 1.0f, nullptr, run_if);
 }
 
 extern "C" int emo_conv_igemm_f16x2(const float* x, const void* wpk2, const float* bias, const float* scale,
                                     const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
                                     int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
                                     int cfg, int ksplit, float* workspace, float* gn_stats, void* stream, float in_scale,
-                                    float w_scale) {
+                                    float w_scale, int* overflow_flag) {
   return conv_igemm_dispatch(PREC_S2, x, wpk2, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
-                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream, in_scale, w_scale);
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream, in_scale, w_scale,
+                             overflow_flag, nullptr);
 }
 
 extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias, const float* scale,

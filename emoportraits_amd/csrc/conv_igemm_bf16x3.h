@@ -62,6 +62,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                             that nothing reuses the destination of an in-flight pinned load (the compiler sees them as dead):
                             those builds fault on the GPU; bits 1 and 8 are safe */
 #endif
+#ifndef EMO_S_TIMING
+#define EMO_S_TIMING 0   /* measurement builds only (tools/conv_phase_timing.py): wave 0 of every work item logs s_memtime at the start
+                            of its prologue, K loop, epilogue, after the epilogue's last instruction and after its stores have
+                            drained, with HW_ID / XCC_ID, into a per-translation-unit device array read by emo_debug_conv_timing_* */
+#endif
+#if EMO_S_TIMING
+#define EMO_S_TLOG_N 65536
+#define EMO_S_TLOG_W 16
+static __device__ unsigned long long emo_s_tlog[EMO_S_TLOG_N * EMO_S_TLOG_W];
+#define EMO_S_STAMP(k_) if (EMO_S_TIMING) { tstamp[k_] = __builtin_amdgcn_s_memtime(); }
+#else
+#define EMO_S_STAMP(k_)
+#endif
+#ifndef EMO_S_STAGGER_DEFAULT
+#define EMO_S_STAGGER_DEFAULT 0   /* EMO_CONV_STAGGER overrides at run time */
+#endif
 #ifndef EMO_S_PRODUCTS
 #define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
 #endif
@@ -93,7 +109,16 @@ struct ConvCfgS {
   static constexpr int OFF_DUMP = OFF_P + 2 * PBUF;      // 64 dump slots (stores of threads without a quad)
   static constexpr int OFF_SCT = OFF_DUMP + 64;          // scale / shift tables (fp32)
   static constexpr int SCT = 1024;
-  static constexpr int LDS_BYTES = OFF_SCT * 16 + 2 * SCT * 4;
+  // epilogue (conv_epilogue_rows): per-block bias table, the GroupNorm (mean, M2) exchange, and per wave a [32 channels][64
+  // positions] fp32 transposition scratch.  The scratch lives in the patch buffer the last stage has just finished with when
+  // that is large enough, in a region of its own otherwise
+  static constexpr int EPI_ROWF = 68;                    // floats per channel row: 64 positions + 4 (bank spread of the b128 stores)
+  static constexpr int EPI_WAVE = 32 * EPI_ROWF;         // floats per wave
+  static constexpr int OFF_BIAS_F = OFF_SCT * 4 + 2 * SCT;            // (float index) [BM], permuted for the row layout
+  static constexpr int OFF_STAT_F = OFF_BIAS_F + BM;                   // [WGP][BM][2]
+  static constexpr int OFF_EPI_F = OFF_STAT_F + 2 * WGP * BM;
+  static constexpr bool EPI_IN_PATCH = PBUF * 4 >= WGP * EPI_WAVE;
+  static constexpr int LDS_BYTES = (OFF_EPI_F + (EPI_IN_PATCH ? 0 : WGP * EPI_WAVE)) * 4;
   // LDS-DMA instructions EVERY wave issues per kernel row (1 KiB each).  3 planes: 18 pieces, waves 2, 3 re-copy pieces 16,
   // 17 (uniform vmcnt counts); 2 planes: 12 pieces, 3 per wave
   static constexpr int NDMA = SPLIT == 3 ? 5 : 3;
@@ -103,8 +128,183 @@ struct ConvCfgS {
   static_assert(PR * NQ <= QPG, "one interior quad per thread and stage");
   static_assert(NHALO <= 64, "the halo pixels of a stage are staged by one wave");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-  static_assert(OFF_P * 4 >= 2 * WGP * BM, "the GroupNorm tile statistics are exchanged through the weight buffers");
 };
+
+// sum over the 16 lanes of a DPP row, every lane ends with the total (butterfly: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror -- after the quad steps the lanes of a quad agree, so the mirrors swap equal-valued quads / halves).  All 64 lanes
+// must be active.
+__device__ __forceinline__ float emo_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+
+// Epilogue of the split kernel.  conv_epilogue (conv_igemm.h) stores straight from the accumulator layout -- a lane owns one
+// channel, so one store instruction touches 32 cache lines with 32 bytes each -- and measured 16.2-16.9 k cycles per block
+// whatever the layer (tools/conv_phase_timing.py, profiles/r4_conv_phase_timing.jsonl: 15 % of a 128 -> 128 block at 512^2 in the
+// bf16 split, 21 % in the fp16 split).  Here every wave transposes its 64 channels x 64 positions through LDS, 32 channels at a
+// time, and works in ROW layout: lane (g = lane >> 4, t = lane & 15) holds positions 4t .. 4t + 3 of channel 4 * it + g, so a
+// store instruction writes 4 channels x 256 contiguous bytes (the wave's 64 positions are one 64-pixel tile row, or two
+// 32-pixel rows), the residual is read the same way, and the GroupNorm statistics of a channel are one 16-lane DPP reduction.
+//   scratch   this wave's [32][EPI_ROWF] floats      sbias  [BM] bias, entry i * 32 + g * 8 + it = channel i * 32 + 4 * it + g
+//   st_lds    [WGP][BM][2] (mean, M2) exchange
+// Same arithmetic per element as conv_epilogue: (leading + small accumulator) [* out_scale], + bias, + residual, activation;
+// tile statistics: mean over the wave's 64 values, M2 centred at that mean, waves combined with the equal-count update.
+template <int TR, int TW, int TM, int TP, int WGP, int BM, int SPLIT, int ROWF>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, floatx16 (&acc_lo)[TM][TP], floatx16 (&acc_hi)[TM][TP],
+                                                   float* scratch, const float* sbias, float* st_lds, int n, int cotile, int ptile,
+                                                   int ks, int x0, int y0, int z0, int wp, int half, int l32, int lane, int tid,
+                                                   unsigned long long* tstamp = nullptr) {
+  static_assert(TP == 2 && TM * 32 * 1 <= BM, "wave tile of 64 positions");
+  constexpr int NIT = 8;                                  // 4 channels per iteration, 32 per half
+  const int g = lane >> 4, t = lane & 15;
+  const long plane = (long)a.Hl * a.Wl;
+  const long ovol = (long)a.Dl * plane;
+  const bool to_partial = a.partial != nullptr;
+  const bool has_res = a.res != nullptr && !to_partial;
+  const bool want_stats = a.gn_stats != nullptr && !to_partial;
+  float* const obase = to_partial ? a.partial + ((long)ks * a.N + n) * a.Cout * ovol : a.out + (long)n * a.Cout * ovol;
+  const bool out_al = (reinterpret_cast<unsigned long long>(obase) & 15ull) == 0;
+  const int p = wp * (TP * 32) + 4 * t;                  // first of the lane's 4 positions inside the block's tile
+  const int y = y0 + p / TW, x = x0 + p % TW;
+  const long sp = (long)z0 * plane + (long)y * a.Wl + x;
+  const int co0 = cotile * BM + g;                        // + i * 32 + 4 * it
+
+  // residual: every load of the tile is issued before the first use.  The alignment cases are separate straight-line loops --
+  // with the test inside the loop the compiler waits vmcnt(0) behind every single load (seen in the ISA)
+  floatx4 rv[TM][NIT];
+  if (has_res) {
+    const long rvol = a.res_ups ? (long)a.Dl * (a.Hl >> 1) * (a.Wl >> 1) : ovol;
+    const long rsp = a.res_ups ? ((long)z0 * (a.Hl >> 1) + (y >> 1)) * (a.Wl >> 1) + (x >> 1) : sp;
+    const float* rbase = a.res + (long)n * a.Cout * rvol + rsp;
+    const unsigned long long ra = reinterpret_cast<unsigned long long>(a.res);
+    long roff[TM][NIT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int co = co0 + i * 32 + 4 * it;
+        roff[i][it] = (long)(co < a.Cout ? co : a.Cout - 1) * rvol;
+      }
+    if (a.res_ups) {
+      if ((ra & 7ull) == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const float2 r2 = *reinterpret_cast<const float2*>(rbase + roff[i][it]);
+            rv[i][it] = floatx4{r2.x, r2.x, r2.y, r2.y};
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const float* rp = rbase + roff[i][it];
+            const float r0 = rp[0], r1 = rp[1];
+            rv[i][it] = floatx4{r0, r0, r1, r1};
+          }
+      }
+    } else if ((ra & 15ull) == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) rv[i][it] = *reinterpret_cast<const floatx4*>(rbase + roff[i][it]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const float* rp = rbase + roff[i][it];
+          rv[i][it] = floatx4{rp[0], rp[1], rp[2], rp[3]};
+        }
+    }
+  }
+
+  EMO_S_STAMP(7)       // (measurement builds: residual loads issued)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i == 1) { EMO_S_STAMP(8) }   // (first 32 channels stored)
+    // accumulator layout -> LDS: tile (i, j), register quad q of lane (half, l32) = channel i * 32 + l32, positions
+    // j * 32 + 8 * q + 4 * half .. + 3
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        floatx4 c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sum = acc_lo[i][j][4 * q + e] + acc_hi[i][j][4 * q + e];
+          c[e] = SPLIT == 3 ? sum : sum * a.out_scale;
+        }
+        *reinterpret_cast<floatx4*>(scratch + l32 * ROWF + j * 32 + 8 * q + 4 * half) = c;
+      }
+    // (LDS operations of one wave execute in order: the row reads below see the stores above)
+    floatx4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const floatx4*>(scratch + (4 * it + g) * ROWF + 4 * t);
+    float bs[NIT];
+    if (!to_partial) {
+      const floatx4 b0 = *reinterpret_cast<const floatx4*>(sbias + i * 32 + g * 8);
+      const floatx4 b1 = *reinterpret_cast<const floatx4*>(sbias + i * 32 + g * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int co = co0 + i * 32 + 4 * it;
+      if (!to_partial) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = v[it][e] + bs[it];
+          if (has_res) u += rv[i][it][e];
+          v[it][e] = u;
+        }
+        if (a.act != EMO_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[it][e] = emo_act(v[it][e], a.act);
+        }
+      }
+      if (co < a.Cout) emo_store4(obase + (long)co * ovol + sp, v[it], out_al);
+    }
+    if (want_stats) {                                     // wave-uniform; all lanes take part in the row reductions
+      constexpr float inv_cnt = 1.0f / (float)(TP * 32);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const float s4 = (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+        const float mean = emo_row16_sum(s4) * inv_cnt;
+        float m2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[it][e] - mean; m2 = __fmaf_rn(d, d, m2); }
+        m2 = emo_row16_sum(m2);
+        if (t == 0) *reinterpret_cast<float2*>(st_lds + (wp * BM + i * 32 + 4 * it + g) * 2) = make_float2(mean, m2);
+      }
+    }
+  }
+  EMO_S_STAMP(9)
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cotile * BM + tid;
+      if (co < a.Cout) {
+        float mean = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WGP; ++w) mean += st_lds[(w * BM + tid) * 2 + 0];
+        mean *= 1.0f / (float)WGP;
+#pragma unroll
+        for (int w = 0; w < WGP; ++w) {
+          const float d = st_lds[(w * BM + tid) * 2 + 0] - mean;
+          m2 += st_lds[(w * BM + tid) * 2 + 1] + (float)(TP * 32) * d * d;
+        }
+        const long nptiles = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+        float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)n * nptiles + ptile) * a.Cout + co;
+        *dst = make_float2(mean, m2);
+      }
+    }
+  }
+}
 
 template <int TR, int TW, bool UPS, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -127,6 +327,18 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const int wp = wave;
   const int m0 = 0, p0 = wp * TP * 32;
 
+  if (a.run_if != nullptr && *a.run_if == 0) return;   // guarded fallback launch: the fp16-split launch of the layer stayed in range
+  float sat_m = 0.0f;                                    // SPLIT == 2: largest |scaled staged value| this thread has seen
+  // De-phasing.  With one block per CU and blocks of equal length, all 256 CUs run their prologues (patch + weight fetch) and
+  // their epilogues (64 KiB of output each) at the same moment, launch after launch: 16.8 MB bursts that the memory system
+  // serves at its burst rate while the matrix pipes idle (tools/conv_phase_timing.py: prologue 7-9 k cycles, epilogue 12 k,
+  // of a 76-111 k block).  The first block of every CU therefore starts late by its share of `stagger_window`; a CU takes its
+  // next block when the previous one ends, so the offsets persist for the whole launch and the bursts spread out.
+  if (a.stagger_window > 0 && blockIdx.x < 256u) {
+    const unsigned long long until = __builtin_amdgcn_s_memtime() + (((unsigned long long)((blockIdx.x * 97u) & 255u) * (unsigned)a.stagger_window) >> 8);
+    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(16);
+  }
+
   // work item -> (sample, position tile, channel tile, K split): XCD-contiguous order, channel tile fastest (conv_igemm.h).
   // A block walks the work items of its XCD's contiguous range with a stride: gridDim.x == n_work (default) is one item per
   // block; EMO_CONV_BF16X3_PERSISTENT=1 launches min(n_work, CUs) persistent blocks instead.  Measured (profiles/
@@ -141,6 +353,12 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   for (int idx8 = blockIdx.x >> 3; idx8 < n_mine; idx8 += l_stride) {
   int ks = 0;
   const int L = l_base + idx8;
+#if EMO_S_TIMING
+  unsigned long long tstamp[12];
+  for (int k = 0; k < 12; ++k) tstamp[k] = 0;
+  unsigned long long tw_wait = 0, tw_bar = 0, tw_n = 0;
+#endif
+  EMO_S_STAMP(0)
   const int cotile = L % a.n_cotiles;
   int rest = L / a.n_cotiles;
   if (a.ksplit > 1) {
@@ -164,7 +382,9 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const float in_scale = SPLIT == 3 ? 1.0f : a.in_scale;
   const int padD = a.KD >> 1;
   // bounds of the staged value: ReLU or none; the fp16 split saturates at the fp16 range (of the scaled value)
-  constexpr float CLAMP_HI = SPLIT == 3 ? __builtin_inff() : 65504.0f;
+  // (bf16 split: the largest finite bf16, 0x7f7f0000 -- the first term of a larger value would round to infinity and the residual
+  // inf - inf to NaN; +-inf inputs therefore saturate at +-3.39e38, include/emo_hip.h)
+  constexpr float CLAMP_HI = SPLIT == 3 ? 3.3895313892515355e38f : 65504.0f;
   const float clamp_lo = a.relu_in ? 0.0f : -CLAMP_HI;
 
   const int nstages_all = a.n_cchunks * a.KD;
@@ -289,11 +509,17 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   }
 // fp32 transform (GroupNorm affine of the producer, ReLU and zero padding in one v_med3: bounds [0, 0] where the pixel is
 // padding), then the exact three-way split v = h + m + l (round-to-nearest-even at every level; the residuals are exact)
-#define EMO_S_SPLIT8(dst_, val_)                                                                      \
+#define EMO_S_SPLIT8(dst_, pre_, lo_, hi_)                                                            \
   {                                                                                                   \
     opx8 h_, m_, l_;                                                                                  \
+    float t_[8];                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) t_[u] = (pre_);                                     \
+    if constexpr (SPLIT == 2) {   /* range check of the fp16 split: max |pre-clamp value| (v_max3 with |.| modifiers) */ \
+      _Pragma("unroll") for (int u = 0; u < 8; u += 2)                                                \
+        sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[u])), __builtin_fabsf(t_[u + 1])); \
+    }                                                                                                 \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                   \
-      const float v = (val_);                                                                         \
+      const float v = __builtin_amdgcn_fmed3f(t_[u], (lo_), (hi_));                                   \
       if constexpr (SPLIT == 3) {                                                                     \
         h_[u] = (__bf16)v;                                                                            \
         const float r1 = v - (float)h_[u];                                                            \
@@ -314,14 +540,14 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     const bool live_ = q_live;                                                                        \
     _Pragma("unroll") for (int i = (i0_); i < (i0_) + 2; ++i) {                                       \
       opx8* d_ = live_ ? lds8 + (pbase_) + q_slot + i * SUB : dump8;                                \
-      EMO_S_SPLIT8(d_, __builtin_amdgcn_fmed3f(__fmaf_rn(qv[u][i], q_sc[u / 4][u % 4], q_sh[u / 4][u % 4]), q_lo, q_hi)) \
+      EMO_S_SPLIT8(d_, __fmaf_rn(qv[u][i], q_sc[u / 4][u % 4], q_sh[u / 4][u % 4]), q_lo, q_hi)        \
     }                                                                                                 \
   }
 #define EMO_S_STORE_HALO(pbase_)                                                                      \
   {                                                                                                   \
     const bool live_ = h_live;                                                                        \
     opx8* d_ = live_ ? lds8 + (pbase_) + h_slot : dump8;                                            \
-    EMO_S_SPLIT8(d_, __builtin_amdgcn_fmed3f(__fmaf_rn(hv[u], h_sc[u / 4][u % 4], h_sh[u / 4][u % 4]), h_lo, h_hi)) \
+    EMO_S_SPLIT8(d_, __fmaf_rn(hv[u], h_sc[u / 4][u % 4], h_sh[u / 4][u % 4]), h_lo, h_hi)            \
   }
 #define EMO_S_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[u]); }
 #define EMO_S_TOUCH_HALO() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(hv[u]); }
@@ -335,7 +561,22 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     }                                                                                                 \
   }
 #define EMO_S_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#if EMO_S_TIMING == 2
+// measurement build: how long every wave sits in the waitcnt of a K-loop barrier (memory / LDS latency it did not hide) and in
+// the s_barrier itself (skew between the block's waves), summed per work item and wave
+#define EMO_S_BARRIER(n_)                                                                             \
+  {                                                                                                   \
+    const unsigned long long b0_ = __builtin_amdgcn_s_memtime();                                      \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n_) : "memory");                              \
+    const unsigned long long b1_ = __builtin_amdgcn_s_memtime();                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                  \
+    const unsigned long long b2_ = __builtin_amdgcn_s_memtime();                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    tw_wait += b1_ - b0_; tw_bar += b2_ - b1_; ++tw_n;                                                \
+  }
+#else
 #define EMO_S_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
+#endif
 
   // ---- prologue: the three kernel rows of the first stage by DMA, its patch converted into P[0], the loads of the second ----
   EMO_S_DMA_ROW(st_begin, 0);
@@ -347,6 +588,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     const bool real = has_affine && c < a.Cin;
     sct[c] = (real ? a.scale[(long)n * a.Cin + c] : 1.0f) * in_scale;      // (in_scale: 1, or the fp16 split's power of two)
     sct[Cfg::SCT + c] = (real ? a.shift[(long)n * a.Cin + c] : 0.0f) * in_scale;
+  }
+  if (tid < BM) {   // bias of the block's channels in the order the epilogue's row layout reads it (conv_epilogue_rows)
+    const int co_ = cotile * BM + tid;
+    const float b_ = (a.bias != nullptr && a.partial == nullptr) ? a.bias[co_ < a.Cout ? co_ : a.Cout - 1] : 0.0f;
+    smem[Cfg::OFF_BIAS_F + (tid >> 5) * 32 + (tid & 3) * 8 + ((tid & 31) >> 2)] = b_;
   }
   EMO_S_WAIT(0);
   __syncthreads();   // scale / shift tables visible
@@ -378,6 +624,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
   constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
 
+  EMO_S_STAMP(1)
   for (int cg = st_begin; cg < st_end; ++cg) {
     const int cgrel = cg - st_begin;
     const int par = cgrel & 1;
@@ -467,8 +714,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     }
     if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
   }
+  EMO_S_STAMP(2)
   EMO_S_WAIT(0);      // the re-issued loads / DMA of the clamped last stages are dead: drain them
+  EMO_S_STAMP(5)
   __syncthreads();    // ... and the LDS they target is reused by the epilogue
+  EMO_S_STAMP(6)
 #undef EMO_S_SET_STAGE
 #undef EMO_S_ISSUE_QUAD
 #undef EMO_S_ISSUE_HALO
@@ -484,13 +734,40 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #undef EMO_S_BARRIER
 #undef EMO_S_LOAD_FRAGS
 
+  {
+    // transposition scratch: the patch buffer of the last stage (every wave is past its last fragment read: barrier above)
+    const int last_par = (st_end - st_begin - 1) & 1;
+    float* const scratch = smem + (Cfg::EPI_IN_PATCH ? (Cfg::OFF_P + last_par * PBUF) * 4 : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
+    conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(a, acc_lo, acc_hi, scratch, smem + Cfg::OFF_BIAS_F,
+                                                                      smem + Cfg::OFF_STAT_F, n, cotile, ptile, ks, x0, y0, z0, wp,
+                                                                      half, l32, lane, tid
+#if EMO_S_TIMING
+                                                                      , tstamp
+#endif
+                                                                      );
+  }
+  if constexpr (SPLIT == 2) {
+    if (a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
+  }
+#if EMO_S_TIMING
+  EMO_S_STAMP(3)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  EMO_S_STAMP(4)
+  if (tid == 0 && L < EMO_S_TLOG_N) {
+    unsigned long long* t_ = emo_s_tlog + (long)L * EMO_S_TLOG_W;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TP; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_lo[i][j][r] = SPLIT == 3 ? acc_lo[i][j][r] + acc_hi[i][j][r] : (acc_lo[i][j][r] + acc_hi[i][j][r]) * a.out_scale;
-  conv_epilogue<1, TR, TW, TM, TP, WGP, BM>(a, acc_lo, acc_hi, smem, n, cotile, ptile, ks, x0, y0, z0, m0, p0, wp, half, l32, tid);
+    for (int k = 0; k < 12; ++k) t_[k] = tstamp[k];
+    t_[12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+    t_[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+    t_[14] = (unsigned long long)blockIdx.x;
+  }
+#if EMO_S_TIMING == 2
+  if (lane == 0 && L < EMO_S_TLOG_N / 4) {   // per-wave barrier accounting in the upper three quarters of the log (first N/4 items)
+    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)L * 4 + wave) * EMO_S_TLOG_W;
+    w_[0] = tw_wait; w_[1] = tw_bar; w_[2] = tw_n; w_[3] = tstamp[2] - tstamp[1];
+  }
+#endif
+#endif
   __syncthreads();    // the next work item's prologue overwrites the LDS the epilogue exchanged its statistics through
   }
 }
@@ -525,7 +802,18 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
   if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
   a.n_work = (int)(nt * cot * a.N * a.ksplit);
-  const int grid = persistent && a.n_work > ncu ? ncu : a.n_work;
+  {
+    // de-phasing window (kernel comment): a block lasts about stages x 9 steps x 4 * NPROD MFMAs x 40 cycles + 25 k; spread the
+    // CUs over one block length, but never spend more than ~1 % of the launch on it (half the window is lost at the tail)
+    static const int stagger = [] { const char* e = getenv("EMO_CONV_STAGGER"); return e ? atoi(e) : EMO_S_STAGGER_DEFAULT; }();
+    const long t_block = (long)a.stages_per_split * 9 * 4 * Cfg::NPROD * 40 + 25000;
+    const long per_cu = (a.n_work + ncu - 1) / ncu;
+    long win = t_block < per_cu * t_block / 50 ? t_block : per_cu * t_block / 50;
+    if (per_cu < 2) win = 0;
+    a.stagger_window = stagger ? (int)(win > 0x3fffffffL ? 0x3fffffffL : win) : 0;
+  }
+  // (a guarded fallback launch is normally skipped: min(n_work, CUs) blocks read the flag and leave instead of n_work)
+  const int grid = (persistent || a.run_if != nullptr) && a.n_work > ncu ? ncu : a.n_work;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)Cfg::LDS_BYTES, s, a);
   return emo_launch_status();
 }

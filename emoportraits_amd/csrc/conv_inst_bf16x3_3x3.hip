@@ -7,3 +7,12 @@ conv_launch_fn conv_lookup_bf16x3_3x3(int Wl, int ups) {
   if (Wl == 32 && !ups) return &conv_igemm_bf16x3_launch<8, 32, false>;
   return nullptr;
 }
+
+#if EMO_S_TIMING
+// measurement builds only: the per-work-item phase stamps of the last launches (conv_igemm_bf16x3.h, EMO_S_TIMING)
+extern "C" int emo_debug_conv_timing_bf16x3(unsigned long long* host_out, int n_items) {
+  if (!host_out || n_items < 0 || n_items > EMO_S_TLOG_N) return EMO_ERR_BAD_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return EMO_ERR_BAD_ARG;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(emo_s_tlog), (size_t)n_items * EMO_S_TLOG_W * sizeof(unsigned long long)) == hipSuccess ? EMO_OK : EMO_ERR_BAD_ARG;
+}
+#endif

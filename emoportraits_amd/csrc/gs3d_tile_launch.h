@@ -39,12 +39,12 @@ static int raise_dynamic_lds(K kern) {
   static std::set<std::pair<const void*, int>> raised;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return EMO_ERR_UNSUPPORTED;
   const std::pair<const void*, int> key(reinterpret_cast<const void*>(kern), dev);
   std::lock_guard<std::mutex> lock(mu);
   if (!raised.count(key)) {
     e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return EMO_ERR_UNSUPPORTED;   // (not a raw hipError_t: callers see EMO_* codes only)
     raised.insert(key);
   }
   return EMO_OK;
@@ -105,7 +105,11 @@ int launch_tile(const float* vol, const float* grid, const float* theta, const f
   p.upb = upb;
   p.ngroups = emo_cdiv(p.units, upb);
   const size_t lds = (size_t)lds_kib * 1024;
-  p.cap_slots = (int)((lds - TILE_HDR_BYTES - tile_scratch_bytes(IN_P4, OUT_P4, threads)) / 16);
+  // header + scratch + a stage of at least 64 slots, or the tuning word is rejected (an unsigned underflow here would let the
+  // kernel stage far beyond the LDS it was given; a tile whose box does not fit the stage takes the kernel's direct-gather path)
+  const size_t lds_fixed = (size_t)TILE_HDR_BYTES + tile_scratch_bytes(IN_P4, OUT_P4, threads);
+  if (lds < lds_fixed + 1024) return EMO_ERR_BAD_ARG;
+  p.cap_slots = (int)((lds - lds_fixed) / 16);
   if (p.cap_slots > TILE_MAXI * threads) p.cap_slots = TILE_MAXI * threads;
   if (threads == 256) {
     if (lv == 0) return launch_tile_cfg<PAD, MODE, IN_P4, OUT_P4, 256, 1>(p, lds, s);

@@ -30,9 +30,14 @@ class Graphed:
     Outputs live in the graph's static buffers: by default they are cloned so they survive the next replay; pass
     clone_outputs=False to hand out the static buffers themselves (valid until the next call with the same signature)."""
 
-    def __init__(self, fn, warmup=2, clone_outputs=True, max_signatures=8):
+    def __init__(self, fn, warmup=2, clone_outputs=True, max_signatures=8, eager_calls=0):
+        """eager_calls: calls per input signature that run fn directly before the signature is captured -- a wrapper that
+        turns graphs on by default pays the capture (two warm-up runs + one captured run + static buffers) only for shapes
+        that actually recur"""
         self.fn, self.warmup, self.clone_outputs, self.max_signatures = fn, warmup, clone_outputs, max_signatures
+        self.eager_calls = eager_calls
         self._cache = {}
+        self._seen = {}
 
     def _capture(self, tensors):
         static_in = [t.clone() for t in tensors]
@@ -54,6 +59,11 @@ class Graphed:
     def __call__(self, *tensors):
         key = tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors)
         entry = self._cache.get(key)
+        if entry is None and self._seen.get(key, 0) < self.eager_calls:
+            if len(self._seen) > 64:
+                self._seen.clear()
+            self._seen[key] = self._seen.get(key, 0) + 1
+            return self.fn(*tensors)
         if entry is None:
             if len(self._cache) >= self.max_signatures:
                 self._cache.pop(next(iter(self._cache)))

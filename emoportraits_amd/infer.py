@@ -94,7 +94,7 @@ class InferenceWrapper:
                  fixed_bounding_box=False, project_dir='./', folder='mp_logs', model_='va',
                  torch_home='', debug=False, print_model=False, print_params=True, args_overwrite={}, state_dict=None,
                  pose_momentum=0.5, rank=0, args_path=None, embedders=None, head_pose_regressor_path=None,
-                 use_graphs=False, precision=None):
+                 use_graphs=True, precision=None):
         if not use_gpu:
             raise RuntimeError("emoportraits_amd runs on MI355X only: use_gpu=False is not supported (no CPU path)")
         if model_ != 'va':
@@ -134,16 +134,21 @@ class InferenceWrapper:
         self.embedders = {**native, **dict(embedders or {})}
         # hipGraph replay of the per-frame sequences (emoportraits_amd/graphs.py); only this repo's own executors are
         # captured, user-supplied embedder callables always run eagerly
+        # On by default: a drop-in user calls forward() one frame at a time, which is launch-bound without the replay
+        # (bench.py extras: emotion_driver_forward_fps, latency_b1_ms).  The first call of an input signature runs eagerly,
+        # the second captures, later ones replay (use_graphs='eager_first' semantics; use_graphs=False never captures).
         self.use_graphs = bool(use_graphs)
         self._graphed = {}
         if self.use_graphs:
+            first = 0 if use_graphs == 'capture_first' else 1
             self._graphed['driver'] = graphs.Graphed(
-                lambda pose, theta: self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, pose, theta))
+                lambda pose, theta: self.hot_path.driver_pass(self._canonical_cl, self.idt_embed, pose, theta), eager_calls=first)
             hp_net, ex_net = native.get('head_pose_regressor'), native.get('expression_embedder')
             if hp_net is not None and self.embedders['head_pose_regressor'] is hp_net:
-                self._graphed['head_pose_regressor'] = graphs.Graphed(lambda crop: hp_net.forward(crop, True))
+                self._graphed['head_pose_regressor'] = graphs.Graphed(lambda crop: hp_net.forward(crop, True), eager_calls=first)
             if ex_net is not None and self.embedders['expression_embedder'] is ex_net:
-                self._graphed['expression_embedder'] = graphs.Graphed(lambda crop, theta: ex_net(crop, theta, True)[:2])
+                self._graphed['expression_embedder'] = graphs.Graphed(lambda crop, theta: ex_net(crop, theta, True)[:2],
+                                                                      eager_calls=first)
 
         self.fixed_bounding_box = fixed_bounding_box
         self.momentum = 0.01

@@ -294,6 +294,9 @@ class HotPath:
         'bf16x3' fp32 results on the bf16 matrix pipes in the 3x3 layers csrc/conv_igemm_bf16x3.h covers -- every operand split
                  exactly into three bf16 terms, six partial products, fp32 accumulation: held to the same parity bounds as 'f32'
                  (tests/test_conv_bf16x3_gpu.py, tests/test_bench_config_parity_gpu.py) -- exact-fp32 MFMA elsewhere;
+        'f16x2'  the same layers with half the matrix work: the scaled operands as two fp16 terms, three products (error against
+                 fp64 that of an fp32 convolution).  Its operand range (+-2047 after norm + ReLU) is checked on the device by
+                 every launch; a guarded bf16x3 launch recomputes a layer whose check fired, so results never depend on it;
         'f16'    opt-in reduced precision (BASELINE configs[4]): fp16 MFMA operands with fp32 accumulation in the 3x3 / 1x1
                  convolutions; tensors in HBM stay fp32"""
         self.cfg = cfg
@@ -331,10 +334,22 @@ class HotPath:
                 from .encoder import LocalEncoder
                 self.local_encoder = LocalEncoder(sd, "local_encoder_nw", cfg, self.device)
 
+    def _clear_flags(self):
+        """'f16x2': zero the overflow words of the fp16-split layers at the start of a pass (one fill kernel, stream-ordered,
+        captured with the pass).  A word raised during the pass makes the guarded bf16x3 launch behind that layer recompute it
+        (ops.conv_igemm); overflow_events() reports which layers did."""
+        if self.precision == "f16x2":
+            ops.clear_overflow_flags(self.device)
+
+    def overflow_events(self):
+        """{slot: layer name} of the fp16-split layers whose range check fired since the last pass started (host sync)"""
+        return ops.overflow_events(self.device)
+
     # ---- per identity -------------------------------------------------------------------------------
     def source_pass(self, source_img_masked, idt_embed, source_pose_embed, theta_src, keep=False):
         """-> canonical volume [1,c,d,s,s] (NCDHW, as the reference caches it in self.target_latent_volume)"""
         c, d, s = self.c, self.d, self.s
+        self._clear_flags()
         latents = self.local_encoder(source_img_masked)
         emb = self.embed(source_pose_embed, idt_embed)
         delta_xy = self.xy_generator(emb)
@@ -359,6 +374,7 @@ class HotPath:
     # ---- per driver batch ---------------------------------------------------------------------------
     def driver_pass(self, canonical_cl, idt_embed, target_pose_embed, theta_drv, keep=False):
         B = target_pose_embed.shape[0]
+        self._clear_flags()
         emb = self.embed(target_pose_embed, idt_embed)
         delta_uv = self.uv_generator(emb)
         lay = "ndhwc"

@@ -78,7 +78,10 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
         raise ValueError(f"volume batch {Nv} does not match grid batch {N}")
     stride = 0 if (Nv == 1 and N > 1) else C * D * H * W
     if (in_layout == "ncdhw" and out_layout == "ncdhw" and variant == 0 and C % 4 == 0 and C >= 16
-            and Nv * C * D * H * W >= (1 << 20)):
+            and Nv * C * D * H * W >= (1 << 20)
+            # limits of the channels-last kernels the redirect lands on (csrc/grid_sample3d.hip): 64 tap records + C rows of 65
+            # floats in <= 64 KiB of LDS, 32-bit byte offsets inside one volume.  Beyond them the direct NCDHW gather runs
+            and C * 260 + 5120 <= 65536 and C * D * H * W * 4 < 2 ** 32):
         # the reference's call shape (model.grid_sample(NCDHW, grid) -> NCDHW, va.py:264-265) on a large volume: one repack
         # to channels-last + the channels-last gather (NCDHW out) moves 51 MB in 23 us, the NCDHW gather needs 35 us
         # (its 4-byte corner loads are bound by the vector-memory instruction rate; profiles/r3_sampler_seam.jsonl)
@@ -292,13 +295,29 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
     entry = {"f32": lib.emo_conv_igemm_f32, "f16": lib.emo_conv_igemm_f16acc32, "bf16x3": lib.emo_conv_igemm_bf16x3,
              "f16x2": lib.emo_conv_igemm_f16x2}[prec]
     wpk = layer.packed(cfg, prec)
-    extra = (pack_mod.F16X2_IN_SCALE, layer.w_scale) if prec == "f16x2" else ()
-    rc = entry(hip.ptr(x), hip.ptr(wpk), hip.ptr(layer.bias), hip.ptr(scale),
-               hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W, layer.kd,
-               layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks,
-               hip.ptr(ws), hip.ptr(stats.stats) if stats is not None else None, hip.current_stream(), *extra)
-    hip.check(rc, f"emo_conv_igemm_{prec}[{layer.name}]")
+    common = (hip.ptr(layer.bias), hip.ptr(scale), hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W,
+              layer.kd, layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks, hip.ptr(ws),
+              hip.ptr(stats.stats) if stats is not None else None, hip.current_stream())
+    if prec == "f16x2":
+        # the fp16 split checks its operand range on the device (overflow word of the layer); the guarded bf16x3 launch behind
+        # it recomputes the layer with exact operands when the word is raised -- no host synchronisation, graph-capturable
+        flag = pack_mod.overflow_flag_ptr(x.device, layer.flag_slot) if F16X2_GUARD else None
+        rc = entry(hip.ptr(x), hip.ptr(wpk), *common, pack_mod.F16X2_IN_SCALE, layer.w_scale, flag)
+        hip.check(rc, f"emo_conv_igemm_f16x2[{layer.name}]")
+        if F16X2_GUARD:
+            rc = lib.emo_conv_igemm_bf16x3(hip.ptr(x), hip.ptr(layer.packed(cfg, "bf16x3")), *common, flag)
+            hip.check(rc, f"emo_conv_igemm_bf16x3[{layer.name}, guarded]")
+    else:
+        extra = (None,) if prec == "bf16x3" else ()
+        rc = entry(hip.ptr(x), hip.ptr(wpk), *common, *extra)
+        hip.check(rc, f"emo_conv_igemm_{prec}[{layer.name}]")
     return (out, stats) if want_stats else out
+
+
+# A/B switch (measurements only): 0 launches the fp16 split without its device-side range check and guarded recomputation
+F16X2_GUARD = __import__("os").environ.get("EMO_F16X2_GUARD", "1") != "0"
+clear_overflow_flags = pack_mod.clear_overflow_flags
+overflow_events = pack_mod.overflow_events
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -136,6 +136,46 @@ def pack_weight_bf16x3(w):
 
 F16X2_IN_SCALE = 32.0      # emo_conv_igemm_f16x2: the staged input is multiplied by this (inputs beyond +-2047 saturate)
 
+# Overflow flags of the fp16-split layers (include/emo_hip.h, emo_conv_igemm_f16x2): one int32 word per layer in a per-device
+# pool.  A launch raises its layer's word when a staged value left the fp16 range; the guarded emo_conv_igemm_bf16x3 launch that
+# ops.conv_igemm issues right behind it then recomputes the layer with exact operands.  Words are sticky until
+# clear_overflow_flags(): a stale 1 only costs an unnecessary (correct) recomputation.
+_FLAG_POOL_WORDS = 4096
+_flag_pools = {}     # device -> [int32 tensor, next free slot, {slot: layer name}]
+
+
+def _flag_pool(device):
+    import torch as _t
+    key = str(_t.device(device))
+    if key not in _flag_pools:
+        _flag_pools[key] = [_t.zeros(_FLAG_POOL_WORDS, dtype=_t.int32, device=device), 0, {}]
+    return _flag_pools[key]
+
+
+def overflow_flag_slot(device, name=None):
+    pool = _flag_pool(device)
+    slot = pool[1] % _FLAG_POOL_WORDS        # (wraps after 4096 layers: sharing a word is conservative, never wrong)
+    pool[1] += 1
+    pool[2][slot] = name
+    return slot
+
+
+def overflow_flag_ptr(device, slot):
+    return ctypes.c_void_p(_flag_pool(device)[0].data_ptr() + 4 * slot)
+
+
+def clear_overflow_flags(device):
+    """zero every overflow word of the device's pool (stream-ordered: one fill kernel).  HotPath / Stage2 call it at the start
+    of a pass."""
+    _flag_pool(device)[0].zero_()
+
+
+def overflow_events(device):
+    """{slot: layer name} of the words that are raised right now (host synchronisation: diagnostics and tests)"""
+    pool = _flag_pool(device)
+    raised = pool[0].nonzero().flatten().tolist()
+    return {s: pool[2].get(s) for s in raised}
+
 
 def pack_weight_f16x2(w):
     """operand layout of emo_conv_igemm_f16x2: the bf16x3 layout with two fp16 planes of w * w_scale, w_scale = the power of
@@ -272,8 +312,9 @@ _build_precision = "f32"
 # 'f32': the exact-fp32 MFMA kernel everywhere.  'bf16x3': fp32 results on the bf16 matrix pipes -- operands split exactly into
 # three bf16 terms, six partial products, fp32 accumulation (csrc/conv_igemm_bf16x3.h) -- on the 3x3 layers that kernel covers,
 # the exact-fp32 kernel elsewhere.  'f16': reduced precision (fp16 operands), opt-in.
-# 'f16x2': opt-in companion of 'bf16x3' with half the matrix work -- the scaled operands as two fp16 terms (2^-24 relative),
-# three products; inputs beyond +-2047 after norm + ReLU saturate (include/emo_hip.h, emo_conv_igemm_f16x2).
+# 'f16x2': companion of 'bf16x3' with half the matrix work -- the scaled operands as two fp16 terms (2^-24 relative), three
+# products.  Its operand range (inputs beyond +-2047 after norm + ReLU saturate) is checked ON THE DEVICE by every launch, and a
+# guarded bf16x3 launch of the same layer recomputes it when the check fires (include/emo_hip.h, emo_conv_igemm_f16x2).
 PRECISIONS = ("f32", "f16", "bf16x3", "f16x2")
 
 
@@ -354,6 +395,9 @@ class PackedConv:
             self.packed(first if first in self.allowed else CFG_B)
         elif precision in ("bf16x3", "f16x2"):
             self.packed(CFG_D, precision)       # eager, like the fp32 layout: the first launch is not a host-side packing job
+            if precision == "f16x2":            # the guarded exact recomputation behind a raised overflow flag (ops.conv_igemm)
+                self.packed(CFG_D, "bf16x3")
+                self.flag_slot = overflow_flag_slot(device, name)
 
     def packed(self, cfg, precision="f32"):
         """packed weights for a block config: fp32 layout, or the fp16 operand layout (64 x 256 and 128 x 256 tiles)"""

@@ -101,8 +101,13 @@ def broadcast_source_cache(cache, shapes=None, src=0, device=None, world=None, r
             tensors.append(t)
             rows += [t.dim()] + list(t.shape) + [0] * (_MAX_DIMS - t.dim())
         header.copy_(torch.tensor(rows, dtype=torch.int64))
-    if not dist.is_initialized():
+    if world == 1 and not dist.is_initialized():
         return dict(zip(names, tensors))
+    if not dist.is_initialized():
+        raise RuntimeError(f"broadcast_source_cache(world={world}) without a process group: call init_distributed() first")
+    if world != dist.get_world_size():
+        # e.g. InferenceWrapper(num_gpus=1) under torchrun: a collective the other ranks never join would hang
+        raise RuntimeError(f"world={world} does not match the process group's {dist.get_world_size()} ranks")
     if not exchange_shapes:
         if shapes is None or any(n not in shapes for n in names):
             raise RuntimeError("exchange_shapes=False needs the shape of every entry on every rank")

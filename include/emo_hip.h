@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 5
+#define EMO_ABI_VERSION 6
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
@@ -191,26 +191,43 @@ int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias
  * cfg 3 (64 x 256 tile = 4 x 64 pixels, or 8 x 32 on 32-wide maps without upsample; one block per CU); output
  * width % 64 == 0 and height % 4 == 0, or width 32 and height % 8 == 0; Cin % 8 == 0; x 16-byte
  * aligned; Cin <= 1024 when scale / shift are given.  wpk3: bf16 weights packed
- * [co_tile][Cin chunk of 16][kd][kernel row][plane h|m|l][kernel column][half][BM = 64][8] (channel in chunk = 8*half + 0..7). */
+ * [co_tile][Cin chunk of 16][kd][kernel row][plane h|m|l][kernel column][half][BM = 64][8] (channel in chunk = 8*half + 0..7).
+ * Operand range (tests/test_conv_bf16x3_gpu.py::test_conv_bf16x3_operand_contract): the split is exact for every finite staged
+ * value up to the largest finite bf16, 3.3895e38 (0x7f7f0000); staged values beyond it, +-inf included, SATURATE there (their
+ * first bf16 term would round to infinity and the residual inf - inf to NaN) -- the exact-fp32 kernel passes +-inf on.  A NaN
+ * input is staged as the lower clamp bound (0 with relu_in, else -3.39e38) by the v_med3 that also applies ReLU and zero padding,
+ * exactly as in emo_conv_igemm_f32.  Signed zeros and fp32 subnormals are split like any other value (a subnormal's terms are
+ * bf16 subnormals; the matrix pipe may flush them: absolute error <= 2^-126 per product).
+ * run_if   NULL, or a device word: the launch (both halves of a K-split launch) does nothing unless *run_if != 0 when it starts
+ *          executing -- the guarded fallback behind emo_conv_igemm_f16x2's overflow_flag (same stream, launched right after it). */
 int emo_conv_pack_info_bf16x3(int KH, int KW, int cfg, int* BM, int* KC);
 int emo_conv_igemm_bf16x3(const float* x, const void* wpk3, const float* bias,
                           const float* scale, const float* shift, const float* res, float* out,
                           int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
                           int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
-                          float* gn_stats, void* stream);
+                          float* gn_stats, void* stream, const int* run_if);
 
-/* Opt-in companion of emo_conv_igemm_bf16x3 with half the matrix work: the SCALED operands (x * in_scale after the producer's
+/* Companion of emo_conv_igemm_bf16x3 with half the matrix work: the SCALED operands (x * in_scale after the producer's
  * norm + ReLU, w * w_scale; powers of two) as the sum of two fp16 terms -- 22+ significand bits, exact to 2^-24 relative for
  * |value| >= 2^-2, to 2^-25 absolute below -- and the three partial products x1 w1 + x1 w2 + x2 w1 (dropped: x2 w2 <= 2^-24),
  * fp32 accumulation, result * 1 / (in_scale * w_scale).  Error against an fp64 convolution: that of a plain fp32 convolution
- * (tools/split_accuracy.py; tests/test_conv_bf16x3_gpu.py).  CONTRACT: |x * in_scale| saturates at 65504 (in_scale 32: inputs
- * beyond +-2047 after norm + ReLU are clipped), which is why it is not the default.  wpk2: fp16 weights packed like wpk3 with
- * two planes [.. kernel row][plane 1|2][kernel column][half][BM = 64][8].  Otherwise as emo_conv_igemm_bf16x3. */
+ * (tools/split_accuracy.py; tests/test_conv_bf16x3_gpu.py).  wpk2: fp16 weights packed like wpk3 with two planes
+ * [.. kernel row][plane 1|2][kernel column][half][BM = 64][8].  Otherwise as emo_conv_igemm_bf16x3.
+ * CONTRACT, checked on the device: |x * in_scale| saturates at 65504 (in_scale 32: staged inputs beyond +-2047 are clipped).
+ *   overflow_flag  NULL (unchecked), or a device word the caller has zeroed: every thread tracks the largest |x * in_scale| it
+ *          stages BEFORE the clamp (one v_max3 per two values) and the launch stores 1 there if any exceeded 65504 (+-inf
+ *          included; a NaN is staged as the lower clamp bound like everywhere else and does not raise it).  Halo pixels are
+ *          checked by every block that stages them; a value that is only ever clamped away by relu_in (below -65504) still
+ *          raises the flag -- conservative.
+ *   The caller then launches emo_conv_igemm_bf16x3 on the same arguments with run_if = overflow_flag on the same stream: it
+ *   recomputes `out` (and gn_stats) only when the flag was raised -- no host synchronisation, hipGraph-capturable; the pair
+ *   is what emoportraits_amd.ops.conv_igemm issues for a precision="f16x2" layer
+ *   (tests/test_conv_bf16x3_gpu.py::test_conv_f16x2_overflow_is_detected_and_recomputed). */
 int emo_conv_igemm_f16x2(const float* x, const void* wpk2, const float* bias,
                          const float* scale, const float* shift, const float* res, float* out,
                          int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
                          int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
-                         float* gn_stats, void* stream, float in_scale, float w_scale);
+                         float* gn_stats, void* stream, float in_scale, float w_scale, int* overflow_flag);
 
 /* ---------------------------------------------------------------------------------------------
  * resampling / pointwise helpers (HBM-bound, one pass)

@@ -100,18 +100,115 @@ def test_conv_bf16x3_decoder_layer_at_bench_size_agrees_with_the_fp32_kernel():
     assert d < 1e-5
 
 
-def test_conv_f16x2_contract_small_values_and_saturation():
+def test_conv_f16x2_contract_small_values_and_saturation(monkeypatch):
     """the fp16 two-term split: values far below 1 keep their fp32 accuracy in absolute terms (subnormal second terms lose
-    nothing that matters), and inputs beyond 65504 / in_scale saturate -- the documented contract that keeps it opt-in"""
+    nothing that matters); inputs beyond 65504 / in_scale saturate in the UNCHECKED kernel (EMO_F16X2_GUARD=0 semantics: no
+    overflow word, no guarded recomputation) -- the range the device-side check of the default mode guards"""
     g = torch.Generator().manual_seed(6)
     w = torch.randn(64, 32, 3, 3, generator=g) / 17
     layer = pack.PackedConv("s", w, None, DEV, cfg=3, precision="f16x2")
     x = torch.randn(1, 32, 8, 64, generator=g) * torch.logspace(-6, 1, 32).view(1, 32, 1, 1)
     ref = F.conv2d(x.double(), w.double(), padding=1)
+    ops.clear_overflow_flags(DEV)
     got = ops.conv_igemm(x.to(DEV), layer).cpu().double()
     assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert ops.overflow_events(DEV) == {}
+    monkeypatch.setattr(ops, "F16X2_GUARD", False)
     big = torch.full((1, 32, 8, 64), 3000.0)                   # 3000 * 32 > 65504: clipped to 2047
     got = ops.conv_igemm(big.to(DEV), layer).cpu()
     lim = 65504.0 / pack.F16X2_IN_SCALE
     ref_sat = F.conv2d(torch.full((1, 32, 8, 64), lim), w, padding=1)
     assert (got - ref_sat).abs().max().item() <= 1e-4 * ref_sat.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [dict(relu_in=True, affine=True, res=False, ksplit=None, ups=False),
+                                  dict(relu_in=False, affine=False, res=True, ksplit=None, ups=True),
+                                  dict(relu_in=True, affine=True, res=True, ksplit=3, ups=False)])
+def test_conv_f16x2_overflow_is_detected_and_recomputed(case):
+    """adversarial activations for the fp16 split (include/emo_hip.h, emo_conv_igemm_f16x2): one staged value beyond +-2047 raises
+    the layer's overflow word on the device, and the guarded emo_conv_igemm_bf16x3 launch behind it rewrites output and tile
+    statistics -- BIT-IDENTICAL to a plain bf16x3 launch of the layer.  In range, the word stays 0 and the result is the fp16
+    split's.  No host synchronisation is involved in the decision."""
+    g = torch.Generator().manual_seed(31)
+    N, Cin, Cout, H, W = 2, 48, 128, 16, 64
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    x = torch.randn(N, Cin, H, W, generator=g)
+    ups = case["ups"]
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    sc = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV) if case["affine"] else None
+    sh = (torch.randn(N, Cin, generator=g) * 0.2).to(DEV) if case["affine"] else None
+    res = torch.randn(N, Cout, Ho, Wo, generator=g).to(DEV) if case["res"] else None
+    l2 = pack.PackedConv("adv", w, b, DEV, cfg=3, precision="f16x2")
+    l3 = pack.PackedConv("adv3", w, b, DEV, cfg=3, precision="bf16x3")
+    kw = dict(relu_in=case["relu_in"], ups=ups, res=res, ksplit=case["ksplit"], want_stats=True)
+
+    def run(layer, xin):
+        out, st = ops.conv_igemm(xin.to(DEV), layer, sc, sh, **kw)
+        return out.cpu(), (None if st is None else st.stats.cpu())
+
+    ops.clear_overflow_flags(DEV)
+    in_range, st_in = run(l2, x)
+    assert ops.overflow_events(DEV) == {}, "in-range input raised the overflow word"
+    exact, st_exact = run(l3, x)
+    assert not torch.equal(in_range, exact)                       # (the fp16 split ran: its rounding differs from the bf16 split's)
+    assert (in_range - exact).abs().max().item() <= 2e-5 * exact.abs().max().item()
+
+    for big in (5000.0, -5000.0, float("inf")):
+        if case["relu_in"] and big < 0 and case["affine"]:
+            pass                                                  # (clamped away by the ReLU, still flagged: conservative)
+        xa = x.clone()
+        xa[1, 7, 5, 33] = big                                     # one element; halo of two tiles when H is tiled by 4
+        ops.clear_overflow_flags(DEV)
+        got, st_got = run(l2, xa)
+        ev = ops.overflow_events(DEV)
+        assert list(ev.values()) == ["adv"], (big, ev)
+        want, st_want = run(l3, xa)
+        assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(want, nan=7.0)), big
+        if st_got is not None:
+            assert torch.equal(torch.nan_to_num(st_got, nan=7.0), torch.nan_to_num(st_want, nan=7.0))
+    # the word is sticky until cleared: the next (in-range) call still recomputes -- exact result, never a wrong one
+    again, _ = run(l2, x)
+    assert torch.equal(again, exact)
+    ops.clear_overflow_flags(DEV)
+    again, _ = run(l2, x)
+    assert torch.equal(again, in_range)
+
+
+def test_conv_bf16x3_operand_contract():
+    """non-finite and extreme operands of the bf16 split, as include/emo_hip.h states them: finite values up to the largest
+    finite bf16 are split exactly (FLT_MAX-scale inputs give what the exact-fp32 kernel gives); +-inf SATURATE at +-3.39e38
+    instead of turning into NaN through the residual inf - inf; a NaN is staged as the lower clamp bound (as in the fp32
+    kernel); signed zeros and fp32 subnormals behave like the fp32 kernel to within 2^-126 per product"""
+    g = torch.Generator().manual_seed(41)
+    Cin, Cout, H, W = 16, 64, 4, 64
+    w = torch.zeros(Cout, Cin, 3, 3)
+    w[:, 0, 1, 1] = torch.linspace(-1, 1, Cout)                   # centre tap of channel 0 only: out[co] = w * x[0]
+    l3 = pack.PackedConv("c3", w, None, DEV, cfg=3, precision="bf16x3")
+    l1 = pack.PackedConv("c1", w, None, DEV, cfg=3, precision="f32")
+    BF16_MAX = 3.3895313892515355e38
+
+    def both(x, **kw):
+        return ops.conv_igemm(x.to(DEV), l3, **kw).cpu(), ops.conv_igemm(x.to(DEV), l1, **kw).cpu()
+
+    x = torch.zeros(1, Cin, H, W)
+    x[0, 0, 1, 5], x[0, 0, 1, 6], x[0, 0, 2, 7] = 3.0e38, -3.0e38, BF16_MAX   # finite, at the top of the range: exact split
+    a, b = both(x)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    x = torch.zeros(1, Cin, H, W)
+    x[0, 0, 1, 5], x[0, 0, 2, 9] = float("inf"), float("-inf")
+    a, b = both(x)
+    assert not torch.isnan(a).any(), "inf - inf in the split residual"
+    want = torch.zeros_like(a)
+    want[0, :, 1, 5] = w[:, 0, 1, 1] * BF16_MAX
+    want[0, :, 2, 9] = w[:, 0, 1, 1] * -BF16_MAX
+    assert (a - want).abs().max().item() <= 1e-6 * BF16_MAX       # saturated, finite
+    assert torch.isinf(b[0, -1, 1, 5])                            # the exact-fp32 kernel passes inf on (documented difference)
+    x = torch.zeros(1, Cin, H, W)
+    x[0, 0, 1, 5] = float("nan")
+    a, b = both(x, relu_in=True)
+    assert torch.equal(a, b) and not torch.isnan(a).any()         # NaN -> lower clamp bound (0 with ReLU) in both kernels
+    x = torch.full((1, Cin, H, W), -0.0)
+    x[0, 0, 1, 5], x[0, 0, 1, 6], x[0, 0, 1, 7] = 1e-40, -3e-39, 1.1754942e-38   # fp32 subnormals
+    a, b = both(x)
+    assert (a - b).abs().max().item() <= 2e-38 and (a.double() - b.double()).abs().max().item() <= 2 ** -126 * 1.01

@@ -55,7 +55,10 @@ def _all_layouts(vol_cpu, grid_cpu=None, theta_cpu=None, pm="zeros", shared=Fals
         for tag, var in TILE_TUNINGS:
             o = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="p4", variant=ops.TILE | var)
             res["p4_tile" + tag] = ops.volume_from_p4(o).cpu()
-            res["p4_tile_to_ncdhw" + tag] = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="ncdhw", variant=ops.TILE | var).cpu()
+            # (P4 -> NCDHW keeps 4 KiB of transposition scratch next to the stage: the 2 KiB tuning is rejected there,
+            # test_tile_tuning_word_with_too_little_lds_is_rejected; the tiny stage is 6 KiB for this pair)
+            var_n = ops.tile_variant((8, 8, 8), lds_kib=6) if tag == "_tiny_stage" else var
+            res["p4_tile_to_ncdhw" + tag] = ops.grid_sample3d(vp4, grid, theta, pm, in_layout="p4", out_layout="ncdhw", variant=ops.TILE | var_n).cpu()
     if vol.shape[4] % 4 == 0:
         for tag, var in TILE_TUNINGS:
             res["ncdhw_tile" + tag] = ops.grid_sample3d(vol, grid, theta, pm, variant=ops.TILE | var).cpu()
@@ -82,6 +85,30 @@ def test_random_shapes_vs_torch_cpu(pm, shape):
     ref = F.grid_sample(vol, grid, padding_mode=pm, align_corners=False)
     for name, got in _all_layouts(vol, grid, pm=pm).items():
         assert torch.equal(got, ref), f"{name} {pm} {shape}"
+
+
+def test_tile_tuning_word_with_too_little_lds_is_rejected():
+    """lds_kib below header + scratch + a minimal stage: EMO_ERR_BAD_ARG instead of an unsigned underflow of the stage size
+    (gs3d_tile_launch.h); the same word is fine where no scratch is needed"""
+    g = torch.Generator().manual_seed(11)
+    vol = torch.randn(1, 8, 4, 8, 8, generator=g).to(DEV)
+    grid = (torch.rand(1, 4, 8, 8, 3, generator=g) * 2 - 1).to(DEV)
+    vp4 = ops.volume_to_p4(vol)
+    small = ops.TILE | ops.tile_variant((8, 8, 4), lds_kib=2)
+    with pytest.raises(RuntimeError, match="BAD_ARG"):
+        ops.grid_sample3d(vp4, grid, in_layout="p4", out_layout="ncdhw", variant=small)
+    ref = F.grid_sample(vol.cpu(), grid.cpu(), align_corners=False)
+    assert torch.equal(ops.volume_from_p4(ops.grid_sample3d(vp4, grid, in_layout="p4", out_layout="p4", variant=small)).cpu(), ref)
+
+
+def test_reference_call_shape_beyond_the_channels_last_limits_takes_the_direct_gather():
+    """grid_sample3d(NCDHW, grid) -> NCDHW redirects large volumes through the channels-last kernels; C = 256 exceeds their
+    LDS rows (C * 260 + 5120 <= 64 KiB) and must run the direct NCDHW gather instead of raising (ops.py)"""
+    g = torch.Generator().manual_seed(12)
+    vol = torch.randn(1, 256, 4, 32, 32, generator=g)
+    grid = torch.rand(1, 3, 9, 11, 3, generator=g) * 2.2 - 1.1
+    got = ops.grid_sample3d(vol.to(DEV), grid.to(DEV)).cpu()
+    assert torch.equal(got, F.grid_sample(vol, grid, align_corners=False))
 
 
 def test_odd_channel_count_ncdhw_only():
@@ -187,7 +214,8 @@ def test_delta_grid_mode_equals_materialised_warp(pm):
     vp4 = ops.volume_to_p4(v)
     for tag, var in TILE_TUNINGS:
         assert torch.equal(ops.grid_sample3d(v, delta=delta.to(DEV), padding_mode=pm, variant=ops.TILE | var).cpu(), ref), tag
-        assert torch.equal(ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="ncdhw", variant=ops.TILE | var).cpu(), ref), tag
+        var_n = ops.tile_variant((8, 8, 8), lds_kib=6) if tag == "_tiny_stage" else var   # (P4 -> NCDHW needs its 4 KiB scratch)
+        assert torch.equal(ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="ncdhw", variant=ops.TILE | var_n).cpu(), ref), tag
         o = ops.grid_sample3d(vp4, delta=delta.to(DEV), padding_mode=pm, in_layout="p4", out_layout="p4", variant=ops.TILE | var)
         assert torch.equal(ops.volume_from_p4(o).cpu(), ref), tag
     vcl = ops.volume_to_channels_last(v)

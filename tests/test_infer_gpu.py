@@ -197,12 +197,15 @@ def test_graph_replay_equals_eager_and_follows_a_new_identity(project, tiny):
     src_kw = dict(crop=False, source_mask=torch.ones(1, 1, S, S), custome_idt_embed=tiny["idt_embed"],
                   custome_source_pose_embed=tiny["source_pose_embed"], custome_source_theta_embed=tiny["theta_src"])
     drv_kw = dict(crop=False, custome_target_pose_embed=tiny["target_pose_embed"], custome_target_theta_embed=tiny["theta_drv"])
-    eager, graphed = _wrapper(project), _wrapper(project, use_graphs=True)
+    # (graphs are on by default -- first call of a signature eager, second captured, then replay; `eager` turns them off)
+    eager, graphed = _wrapper(project, use_graphs=False), _wrapper(project)
+    assert graphed.use_graphs and not eager.use_graphs and not eager._graphed
     outs = {}
     for name, w in (("eager", eager), ("graphed", graphed)):
         w.forward(source_image=tiny["img"], **src_kw)
         a = w.forward(**drv_kw)[1].clone()
-        b = w.forward(**drv_kw)[1].clone()                       # second call = pure replay
+        b = w.forward(**drv_kw)[1].clone()                       # second call: captured + replayed
+        assert torch.equal(w.forward(**drv_kw)[1], b)            # third call: pure replay
         w.forward(source_image=tiny["img"].flip(-1), **src_kw)   # new identity
         c = w.forward(**drv_kw)[1].clone()
         outs[name] = (a, b, c)

@@ -1,0 +1,126 @@
+"""The PRODUCT path under world_size 2 (notebooks/infer.py:94-105 is how the reference initialises
+torch.distributed, it never shards frames): two freshly spawned processes -- on the one GPU of a test box through the gloo
+backend (EMO_FORCE_DEVICE=0, EMO_DIST_BACKEND=gloo; RCCL refuses two ranks per device), on two GPUs through RCCL -- each build
+an InferenceWrapper(num_gpus=2, use_graphs=True); rank 0 alone runs the source pass, both call share_source(), both run
+animate() and animate_frames() on the same 33 driver frames.  The parent asserts that every rank produced exactly its
+contiguous shard, that the shards tile the frame range, and that their union equals a single-rank run BIT FOR BIT."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 33
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from emoportraits_amd import parallel
+import torch
+from notebooks.infer import InferenceWrapper
+from test_infer_gpu import _toy_embedders
+tiny = torch.load(os.path.join(%(root)r, "tests", "golden", "tiny_hotpath.pt"), weights_only=False)
+num_gpus = int(os.environ["WORLD_SIZE"])
+w = InferenceWrapper(experiment_name="exp", model_file_name="model.pth", project_dir=%(project)r, folder="logs",
+                     print_params=False, num_gpus=num_gpus, use_graphs=True)
+assert (w.rank, w.world) == (int(os.environ["RANK"]), num_gpus)
+w.embedders.update(_toy_embedders(tiny, w.device))
+S = tiny["cfg"]["image_size"]
+if w.rank == 0:                      # the source pass runs on ONE rank ...
+    w.forward(source_image=tiny["img"], crop=False, source_mask=torch.ones(1, 1, S, S), custome_idt_embed=tiny["idt_embed"],
+              custome_source_pose_embed=tiny["source_pose_embed"], custome_source_theta_embed=tiny["theta_src"])
+else:
+    assert w.target_latent_volume is None
+if num_gpus > 1:
+    w.share_source(src_rank=0)       # ... and its cache reaches the others by one broadcast
+assert w._canonical_cl is not None
+N = %(n)d
+g = torch.Generator().manual_seed(17)
+pose = torch.randn(N, tiny["target_pose_embed"].shape[1], generator=g) * 0.5
+srt = (1 + 0.05 * torch.randn(N, 3, generator=g), 0.3 * torch.randn(N, 3, generator=g), 0.05 * torch.randn(N, 3, generator=g))
+frames = (torch.rand(N, S, S, 3, generator=g) * 255).to(torch.uint8)
+out = {"animate": {}, "animate_frames": {}, "rank": w.rank, "world": w.world}
+for rep in range(2):                 # second sweep: graph replay
+    for b0, u8 in w.animate(pose, srt, batch_size=4):
+        for j in range(u8.shape[0]):
+            out["animate"][b0 + j] = u8[j].cpu()
+for b0, u8 in w.animate_frames(frames, batch_size=4, ring=2):
+    for j in range(u8.shape[0]):
+        out["animate_frames"][b0 + j] = u8[j].clone()
+torch.save(out, os.path.join(%(project)r, "rank%%d_of%%d.pt" %% (w.rank, w.world)))
+parallel.barrier()
+parallel.shutdown()
+print("WORKER_OK", w.rank, flush=True)
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _project(tmp_path, golden_dir):
+    from emoportraits_amd import config
+    tiny = torch.load(os.path.join(golden_dir, "tiny_hotpath.pt"), weights_only=False)
+    exp = tmp_path / "logs" / "exp"
+    (exp / "checkpoints").mkdir(parents=True)
+    cfg = config.hot_path_config(overrides=tiny["cfg"])
+    with open(exp / "args.txt", "wt") as f:
+        for k, v in cfg.items():
+            f.write(f"{k}: {v}\n")
+        f.write("experiment_name: exp\nuse_seg: True\n")
+    torch.save(tiny["state_dict"], exp / "checkpoints" / "model.pth")
+    return str(tmp_path)
+
+
+def _spawn(world, project, share_gpu):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        for k in ("EMO_DIST_BACKEND", "EMO_FORCE_DEVICE", "EMO_DIST_FORCE_INIT"):
+            env.pop(k, None)
+        if share_gpu and world > 1:
+            env.update(EMO_FORCE_DEVICE="0", EMO_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % dict(root=ROOT, project=project, n=N_FRAMES)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "WORKER_OK" in o, o[-4000:]
+    return [torch.load(os.path.join(project, f"rank{r}_of{world}.pt"), weights_only=False) for r in range(world)]
+
+
+def _check(world, tmp_path, golden_dir, share_gpu):
+    from emoportraits_amd import parallel
+    project = _project(tmp_path, golden_dir)
+    single = _spawn(1, project, share_gpu)[0]
+    assert sorted(single["animate"]) == list(range(N_FRAMES)) == sorted(single["animate_frames"])
+    ranks = _spawn(world, project, share_gpu)
+    for kind in ("animate", "animate_frames"):
+        covered = []
+        for r, out in enumerate(ranks):
+            lo, hi = parallel.shard_range(N_FRAMES, r, world)
+            assert sorted(out[kind]) == list(range(lo, hi)), (kind, r, sorted(out[kind]))     # its contiguous shard, nothing else
+            covered += list(out[kind])
+            for i, frame in out[kind].items():
+                assert torch.equal(frame, single[kind][i]), f"{kind}: frame {i} of rank {r} differs from the single-rank run"
+        assert sorted(covered) == list(range(N_FRAMES))                                       # the shards tile the range
+    print(f"PARITY two-rank product path: world {world}, {N_FRAMES} frames, animate + animate_frames bit-identical to 1 rank")
+
+
+def test_two_ranks_share_one_gpu_gloo(tmp_path, golden_dir):
+    _check(2, tmp_path, golden_dir, share_gpu=True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_two_ranks_two_gpus_rccl(tmp_path, golden_dir):
+    _check(2, tmp_path, golden_dir, share_gpu=False)
