@@ -526,14 +526,21 @@ def main():
         ms, fl, n = by_k[k]
         tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         pmc, pmc_path = None, ""
-        pat = "r*_pmc_conv_bf16x3_traffic.json" if k == "bf16x3" else "r*_pmc_conv_traffic.json"
+        pat = {"bf16x3": "r*_pmc_conv_bf16x3_traffic.json", "f16x2": "r*_pmc_conv_f16x2_traffic.json"}.get(k, "r*_pmc_conv_traffic.json")
         found = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", pat)))[-1:]
         if found:
             try:
                 pmc, pmc_path = json.load(open(found[0])).get("hbm_bytes_per_launch"), found[0]
             except Exception:
                 pmc = None
-        if k == "bf16x3":
+        if k == "f16x2":
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+            name = ("conv_igemm_bf16x3_kernel<SPLIT = 2> (fp32 3x3 conv on the fp16 matrix pipes: scaled operands as two fp16 terms, 3 "
+                    "v_mfma_f32_32x32x16_f16 products per fp32 product, fp32 accumulation; operand range checked on the device, "
+                    "guarded bf16x3 recomputation launch behind every layer)")
+            note = ("achieved = algorithmic fp32 FLOPs / event time of the launch PAIR (fp16-split launch + its guarded, normally "
+                    "skipped, bf16x3 launch); peak = 2500 TF dense fp16 / 3 products")
+        elif k == "bf16x3":
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0
             name = ("conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes: exact 3-way operand split, 6 "
                     "v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation)")
@@ -568,6 +575,11 @@ def main():
                    "conv_arithmetic": {"bf16x3": "fp32 tensors and accumulation; 3x3 decoder convs: every fp32 operand split exactly "
                                                  "into 3 bf16 terms, 6 partial products on the bf16 matrix pipes (error vs fp64 <= "
                                                  "the fp32 MFMA kernel's, tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
+                                       "f16x2": "fp32 tensors and accumulation; 3x3 decoder convs: every scaled fp32 operand as two "
+                                                "fp16 terms (2^-24 relative), 3 partial products on the fp16 matrix pipes (error vs fp64 "
+                                                "1.1x the fp32 MFMA kernel's); the operand range is checked on the device by every "
+                                                "launch and a guarded bf16x3 launch recomputes a layer that left it "
+                                                "(tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
                                        "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution"}[hp.precision],
                    "step_launch": step_launch,
                    "metered_pass": (f"roofline figures: the same {a.steps} steps launched eagerly with HIP events around every conv / "

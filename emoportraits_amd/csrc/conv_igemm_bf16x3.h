@@ -20,7 +20,8 @@
 //                                                           channel group by LDS-DMA (host-packed, host-split tensor) as soon
 //                                                           as its last fragments have been read: two rows of latency budget
 //       patch    P[2][plane][8-channel group][slot][8]      16 input channels of the (4+2) x (64+2) source patch, split on
-//                                                           the way in (conv_igemm_f16.h staging: quads, halo wave, slots)
+//                                                           the way in (16-byte quads; the halo pixels ride on the lanes
+//                                                           that own no quad; slots as in conv_igemm_f16.h)
 //   * K loop over channel groups cg (16 channels [x depth tap]) x kernel rows r x tap columns s; one step (cg, r, s) =
 //     12 ds_read_b128 (3 planes x (2 weight + 2 patch fragments)) feeding 24 MFMAs (4 tiles x 6 products) = 768 matrix
 //     cycles per SIMD; fragments are read one step ahead into three rotating register sets.
@@ -29,11 +30,11 @@
 //     the next row (issued two rows ago) is waited for right there -- the fragments of its step 0 are prefetched behind it.
 //   * the patch of group cg + 1 is converted during (cg, row 0, step 2) .. (cg, row 1, step 1) from registers loaded during
 //     cg - 1; the loads of cg + 2 are issued behind MIDBAR(cg, 1).  vmcnt bookkeeping (all VMEM of the loop is inline asm;
-//     every wave issues exactly 5 DMA instructions per row, 8 quad loads, the halo wave 8 more):
+//     every wave issues exactly 5 DMA instructions per row and 8 quad loads per stage):
 //         behind MIDBAR(cg,0): DMA(cg+1,0)    behind MIDBAR(cg,1): DMA(cg+1,1), Q(cg+2)    behind MIDBAR(cg,2): DMA(cg+1,2)
 //         MIDBAR(cg,0) needs DMA(cg,1) and Q(cg+1), leaves DMA(cg,2) in flight: vmcnt(5)
 //         MIDBAR(cg,1) needs DMA(cg,2), leaves DMA(cg+1,0): vmcnt(5)
-//         MIDBAR(cg,2) needs DMA(cg+1,0), leaves DMA(cg+1,1) and Q(cg+2): vmcnt(13), halo wave vmcnt(21)
+//         MIDBAR(cg,2) needs DMA(cg+1,0), leaves DMA(cg+1,1) and Q(cg+2): vmcnt(13)
 // SPLIT = 2 (opt-in, emo_conv_igemm_f16x2): the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 terms of the scaled
 // operand -- x * in_scale = x1 + x2 (+ <= 2^-24 relative; in_scale a power of two folded into the producer's affine, weights
 // scaled per layer on the host) -- and the THREE products x1 w1 + x1 w2 + x2 w1 (dropped: x2 w2 <= 2^-24), result multiplied
@@ -94,11 +95,12 @@ struct ConvCfgS {
   static constexpr int PR = TRS + 2;                     // source rows of the patch
   static constexpr int NQ = TWS / 4;                     // interior quads per row
   static constexpr int NQ1 = NQ + 1;                     // + the pseudo-quad that holds the row's two halo pixels
-  static constexpr int SUB = ((PR * NQ1 + 11) / 16) * 16 + 4;   // slots per sub-row: >= PR * NQ1 and = 4 (mod 16)
+  static constexpr int SUB = ((PR * NQ1 + 4 + 11) / 16) * 16 + 4;   // slots per sub-row: = 4 (mod 16), >= PR * NQ1 used + 4 dump
+                                                         // slots at its tail (pixels a lane loads but does not own)
   static constexpr int CHS = 4 * SUB;                    // slots per 8-channel group
   static constexpr int NG = 2;                           // 8-channel groups per stage
   static constexpr int QPG = 128;                        // threads per group
-  static constexpr int NHALO = NG * 2 * PR;
+  static constexpr int NHQ = 2 * PR;                     // halo pixels of a group: they ride on the group's lanes that own no quad
   // everything below in 16-byte slots
   static constexpr int WPLANE = 3 * 2 * BM;              // one plane of a kernel row: [s][half][BM]
   static constexpr int WROW = NPL * WPLANE;              // one kernel row (all planes)
@@ -106,8 +108,7 @@ struct ConvCfgS {
   static constexpr int PPL = NG * CHS;                   // one plane of the patch
   static constexpr int PBUF = NPL * PPL;
   static constexpr int OFF_P = 3 * WROW;                 // after the three kernel-row weight buffers
-  static constexpr int OFF_DUMP = OFF_P + 2 * PBUF;      // 64 dump slots (stores of threads without a quad)
-  static constexpr int OFF_SCT = OFF_DUMP + 64;          // scale / shift tables (fp32)
+  static constexpr int OFF_SCT = OFF_P + 2 * PBUF;       // scale / shift tables (fp32)
   static constexpr int SCT = 1024;
   // epilogue (conv_epilogue_rows): per-block bias table, the GroupNorm (mean, M2) exchange, and per wave a [32 channels][64
   // positions] fp32 transposition scratch.  The scratch lives in the patch buffer the last stage has just finished with when
@@ -125,8 +126,8 @@ struct ConvCfgS {
   static_assert(WROW_BYTES == (SPLIT == 3 ? 18 : 12) * 1024, "DMA pieces per kernel row");
   static_assert(TR * TW == BP, "planar position tile of BP pixels");
   static_assert(TWS % 4 == 0 && (!UPS || (TR % 2 == 0 && TW % 2 == 0)), "whole quads");
-  static_assert(PR * NQ <= QPG, "one interior quad per thread and stage");
-  static_assert(NHALO <= 64, "the halo pixels of a stage are staged by one wave");
+  static_assert(PR * NQ + NHQ <= QPG, "one interior quad or one halo pixel per thread and stage");
+  static_assert(SUB >= PR * NQ1 + 4, "dump slots");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -314,8 +315,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   constexpr int NPL = Cfg::NPL;
   constexpr int BM = Cfg::BM, TM = Cfg::TM, TP = Cfg::TP, WGP = Cfg::WGP, KC = Cfg::KC;
   constexpr int PR = Cfg::PR, NQ = Cfg::NQ, NQ1 = Cfg::NQ1, SUB = Cfg::SUB, CHS = Cfg::CHS, QPG = Cfg::QPG;
-  constexpr int NHALO = Cfg::NHALO, TWS = Cfg::TWS, WPLANE = Cfg::WPLANE, WROW = Cfg::WROW, PPL = Cfg::PPL, PBUF = Cfg::PBUF;
-  constexpr int HALO_WAVE = 3;
+  constexpr int NHQ = Cfg::NHQ, TWS = Cfg::TWS, WPLANE = Cfg::WPLANE, WROW = Cfg::WROW, PPL = Cfg::PPL, PBUF = Cfg::PBUF;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   opx8* const lds8 = reinterpret_cast<opx8*>(smem);
@@ -392,25 +392,32 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const int st_end = min(nstages_all, st_begin + a.stages_per_split);
   const char* wsrc = reinterpret_cast<const char*>(a.wpk) + ((long)cotile * nstages_all) * (3 * Cfg::WROW_BYTES);
 
-  // ---- staging map (conv_igemm_f16.h): thread t owns quad t % QPG of channel group t / QPG; lane l of HALO_WAVE owns halo
-  //      pixel l (group, patch row, side) ----
+  // ---- staging map: thread t belongs to channel group t / QPG; within the group, lane u < PR * NQ owns interior quad u (4
+  //      consecutive pixels of one patch row), lane PR * NQ + 2 * row + side owns one halo pixel.  A halo lane issues the SAME
+  //      16-byte loads as everybody else -- the aligned quad that contains its pixel (left: x0 - 4 .. x0 - 1, element 3;
+  //      right: x0 + TWS .. + 3, element 0) -- and runs the same conversion; the three pixels it does not own go to dump slots
+  //      at the tail of their sub-row.  No wave does extra work: with a dedicated halo wave (8 dword loads + an 8-value
+  //      conversion per stage on wave 3 only) the other three waves sat 700-850 cycles per stage in the K loop's barriers
+  //      (tools/conv_phase_timing.py on an EMO_S_TIMING=2 build, profiles/r4_conv_phase_waves.jsonl) ----
   const int q_u = tid % QPG;
   const int q_g = __builtin_amdgcn_readfirstlane(tid / QPG);
-  const int q_r = q_u / NQ, q_c = q_u - q_r * NQ;
+  const bool is_quad = q_u < PR * NQ;
+  const int hq = q_u - PR * NQ;
+  const bool is_halo = !is_quad && hq < NHQ;
+  const int h_side = hq & 1;
+  const int q_r = is_quad ? q_u / NQ : (is_halo ? hq >> 1 : 0);
+  const int q_c = is_quad ? q_u - q_r * NQ : 0;
   const int q_y = y0s - 1 + q_r;
-  const bool q_live = q_u < PR * NQ;
-  const bool q_ok = q_live && (unsigned)q_y < (unsigned)a.H;
-  const unsigned q_off = q_ok ? (unsigned)(q_y * a.W + x0s + 4 * q_c) * 4u : 0u;
-  const int q_slot = q_live ? q_g * CHS + q_r * NQ1 + q_c : 0;             // + i * SUB for pixel i, + plane * PPL
-
-  const bool is_halo_wave = wave == HALO_WAVE;
-  const int h_g = lane / (2 * PR), h_rem = lane - h_g * (2 * PR);
-  const int h_r = h_rem >> 1, h_side = h_rem & 1;
-  const int h_y = y0s - 1 + h_r, h_x = h_side ? x0s + TWS : x0s - 1;
-  const bool h_live = lane < NHALO;
-  const bool h_ok = h_live && (unsigned)h_y < (unsigned)a.H && (unsigned)h_x < (unsigned)a.W;
-  const unsigned h_off = h_ok ? (unsigned)(h_y * a.W + h_x) * 4u : 0u;
-  const int h_slot = h_live ? h_g * CHS + h_side * SUB + h_r * NQ1 + NQ : 0;
+  const int q_x = is_quad ? x0s + 4 * q_c : (h_side ? x0s + TWS : x0s - 4);     // first pixel of the lane's 16-byte load
+  const bool q_ok = (is_quad || is_halo) && (unsigned)q_y < (unsigned)a.H && q_x >= 0 && q_x < a.W;
+  const unsigned q_off = q_ok ? (unsigned)(q_y * a.W + q_x) * 4u : 0u;
+  int q_sl[4];                                                                    // LDS slot of pixel i (+ plane * PPL)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int dump = q_g * CHS + i * SUB + PR * NQ1 + (q_u & 3);
+    const int own = is_quad ? q_g * CHS + i * SUB + q_r * NQ1 + q_c : q_g * CHS + h_side * SUB + q_r * NQ1 + NQ;
+    q_sl[i] = (is_quad || (is_halo && i == (h_side ? 0 : 3))) ? own : dump;
+  }
 
   constexpr int TPH = TP;
   floatx16 acc_lo[TM][TPH], acc_hi[TM][TPH];
@@ -452,18 +459,16 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 
   float* const sct = smem + Cfg::OFF_SCT * 4;
   const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem);
-  opx8* const dump8 = lds8 + Cfg::OFF_DUMP + lane;
 
   floatx4 qv[8];
-  float hv[8];
-  float q_lo, q_hi, h_lo, h_hi;
-  floatx4 q_sc[2], q_sh[2], h_sc[2], h_sh[2];
+  float q_lo, q_hi;
+  floatx4 q_sc[2], q_sh[2];
   const emo_intx4 xrs = emo_raw_buffer(xn);
   unsigned usoff[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)u * (unsigned)DHW * 4u));
 
-  int q_tix, h_tix;
+  int q_tix;
   int n_ci0, n_zu;
   bool n_zv;
 #define EMO_S_SET_STAGE(stage_)                                                                       \
@@ -490,23 +495,6 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix;                               \
     q_sc[0] = t4_[0]; q_sc[1] = t4_[1]; q_sh[0] = t4_[Cfg::SCT / 4]; q_sh[1] = t4_[Cfg::SCT / 4 + 1]; \
   }
-#define EMO_S_ISSUE_HALO()                                                                            \
-  {                                                                                                   \
-    const int c0_ = n_ci0 + h_g * 8;                                                                  \
-    const bool cv_ = c0_ < a.Cin;                                                                     \
-    const int cs_ = cv_ ? c0_ : 0;                                                                    \
-    const bool keep_ = h_ok && cv_ && n_zv;                                                           \
-    h_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
-    h_hi = keep_ ? CLAMP_HI : 0.0f;                                                           \
-    const unsigned vo_ = h_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u; \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) hv[u] = emo_bload_pinned(xrs, vo_, usoff[u]);       \
-    h_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
-  }
-#define EMO_S_HALO_TABLE()                                                                            \
-  {                                                                                                   \
-    const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + h_tix;                               \
-    h_sc[0] = t4_[0]; h_sc[1] = t4_[1]; h_sh[0] = t4_[Cfg::SCT / 4]; h_sh[1] = t4_[Cfg::SCT / 4 + 1]; \
-  }
 // fp32 transform (GroupNorm affine of the producer, ReLU and zero padding in one v_med3: bounds [0, 0] where the pixel is
 // padding), then the exact three-way split v = h + m + l (round-to-nearest-even at every level; the residuals are exact)
 #define EMO_S_SPLIT8(dst_, pre_, lo_, hi_)                                                            \
@@ -532,25 +520,18 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       }                                                                                               \
     }                                                                                                 \
     (dst_)[0] = h_;                                                                                   \
-    (dst_)[live_ ? PPL : 0] = m_;                                                                     \
-    if constexpr (SPLIT == 3) (dst_)[live_ ? 2 * PPL : 0] = l_;                                       \
+    (dst_)[PPL] = m_;                                                                                 \
+    if constexpr (SPLIT == 3) (dst_)[2 * PPL] = l_;                                                   \
   }
-#define EMO_S_STORE_QUAD(pbase_, i0_)                                                                 \
+// pixels i0_ .. i0_ + n_ - 1 of the lane's 16-byte loads (every lane stores all four: its own, or into dump slots)
+#define EMO_S_STORE_QUAD(pbase_, i0_, n_)                                                             \
   {                                                                                                   \
-    const bool live_ = q_live;                                                                        \
-    _Pragma("unroll") for (int i = (i0_); i < (i0_) + 2; ++i) {                                       \
-      opx8* d_ = live_ ? lds8 + (pbase_) + q_slot + i * SUB : dump8;                                \
+    _Pragma("unroll") for (int i = (i0_); i < (i0_) + (n_); ++i) {                                    \
+      opx8* d_ = lds8 + (pbase_) + q_sl[i];                                                           \
       EMO_S_SPLIT8(d_, __fmaf_rn(qv[u][i], q_sc[u / 4][u % 4], q_sh[u / 4][u % 4]), q_lo, q_hi)        \
     }                                                                                                 \
   }
-#define EMO_S_STORE_HALO(pbase_)                                                                      \
-  {                                                                                                   \
-    const bool live_ = h_live;                                                                        \
-    opx8* d_ = live_ ? lds8 + (pbase_) + h_slot : dump8;                                            \
-    EMO_S_SPLIT8(d_, __fmaf_rn(hv[u], h_sc[u / 4][u % 4], h_sh[u / 4][u % 4]), h_lo, h_hi)            \
-  }
 #define EMO_S_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[u]); }
-#define EMO_S_TOUCH_HALO() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch(hv[u]); }
 // one kernel row of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
 #define EMO_S_DMA_ROW(stage_, row_)                                                                   \
   {                                                                                                   \
@@ -583,7 +564,6 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   EMO_S_DMA_ROW(st_begin, 1);
   EMO_S_SET_STAGE(st_begin);
   EMO_S_ISSUE_QUAD()
-  if (is_halo_wave) EMO_S_ISSUE_HALO()
   for (int c = tid; c < min(a.Cin, Cfg::SCT); c += 256) {   // (without an affine the index wraps at SCT: identity entries)
     const bool real = has_affine && c < a.Cin;
     sct[c] = (real ? a.scale[(long)n * a.Cin + c] : 1.0f) * in_scale;      // (in_scale: 1, or the fp16 split's power of two)
@@ -597,26 +577,16 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   EMO_S_WAIT(0);
   __syncthreads();   // scale / shift tables visible
   EMO_S_QUAD_TABLE()
-  if (is_halo_wave) EMO_S_HALO_TABLE()
   EMO_S_TOUCH_QUAD()
-  EMO_S_STORE_QUAD(Cfg::OFF_P, 0)
-  EMO_S_STORE_QUAD(Cfg::OFF_P, 2)
-  if (is_halo_wave) {
-    EMO_S_TOUCH_HALO()
-    EMO_S_STORE_HALO(Cfg::OFF_P)
-  }
+  EMO_S_STORE_QUAD(Cfg::OFF_P, 0, 4)
   {
     const int st1 = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
     EMO_S_SET_STAGE(st1);
   }
   EMO_S_ISSUE_QUAD()
   EMO_S_QUAD_TABLE()
-  if (is_halo_wave) {
-    EMO_S_ISSUE_HALO()
-    EMO_S_HALO_TABLE()
-  }
   EMO_S_DMA_ROW(st_begin, 2);            // issue order of the steady state: Q(cg + 1), then DMA(cg, 2)
-  if (is_halo_wave) { EMO_S_BARRIER(Cfg::NDMA + 16); } else { EMO_S_BARRIER(Cfg::NDMA + 8); }   // (LDS stores of P[0] visible)
+  EMO_S_BARRIER(Cfg::NDMA + 8);          // (LDS stores of P[0] visible)
   EMO_S_LOAD_FRAGS(0, 0, Cfg::OFF_P, 0, 0)
 
   // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
@@ -638,11 +608,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       if (s == 2) {
         // MIDBAR(cg, r): every wave has fetched the last weight fragments of this row; the DMA of the next row has landed
         if (!(EMO_S_ABLATE & 4)) {
-          if (r == 2) {
-            if (is_halo_wave) { EMO_S_BARRIER(Cfg::NDMA + 16); } else { EMO_S_BARRIER(Cfg::NDMA + 8); }
-          } else {
-            EMO_S_BARRIER(Cfg::NDMA);
-          }
+          if (r == 2) { EMO_S_BARRIER(Cfg::NDMA + 8); } else { EMO_S_BARRIER(Cfg::NDMA); }
         }
         if (!(EMO_S_ABLATE & 1)) {
           if (r == 0) { EMO_S_DMA_ROW(cg1, 0); } else if (r == 1) { EMO_S_DMA_ROW(cg1, 1); } else { EMO_S_DMA_ROW(cg1, 2); }
@@ -651,10 +617,6 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
           EMO_S_SET_STAGE(cg2);
           EMO_S_ISSUE_QUAD()
           EMO_S_QUAD_TABLE()
-          if (is_halo_wave) {
-            EMO_S_ISSUE_HALO()
-            EMO_S_HALO_TABLE()
-          }
         }
       }
       // ---- one step: the fragments of the NEXT step (three rotating register sets), a piece of the next group's patch
@@ -671,14 +633,13 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
         }
       }
       if (!(EMO_S_ABLATE & 2)) {
-        if (gs == 2) {
+        if (gs == 2) {           // (the registers landed behind MIDBAR(cg, 0); they are re-issued at the top of step 5)
           EMO_S_TOUCH_QUAD()
-          if (is_halo_wave) EMO_S_TOUCH_HALO()
-          EMO_S_STORE_QUAD(pnxt, 0)
+          EMO_S_STORE_QUAD(pnxt, 0, 2)
         } else if (gs == 3) {
-          EMO_S_STORE_QUAD(pnxt, 2)
+          EMO_S_STORE_QUAD(pnxt, 2, 1)
         } else if (gs == 4) {
-          if (is_halo_wave) EMO_S_STORE_HALO(pnxt)
+          EMO_S_STORE_QUAD(pnxt, 3, 1)
         }
       }
 #pragma unroll
@@ -721,14 +682,10 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   EMO_S_STAMP(6)
 #undef EMO_S_SET_STAGE
 #undef EMO_S_ISSUE_QUAD
-#undef EMO_S_ISSUE_HALO
 #undef EMO_S_QUAD_TABLE
-#undef EMO_S_HALO_TABLE
 #undef EMO_S_SPLIT8
 #undef EMO_S_STORE_QUAD
-#undef EMO_S_STORE_HALO
 #undef EMO_S_TOUCH_QUAD
-#undef EMO_S_TOUCH_HALO
 #undef EMO_S_DMA_ROW
 #undef EMO_S_WAIT
 #undef EMO_S_BARRIER
@@ -762,7 +719,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     t_[14] = (unsigned long long)blockIdx.x;
   }
 #if EMO_S_TIMING == 2
-  if (lane == 0 && L < EMO_S_TLOG_N / 4) {   // per-wave barrier accounting in the upper three quarters of the log (first N/4 items)
+  if (lane == 0 && L < EMO_S_TLOG_N / 8) {   // per-wave barrier accounting in rows N/4 .. 3N/4 of the log (first N/8 items)
     unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)L * 4 + wave) * EMO_S_TLOG_W;
     w_[0] = tw_wait; w_[1] = tw_bar; w_[2] = tw_n; w_[3] = tstamp[2] - tstamp[1];
   }

@@ -35,7 +35,7 @@ def analyse_waves(full, n_items):
     """EMO_S_TIMING=2 builds: per wave of a block, the cycles its K loop spent in the waitcnt and in the s_barrier of the
     loop's barriers (rows N/4 + 4 * item + wave of the log)"""
     q4 = full.shape[0] // 4
-    n = min(n_items, q4)
+    n = min(n_items, full.shape[0] // 8)
     w = full[q4:q4 + 4 * n, :4].astype(np.int64).reshape(n, 4, 4)
     if not w[:, :, 2].any():
         return None
