@@ -357,6 +357,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   unsigned long long tstamp[12];
   for (int k = 0; k < 12; ++k) tstamp[k] = 0;
   unsigned long long tw_wait = 0, tw_bar = 0, tw_n = 0;
+  unsigned long long tstep[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // EMO_S_TIMING == 3: cycles per step index of the K loop, summed
 #endif
   EMO_S_STAMP(0)
   const int cotile = L % a.n_cotiles;
@@ -447,15 +448,15 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   }
 
   opx8 fa_[3][NPL][TM], fb_[3][NPL][TP];     // [register set][plane][tile]
-#define EMO_S_LOAD_FRAGS(set_, wbase_, pbase_, r_, s_)                                                \
+#define EMO_S_LOAD_FRAGS_PLANE(set_, pl_, wbase_, pbase_, r_, s_)                                      \
   {                                                                                                   \
-    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                              \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-        fa_[set_][pl][i] = lds8[(wbase_) + pl * WPLANE + (s_) * 2 * BM + a_base + i * 32];           \
-      _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                  \
-        fb_[set_][pl][j] = lds8[(pbase_) + pl * PPL + b_slot[j][r_][s_]];                             \
-    }                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
+      fa_[set_][pl_][i] = lds8[(wbase_) + (pl_) * WPLANE + (s_) * 2 * BM + a_base + i * 32];         \
+    _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                    \
+      fb_[set_][pl_][j] = lds8[(pbase_) + (pl_) * PPL + b_slot[j][r_][s_]];                           \
   }
+#define EMO_S_LOAD_FRAGS(set_, wbase_, pbase_, r_, s_)                                                \
+  { _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) EMO_S_LOAD_FRAGS_PLANE(set_, pl, wbase_, pbase_, r_, s_) }
 
   float* const sct = smem + Cfg::OFF_SCT * 4;
   const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem);
@@ -471,25 +472,44 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   int q_tix;
   int n_ci0, n_zu;
   bool n_zv;
-#define EMO_S_SET_STAGE(stage_)                                                                       \
+  int ld_stage, ld_cc, ld_kd;   // the stage whose patch is being loaded: channel chunk and depth tap, stepped (no division in the loop)
+#define EMO_S_SET_STAGE_VARS()                                                                        \
   {                                                                                                   \
-    const int cc_ = (stage_) / a.KD;                                                                  \
-    n_ci0 = cc_ * KC;                                                                                 \
-    n_zu = z0 + ((stage_) - cc_ * a.KD) - padD;                                                       \
+    n_ci0 = ld_cc * KC;                                                                               \
+    n_zu = z0 + ld_kd - padD;                                                                         \
     n_zv = (unsigned)n_zu < (unsigned)a.D;                                                            \
   }
-#define EMO_S_ISSUE_QUAD()                                                                            \
+#define EMO_S_SET_STAGE_INIT(stage_)                                                                  \
+  {                                                                                                   \
+    ld_stage = (stage_);                                                                              \
+    ld_cc = ld_stage / a.KD;                                                                          \
+    ld_kd = ld_stage - ld_cc * a.KD;                                                                  \
+    EMO_S_SET_STAGE_VARS()                                                                            \
+  }
+// target is ld_stage or ld_stage + 1 (the clamped stage sequence st + 1, st + 2, ...)
+#define EMO_S_SET_STAGE_STEP(target_)                                                                 \
+  {                                                                                                   \
+    if ((target_) != ld_stage) {                                                                      \
+      ++ld_stage;                                                                                     \
+      if (++ld_kd == a.KD) { ld_kd = 0; ++ld_cc; }                                                    \
+    }                                                                                                 \
+    EMO_S_SET_STAGE_VARS()                                                                            \
+  }
+  unsigned q_vo;
+#define EMO_S_ISSUE_BEGIN()                                                                           \
   {                                                                                                   \
     const int c0_ = n_ci0 + q_g * 8;                                                                  \
     const bool cv_ = c0_ < a.Cin;                                                                     \
     const int cs_ = cv_ ? c0_ : 0;                                                                    \
     const bool keep_ = q_ok && cv_ && n_zv;                                                           \
     q_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
-    q_hi = keep_ ? CLAMP_HI : 0.0f;                                                           \
-    const unsigned vo_ = q_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u; \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) qv[u] = emo_bload4_pinned(xrs, vo_, usoff[u]);      \
+    q_hi = keep_ ? CLAMP_HI : 0.0f;                                                                   \
+    q_vo = q_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;         \
     q_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
   }
+#define EMO_S_ISSUE_LOADS(u0_, u1_)                                                                   \
+  { _Pragma("unroll") for (int u = (u0_); u < (u1_); ++u) qv[u] = emo_bload4_pinned(xrs, q_vo, usoff[u]); }
+#define EMO_S_ISSUE_QUAD() { EMO_S_ISSUE_BEGIN() EMO_S_ISSUE_LOADS(0, 8) }
 #define EMO_S_QUAD_TABLE()                                                                            \
   {                                                                                                   \
     const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix;                               \
@@ -533,14 +553,14 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   }
 #define EMO_S_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[u]); }
 // one kernel row of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
-#define EMO_S_DMA_ROW(stage_, row_)                                                                   \
+#define EMO_S_DMA_PIECE(stage_, row_, i_)                                                             \
   {                                                                                                   \
     const char* ws_ = wsrc + ((long)(stage_) * 3 + (row_)) * Cfg::WROW_BYTES;                         \
-    _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) {                                           \
-      const int j = (SPLIT == 2 || i < 4) ? wave + 4 * i : 16 + (wave & 1);                           \
-      emo_dma16_pinned(ws_ + j * 1024 + lane * 16, smem_lds + (unsigned)((row_) * Cfg::WROW_BYTES + j * 1024)); \
-    }                                                                                                 \
+    const int j = (SPLIT == 2 || (i_) < 4) ? wave + 4 * (i_) : 16 + (wave & 1);                       \
+    emo_dma16_pinned(ws_ + j * 1024 + lane * 16, smem_lds + (unsigned)((row_) * Cfg::WROW_BYTES + j * 1024)); \
   }
+#define EMO_S_DMA_ROW(stage_, row_)                                                                   \
+  { _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(stage_, row_, i) }
 #define EMO_S_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #if EMO_S_TIMING == 2
 // measurement build: how long every wave sits in the waitcnt of a K-loop barrier (memory / LDS latency it did not hide) and in
@@ -562,7 +582,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   // ---- prologue: the three kernel rows of the first stage by DMA, its patch converted into P[0], the loads of the second ----
   EMO_S_DMA_ROW(st_begin, 0);
   EMO_S_DMA_ROW(st_begin, 1);
-  EMO_S_SET_STAGE(st_begin);
+  EMO_S_SET_STAGE_INIT(st_begin);
   EMO_S_ISSUE_QUAD()
   for (int c = tid; c < min(a.Cin, Cfg::SCT); c += 256) {   // (without an affine the index wraps at SCT: identity entries)
     const bool real = has_affine && c < a.Cin;
@@ -581,7 +601,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   EMO_S_STORE_QUAD(Cfg::OFF_P, 0, 4)
   {
     const int st1 = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
-    EMO_S_SET_STAGE(st1);
+    EMO_S_SET_STAGE_STEP(st1);
   }
   EMO_S_ISSUE_QUAD()
   EMO_S_QUAD_TABLE()
@@ -605,31 +625,48 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int gs = 0; gs < 9; ++gs) {
       const int r = gs / 3, s = gs % 3;
+#if EMO_S_TIMING == 3
+      const unsigned long long ts0_ = __builtin_amdgcn_s_memtime();
+#endif
       if (s == 2) {
         // MIDBAR(cg, r): every wave has fetched the last weight fragments of this row; the DMA of the next row has landed
         if (!(EMO_S_ABLATE & 4)) {
           if (r == 2) { EMO_S_BARRIER(Cfg::NDMA + 8); } else { EMO_S_BARRIER(Cfg::NDMA); }
         }
-        if (!(EMO_S_ABLATE & 1)) {
-          if (r == 0) { EMO_S_DMA_ROW(cg1, 0); } else if (r == 1) { EMO_S_DMA_ROW(cg1, 1); } else { EMO_S_DMA_ROW(cg1, 2); }
-        }
         if (r == 1 && !(EMO_S_ABLATE & 2)) {
-          EMO_S_SET_STAGE(cg2);
-          EMO_S_ISSUE_QUAD()
-          EMO_S_QUAD_TABLE()
+          EMO_S_SET_STAGE_STEP(cg2);
+          EMO_S_ISSUE_BEGIN()
         }
       }
       // ---- one step: the fragments of the NEXT step (three rotating register sets), a piece of the next group's patch
       //      conversion (behind MIDBAR(cg, 0) its registers have landed), 24 MFMAs.  The order inside the step is pinned with
       //      sched_group_barrier: the compiler left to itself sinks the fragment reads to their first use (LDS latency in
-      //      front of every MFMA) and emits the conversion as one VALU burst (the matrix pipe idles behind it) ----
+      //      front of every MFMA) and emits the conversion as one VALU burst (the matrix pipe idles behind it).
+      //      The step's vector-memory instructions -- the NDMA weight pieces behind a MIDBAR, the 8 quad loads behind
+      //      MIDBAR(cg, 1) -- sit BETWEEN the planes of the fragment reads: their asm statements order against the LDS reads on
+      //      both sides, which the pinning spreads one per MFMA, so they issue among the MFMAs.  Issued as a burst right behind
+      //      the barrier (an LDS-DMA piece costs ~60 cycles of issue, a 16-byte load ~30) they kept the matrix pipe empty for
+      //      260 / 820 / 1050 cycles of the three barrier steps (profiles/r4_conv_phase_steps.jsonl) ----
       __builtin_amdgcn_sched_barrier(0);
-      if (!(EMO_S_ABLATE & 8)) {
-        if (gs < 8) {
-          const int rn = (gs + 1) / 3, sn = (gs + 1) % 3;
-          EMO_S_LOAD_FRAGS((gs + 1) % 3, rn * WROW, pcur, rn, sn)
-        } else {
-          EMO_S_LOAD_FRAGS(0, 0, pnxt, 0, 0)
+      {
+        constexpr int UPP = (8 + NPL - 1) / NPL;          // quad loads per plane slot
+        const int rn = gs < 8 ? (gs + 1) / 3 : 0, sn = gs < 8 ? (gs + 1) % 3 : 0;
+        const int setn = gs < 8 ? (gs + 1) % 3 : 0;
+        const int wbn = rn * WROW, pbn = gs < 8 ? pcur : pnxt;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          if (!(EMO_S_ABLATE & 8)) EMO_S_LOAD_FRAGS_PLANE(setn, pl, wbn, pbn, rn, sn)
+          if (s == 2) {
+            if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(cg1, r, pl)
+            if (r == 1 && !(EMO_S_ABLATE & 2)) EMO_S_ISSUE_LOADS(pl * UPP, (pl + 1) * UPP < 8 ? (pl + 1) * UPP : 8)
+          }
+        }
+        if (s == 2) {
+          if (!(EMO_S_ABLATE & 1)) {
+#pragma unroll
+            for (int i = NPL; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(cg1, r, i)
+          }
+          if (r == 1 && !(EMO_S_ABLATE & 2)) EMO_S_QUAD_TABLE()
         }
       }
       if (!(EMO_S_ABLATE & 2)) {
@@ -672,6 +709,9 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#if EMO_S_TIMING == 3
+      tstep[gs] += __builtin_amdgcn_s_memtime() - ts0_;
+#endif
     }
     if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
   }
@@ -680,7 +720,13 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   EMO_S_STAMP(5)
   __syncthreads();    // ... and the LDS they target is reused by the epilogue
   EMO_S_STAMP(6)
-#undef EMO_S_SET_STAGE
+#undef EMO_S_SET_STAGE_VARS
+#undef EMO_S_SET_STAGE_INIT
+#undef EMO_S_SET_STAGE_STEP
+#undef EMO_S_ISSUE_BEGIN
+#undef EMO_S_ISSUE_LOADS
+#undef EMO_S_DMA_PIECE
+#undef EMO_S_LOAD_FRAGS_PLANE
 #undef EMO_S_ISSUE_QUAD
 #undef EMO_S_QUAD_TABLE
 #undef EMO_S_SPLIT8
@@ -718,6 +764,14 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     t_[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
     t_[14] = (unsigned long long)blockIdx.x;
   }
+#if EMO_S_TIMING == 3
+  if (lane == 0 && L < EMO_S_TLOG_N / 8) {   // per-step cycles of every wave (rows N/4 .. 3N/4)
+    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)L * 4 + wave) * EMO_S_TLOG_W;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w_[k] = tstep[k];
+    w_[9] = (unsigned long long)(st_end - st_begin);
+  }
+#endif
 #if EMO_S_TIMING == 2
   if (lane == 0 && L < EMO_S_TLOG_N / 8) {   // per-wave barrier accounting in rows N/4 .. 3N/4 of the log (first N/8 items)
     unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)L * 4 + wave) * EMO_S_TLOG_W;

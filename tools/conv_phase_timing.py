@@ -36,7 +36,11 @@ def analyse_waves(full, n_items):
     loop's barriers (rows N/4 + 4 * item + wave of the log)"""
     q4 = full.shape[0] // 4
     n = min(n_items, full.shape[0] // 8)
-    w = full[q4:q4 + 4 * n, :4].astype(np.int64).reshape(n, 4, 4)
+    ws = full[q4:q4 + 4 * n, :10].astype(np.int64).reshape(n, 4, 10)
+    if ws[:, :, 9].any() and (ws[:, :, 9] < 4096).all():      # EMO_S_TIMING=3: per-step cycles (column 9 = stages of the item)
+        per_stage = ws[:, :, :9] / ws[:, :, 9:10].clip(min=1)
+        return {f"wave{k}": dict(step_cycles=[int(np.median(per_stage[:, k, g])) for g in range(9)]) for k in range(4)}
+    w = ws[:, :, :4]
     if not w[:, :, 2].any():
         return None
     out = {}
