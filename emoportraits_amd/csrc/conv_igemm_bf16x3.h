@@ -58,10 +58,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 #ifndef EMO_S_ABLATE
 #define EMO_S_ABLATE 0   /* timing experiments only (results are WRONG for any value != 0), bits: 1 = no weight DMA in the K loop,
-                            2 = no patch loads / conversion / LDS stores in the K loop, 4 = no barriers and no vmcnt waits in the
-                            K loop, 8 = no fragment reads in the K loop (MFMAs on stale registers).  Bits 2 and 4 break the rule
-                            that nothing reuses the destination of an in-flight pinned load (the compiler sees them as dead):
-                            those builds fault on the GPU; bits 1 and 8 are safe */
+                            2 = no s_barrier in the K loop (the waitcnt stays), 4 = no quad loads in the K loop */
 #endif
 #ifndef EMO_S_TIMING
 #define EMO_S_TIMING 0   /* measurement builds only (tools/conv_phase_timing.py): wave 0 of every work item logs s_memtime at the start
@@ -107,8 +104,11 @@ struct ConvCfgS {
   static constexpr int WROW_BYTES = WROW * 16;
   static constexpr int PPL = NG * CHS;                   // one plane of the patch
   static constexpr int PBUF = NPL * PPL;
-  static constexpr int OFF_P = 3 * WROW;                 // after the three kernel-row weight buffers
-  static constexpr int OFF_SCT = OFF_P + 2 * PBUF;       // scale / shift tables (fp32)
+  static constexpr int OFF_P = 0;                        // the two patch buffers first: with the buffer a compile-time constant
+                                                         // (stage loop unrolled by two) every fragment read but one plane's is
+                                                         // lane base + immediate offset (ds_read offsets reach 64 KiB)
+  static constexpr int OFF_W = 2 * PBUF;                 // the three kernel-row weight buffers
+  static constexpr int OFF_SCT = OFF_W + 3 * WROW;       // scale / shift tables (fp32)
   static constexpr int SCT = 1024;
   // epilogue (conv_epilogue_rows): per-block bias table, the GroupNorm (mean, M2) exchange, and per wave a [32 channels][64
   // positions] fp32 transposition scratch.  The scratch lives in the patch buffer the last stage has just finished with when
@@ -429,31 +429,43 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
 
-  // patch slot of the lane's output pixel for every tap (+ half * CHS: the lane's 8-channel group)
-  const int a_base = half * BM + m0 + l32;
-  int b_slot[TP][3][3];
+  // LDS byte offsets of the lane's operands: weight fragment (+ row buffer / plane / tap column immediates) and, for every tap,
+  // the patch slot of the lane's output pixel (+ half * CHS: the lane's 8-channel group; + buffer / plane immediates)
+  // Kernel row r adds r patch rows = r * NQ1 slots (an immediate); with the fused upsample the source row of kernel row r is
+  // (row + r + 1) >> 1: kernel row 2 is kernel row 0 plus one patch row, kernel row 1 depends on the parity of the pixel row
+  // and keeps its own registers.
+  const int a_off = (half * BM + m0 + l32) * 16;
+  constexpr int NBR = UPS ? 2 : 1;
+  int b_off[TP][NBR][3];
 #pragma unroll
   for (int j = 0; j < TP; ++j) {
     const int p = p0 + j * 32 + l32;
     const int col = p % TW, row = p / TW;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < NBR; ++r)
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int pr = UPS ? ((row + r - 1 + 2) >> 1) - 1 + 1 : row + r;
         const int pc = UPS ? ((col + s - 1 + 2) >> 1) - 1 : col + s - 1;
         const int slot = pc < 0 ? pr * NQ1 + NQ : (pc >= TWS ? SUB + pr * NQ1 + NQ : (pc & 3) * SUB + pr * NQ1 + (pc >> 2));
-        b_slot[j][r][s] = half * CHS + slot;
+        b_off[j][r][s] = (half * CHS + slot) * 16;
       }
   }
+#define EMO_S_B_OFF(j_, r_, s_) (UPS ? ((r_) == 2 ? b_off[j_][0][s_] + NQ1 * 16 : b_off[j_][(r_) < NBR ? (r_) : 0][s_]) \
+                                     : b_off[j_][0][s_] + (r_) * NQ1 * 16)
+  int q_slb[4];                                           // byte offsets of the lane's four staging slots inside a patch buffer
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q_slb[i] = q_sl[i] * 16;
 
-  opx8 fa_[3][NPL][TM], fb_[3][NPL][TP];     // [register set][plane][tile]
+  const char* const lds_c = reinterpret_cast<const char*>(smem);
+  char* const lds_w = reinterpret_cast<char*>(smem);
+  opx8 fa_[2][NPL][TM], fb_[2][NPL][TP];     // [register set: this step / the next][plane][tile]
 #define EMO_S_LOAD_FRAGS_PLANE(set_, pl_, wbase_, pbase_, r_, s_)                                      \
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
-      fa_[set_][pl_][i] = lds8[(wbase_) + (pl_) * WPLANE + (s_) * 2 * BM + a_base + i * 32];         \
+      fa_[set_][pl_][i] = *reinterpret_cast<const opx8*>(lds_c + a_off + ((wbase_) + (pl_) * WPLANE + (s_) * 2 * BM + i * 32) * 16); \
     _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                    \
-      fb_[set_][pl_][j] = lds8[(pbase_) + (pl_) * PPL + b_slot[j][r_][s_]];                           \
+      fb_[set_][pl_][j] = *reinterpret_cast<const opx8*>(lds_c + EMO_S_B_OFF(j, r_, s_) + ((pbase_) + (pl_) * PPL) * 16); \
   }
 #define EMO_S_LOAD_FRAGS(set_, wbase_, pbase_, r_, s_)                                                \
   { _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) EMO_S_LOAD_FRAGS_PLANE(set_, pl, wbase_, pbase_, r_, s_) }
@@ -461,15 +473,20 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   float* const sct = smem + Cfg::OFF_SCT * 4;
   const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem);
 
-  floatx4 qv[8];
-  float q_lo, q_hi;
-  floatx4 q_sc[2], q_sh[2];
+  // raw patch registers, double-buffered by stage parity: the loads of stage k + 2 are issued (into buffer k & 1) while the
+  // conversion of stage k + 1 still reads buffer (k + 1) & 1 -- that lets the conversion spread over eight steps of a stage,
+  // half a pixel (4 channels) per step, instead of 2 + 1 + 1 pixels in three steps (where 120 VALU beside 24 resp. 12 MFMAs
+  // made those steps issue-bound: 1690 / 880 / 820 cycles against 768, profiles/r4_conv_phase_steps.jsonl)
+  floatx4 qv[2][8];
+  float q_lo[2], q_hi[2];
+  int q_tix[2];
+  floatx4 q_sc, q_sh;                       // scale / shift of the four channels being converted (read at the top of the step)
+  opx8 cv_h, cv_m, cv_l;                    // the pixel under conversion: 8 channels per plane, filled in two halves
   const emo_intx4 xrs = emo_raw_buffer(xn);
   unsigned usoff[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)u * (unsigned)DHW * 4u));
 
-  int q_tix;
   int n_ci0, n_zu;
   bool n_zv;
   int ld_stage, ld_cc, ld_kd;   // the stage whose patch is being loaded: channel chunk and depth tap, stepped (no division in the loop)
@@ -496,68 +513,67 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     EMO_S_SET_STAGE_VARS()                                                                            \
   }
   unsigned q_vo;
-#define EMO_S_ISSUE_BEGIN()                                                                           \
+#define EMO_S_ISSUE_BEGIN(b_)                                                                         \
   {                                                                                                   \
     const int c0_ = n_ci0 + q_g * 8;                                                                  \
     const bool cv_ = c0_ < a.Cin;                                                                     \
     const int cs_ = cv_ ? c0_ : 0;                                                                    \
     const bool keep_ = q_ok && cv_ && n_zv;                                                           \
-    q_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
-    q_hi = keep_ ? CLAMP_HI : 0.0f;                                                                   \
+    q_lo[b_] = keep_ ? clamp_lo : 0.0f;                                                               \
+    q_hi[b_] = keep_ ? CLAMP_HI : 0.0f;                                                               \
     q_vo = q_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;         \
-    q_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
+    q_tix[b_] = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                     \
   }
-#define EMO_S_ISSUE_LOADS(u0_, u1_)                                                                   \
-  { _Pragma("unroll") for (int u = (u0_); u < (u1_); ++u) qv[u] = emo_bload4_pinned(xrs, q_vo, usoff[u]); }
-#define EMO_S_ISSUE_QUAD() { EMO_S_ISSUE_BEGIN() EMO_S_ISSUE_LOADS(0, 8) }
-#define EMO_S_QUAD_TABLE()                                                                            \
+#define EMO_S_ISSUE_LOADS(b_, u0_, u1_)                                                               \
+  { _Pragma("unroll") for (int u = (u0_); u < (u1_); ++u) qv[b_][u] = emo_bload4_pinned(xrs, q_vo, usoff[u]); }
+#define EMO_S_HALF_TABLE(b_, hf_)                                                                     \
   {                                                                                                   \
-    const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix;                               \
-    q_sc[0] = t4_[0]; q_sc[1] = t4_[1]; q_sh[0] = t4_[Cfg::SCT / 4]; q_sh[1] = t4_[Cfg::SCT / 4 + 1]; \
+    const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix[b_] + (hf_);                   \
+    q_sc = t4_[0]; q_sh = t4_[Cfg::SCT / 4];                                                          \
   }
-// fp32 transform (GroupNorm affine of the producer, ReLU and zero padding in one v_med3: bounds [0, 0] where the pixel is
-// padding), then the exact three-way split v = h + m + l (round-to-nearest-even at every level; the residuals are exact)
-#define EMO_S_SPLIT8(dst_, pre_, lo_, hi_)                                                            \
+#define EMO_S_TOUCH_QUAD(b_) { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[b_][u]); }
+// Conversion of channels 4 * hf_ .. + 3 of pixel i_ of buffer b_: fp32 transform (GroupNorm affine of the producer; ReLU,
+// saturation and zero padding in one v_med3: bounds [0, 0] where the pixel is padding), then the exact split into the operand
+// planes -- v = h + m + l, round-to-nearest-even at every level, the residuals are exact (SPLIT = 2: h + m of the scaled value).
+// The second half stores the pixel's slot of every plane (every lane stores all four pixels of its loads: its own, or into
+// dump slots).
+#define EMO_S_CONV_HALF(b_, pbase_, i_, hf_)                                                          \
   {                                                                                                   \
-    opx8 h_, m_, l_;                                                                                  \
-    float t_[8];                                                                                      \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) t_[u] = (pre_);                                     \
+    float t_[4];                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                     \
+      t_[k] = __fmaf_rn(qv[b_][4 * (hf_) + k][i_], q_sc[k], q_sh[k]);                                 \
     if constexpr (SPLIT == 2) {   /* range check of the fp16 split: max |pre-clamp value| (v_max3 with |.| modifiers) */ \
-      _Pragma("unroll") for (int u = 0; u < 8; u += 2)                                                \
-        sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[u])), __builtin_fabsf(t_[u + 1])); \
+      sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[0])), __builtin_fabsf(t_[1])); \
+      sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[2])), __builtin_fabsf(t_[3])); \
     }                                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                   \
-      const float v = __builtin_amdgcn_fmed3f(t_[u], (lo_), (hi_));                                   \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                   \
+      const int u = 4 * (hf_) + k;                                                                    \
+      const float v = __builtin_amdgcn_fmed3f(t_[k], q_lo[b_], q_hi[b_]);                             \
       if constexpr (SPLIT == 3) {                                                                     \
-        h_[u] = (__bf16)v;                                                                            \
-        const float r1 = v - (float)h_[u];                                                            \
-        m_[u] = (__bf16)r1;                                                                           \
-        const float r2 = r1 - (float)m_[u];                                                           \
-        l_[u] = (__bf16)r2;                                                                           \
+        cv_h[u] = (__bf16)v;                                                                          \
+        const float r1 = v - (float)cv_h[u];                                                          \
+        cv_m[u] = (__bf16)r1;                                                                         \
+        const float r2 = r1 - (float)cv_m[u];                                                         \
+        cv_l[u] = (__bf16)r2;                                                                         \
       } else {                                                                                        \
-        h_[u] = (_Float16)v;                                                                          \
-        m_[u] = (_Float16)(v - (float)h_[u]);                                                         \
+        cv_h[u] = (_Float16)v;                                                                        \
+        cv_m[u] = (_Float16)(v - (float)cv_h[u]);                                                     \
       }                                                                                               \
     }                                                                                                 \
-    (dst_)[0] = h_;                                                                                   \
-    (dst_)[PPL] = m_;                                                                                 \
-    if constexpr (SPLIT == 3) (dst_)[2 * PPL] = l_;                                                   \
-  }
-// pixels i0_ .. i0_ + n_ - 1 of the lane's 16-byte loads (every lane stores all four: its own, or into dump slots)
-#define EMO_S_STORE_QUAD(pbase_, i0_, n_)                                                             \
-  {                                                                                                   \
-    _Pragma("unroll") for (int i = (i0_); i < (i0_) + (n_); ++i) {                                    \
-      opx8* d_ = lds8 + (pbase_) + q_sl[i];                                                           \
-      EMO_S_SPLIT8(d_, __fmaf_rn(qv[u][i], q_sc[u / 4][u % 4], q_sh[u / 4][u % 4]), q_lo, q_hi)        \
+    if ((hf_) == 1) {                                                                                 \
+      char* d_ = lds_w + q_slb[i_] + (pbase_) * 16;                                                   \
+      *reinterpret_cast<opx8*>(d_) = cv_h;                                                            \
+      *reinterpret_cast<opx8*>(d_ + PPL * 16) = cv_m;                                                 \
+      if constexpr (SPLIT == 3) *reinterpret_cast<opx8*>(d_ + 2 * PPL * 16) = cv_l;                   \
     }                                                                                                 \
   }
-#define EMO_S_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 8; ++u) emo_touch4(qv[u]); }
 // one kernel row of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
 #define EMO_S_DMA_PIECE(stage_, row_, i_)                                                             \
   {                                                                                                   \
     const char* ws_ = wsrc + ((long)(stage_) * 3 + (row_)) * Cfg::WROW_BYTES;                         \
     const int j = (SPLIT == 2 || (i_) < 4) ? wave + 4 * (i_) : 16 + (wave & 1);                       \
-    emo_dma16_pinned(ws_ + j * 1024 + lane * 16, smem_lds + (unsigned)((row_) * Cfg::WROW_BYTES + j * 1024)); \
+    emo_dma16_pinned(ws_ + j * 1024 + lane * 16,                                                      \
+                     smem_lds + (unsigned)(Cfg::OFF_W * 16 + (row_) * Cfg::WROW_BYTES + j * 1024));   \
   }
 #define EMO_S_DMA_ROW(stage_, row_)                                                                   \
   { _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(stage_, row_, i) }
@@ -578,142 +594,172 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #else
 #define EMO_S_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
 #endif
+#define EMO_S_LOOP_BARRIER(n_) { if (EMO_S_ABLATE & 2) { EMO_S_WAIT(n_); } else { EMO_S_BARRIER(n_); } }
 
-  // ---- prologue: the three kernel rows of the first stage by DMA, its patch converted into P[0], the loads of the second ----
+  // ---- prologue: the kernel rows of the first stage by DMA, the loads of the first two stages, the first patch converted into
+  //      P[0]; it leaves the state every stage leaves to the next: buffer 1 holds the landed loads of the second stage, the
+  //      tables are that stage's, DMA(first stage, row 2) is in flight, fragment set 0 holds step 0 ----
+  // (the table entries travel through registers: their global loads are issued BEFORE the pinned loads and stored to LDS
+  // behind them -- one memory round trip for everything, and while pinned loads are in flight the compiler has nothing to do
+  // but a few LDS stores: it must never copy or spill a register whose load has not landed, tools/kernel_resources.py --audit)
+  constexpr int NTE = Cfg::SCT / 256;
+  float te_sc[NTE], te_sh[NTE], te_b = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NTE; ++k) {
+    const int c = tid + 256 * k;
+    const bool real = has_affine && c < a.Cin;
+    te_sc[k] = real ? a.scale[(long)n * a.Cin + c] : 1.0f;
+    te_sh[k] = real ? a.shift[(long)n * a.Cin + c] : 0.0f;
+  }
+  if (tid < BM && a.bias != nullptr && a.partial == nullptr) {
+    const int co_ = cotile * BM + tid;
+    te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];
+  }
   EMO_S_DMA_ROW(st_begin, 0);
   EMO_S_DMA_ROW(st_begin, 1);
   EMO_S_SET_STAGE_INIT(st_begin);
-  EMO_S_ISSUE_QUAD()
-  for (int c = tid; c < min(a.Cin, Cfg::SCT); c += 256) {   // (without an affine the index wraps at SCT: identity entries)
-    const bool real = has_affine && c < a.Cin;
-    sct[c] = (real ? a.scale[(long)n * a.Cin + c] : 1.0f) * in_scale;      // (in_scale: 1, or the fp16 split's power of two)
-    sct[Cfg::SCT + c] = (real ? a.shift[(long)n * a.Cin + c] : 0.0f) * in_scale;
-  }
-  if (tid < BM) {   // bias of the block's channels in the order the epilogue's row layout reads it (conv_epilogue_rows)
-    const int co_ = cotile * BM + tid;
-    const float b_ = (a.bias != nullptr && a.partial == nullptr) ? a.bias[co_ < a.Cout ? co_ : a.Cout - 1] : 0.0f;
-    smem[Cfg::OFF_BIAS_F + (tid >> 5) * 32 + (tid & 3) * 8 + ((tid & 31) >> 2)] = b_;
-  }
-  EMO_S_WAIT(0);
-  __syncthreads();   // scale / shift tables visible
-  EMO_S_QUAD_TABLE()
-  EMO_S_TOUCH_QUAD()
-  EMO_S_STORE_QUAD(Cfg::OFF_P, 0, 4)
+  EMO_S_ISSUE_BEGIN(0)
+  EMO_S_ISSUE_LOADS(0, 0, 8)
   {
     const int st1 = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
     EMO_S_SET_STAGE_STEP(st1);
   }
-  EMO_S_ISSUE_QUAD()
-  EMO_S_QUAD_TABLE()
-  EMO_S_DMA_ROW(st_begin, 2);            // issue order of the steady state: Q(cg + 1), then DMA(cg, 2)
-  EMO_S_BARRIER(Cfg::NDMA + 8);          // (LDS stores of P[0] visible)
-  EMO_S_LOAD_FRAGS(0, 0, Cfg::OFF_P, 0, 0)
+  EMO_S_ISSUE_BEGIN(1)
+  EMO_S_ISSUE_LOADS(1, 0, 8)
+#pragma unroll
+  for (int k = 0; k < NTE; ++k) {       // (without an affine the index wraps at SCT: identity entries)
+    const int c = tid + 256 * k;
+    if (c < min(a.Cin, Cfg::SCT)) {
+      sct[c] = te_sc[k] * in_scale;      // (in_scale: 1, or the fp16 split's power of two)
+      sct[Cfg::SCT + c] = te_sh[k] * in_scale;
+    }
+  }
+  // bias of the block's channels in the order the epilogue's row layout reads it (conv_epilogue_rows)
+  if (tid < BM) smem[Cfg::OFF_BIAS_F + (tid >> 5) * 32 + (tid & 3) * 8 + ((tid & 31) >> 2)] = te_b;
+  EMO_S_WAIT(0);
+  EMO_S_TOUCH_QUAD(0)
+  EMO_S_TOUCH_QUAD(1)
+  __syncthreads();   // scale / shift tables visible
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    EMO_S_HALF_TABLE(0, 0)
+    EMO_S_CONV_HALF(0, Cfg::OFF_P, i, 0)
+    EMO_S_HALF_TABLE(0, 1)
+    EMO_S_CONV_HALF(0, Cfg::OFF_P, i, 1)
+  }
+  EMO_S_HALF_TABLE(1, 0)                 // (what step 0 of the first stage converts with)
+  EMO_S_DMA_ROW(st_begin, 2);
+  EMO_S_BARRIER(Cfg::NDMA);              // (LDS stores of P[0] visible; DMA(first stage, 2) stays in flight)
+  EMO_S_LOAD_FRAGS(0, Cfg::OFF_W, Cfg::OFF_P, 0, 0)
 
   // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
   constexpr int NPROD = SPLIT == 3 ? EMO_S_PRODUCTS : 3;
   constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
   constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
 
+  // ---- K loop, two stages per iteration (buffer parities and fragment sets are compile-time constants).  Stage cg, parity par:
+  //        steps 0 .. 7   half a pixel each of the patch of stage cg + 1 is converted from qv[par ^ 1] into P[par ^ 1]
+  //        MIDBAR(cg, 0) (top of step 2): DMA(cg, 1) has landed [vmcnt NDMA: DMA(cg, 2) may fly]; then DMA(cg + 1, 0) and the
+  //                       quad loads of stage cg + 2 into qv[par] (free since the previous stage's step 7)
+  //        MIDBAR(cg, 1) (top of step 5): DMA(cg, 2) has landed [vmcnt NDMA + 8]; then DMA(cg + 1, 1)
+  //        MIDBAR(cg, 2) (top of step 8): DMA(cg + 1, 0) and the quad loads have landed [vmcnt NDMA: DMA(cg + 1, 1) may fly];
+  //                       every wave has stored its share of P[par ^ 1] and is past its last read of weight row 2; then
+  //                       DMA(cg + 1, 2) and the first fragments of stage cg + 1 from P[par ^ 1]
+  //      every wave issues exactly NDMA pieces per row and 8 quad loads per stage, so the counts are uniform ----
   EMO_S_STAMP(1)
-  for (int cg = st_begin; cg < st_end; ++cg) {
-    const int cgrel = cg - st_begin;
-    const int par = cgrel & 1;
-    const int pcur = Cfg::OFF_P + par * PBUF, pnxt = Cfg::OFF_P + (par ^ 1) * PBUF;
-    const int cg1 = (cg + 1) < st_end ? (cg + 1) : cg;          // clamped on the last stages: harmless re-stage
-    const int cg2 = (cg + 2) < st_end ? (cg + 2) : cg1;
-    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
+  const int st_last = st_end - 1;
+  for (int cg0 = st_begin; cg0 < st_end; cg0 += 2) {
 #pragma unroll
-    for (int gs = 0; gs < 9; ++gs) {
-      const int r = gs / 3, s = gs % 3;
+    for (int par = 0; par < 2; ++par) {
+      const int cg = cg0 + par;
+      if (cg >= st_end) break;
+      const int pcur = Cfg::OFF_P + par * PBUF, pnxt = Cfg::OFF_P + (par ^ 1) * PBUF;
+      const int cg1 = (cg + 1) < st_end ? (cg + 1) : st_last;     // clamped on the last stages: harmless re-stage
+      const int cg2 = (cg + 2) < st_end ? (cg + 2) : st_last;
+      if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int gs = 0; gs < 9; ++gs) {
+        const int r = gs / 3, s = gs % 3;
+        const int fcur = (par * 9 + gs) & 1, fnxt = fcur ^ 1;     // fragment register sets of this step and the next
 #if EMO_S_TIMING == 3
-      const unsigned long long ts0_ = __builtin_amdgcn_s_memtime();
+        const unsigned long long ts0_ = __builtin_amdgcn_s_memtime();
 #endif
-      if (s == 2) {
-        // MIDBAR(cg, r): every wave has fetched the last weight fragments of this row; the DMA of the next row has landed
-        if (!(EMO_S_ABLATE & 4)) {
-          if (r == 2) { EMO_S_BARRIER(Cfg::NDMA + 8); } else { EMO_S_BARRIER(Cfg::NDMA); }
-        }
-        if (r == 1 && !(EMO_S_ABLATE & 2)) {
-          EMO_S_SET_STAGE_STEP(cg2);
-          EMO_S_ISSUE_BEGIN()
-        }
-      }
-      // ---- one step: the fragments of the NEXT step (three rotating register sets), a piece of the next group's patch
-      //      conversion (behind MIDBAR(cg, 0) its registers have landed), 24 MFMAs.  The order inside the step is pinned with
-      //      sched_group_barrier: the compiler left to itself sinks the fragment reads to their first use (LDS latency in
-      //      front of every MFMA) and emits the conversion as one VALU burst (the matrix pipe idles behind it).
-      //      The step's vector-memory instructions -- the NDMA weight pieces behind a MIDBAR, the 8 quad loads behind
-      //      MIDBAR(cg, 1) -- sit BETWEEN the planes of the fragment reads: their asm statements order against the LDS reads on
-      //      both sides, which the pinning spreads one per MFMA, so they issue among the MFMAs.  Issued as a burst right behind
-      //      the barrier (an LDS-DMA piece costs ~60 cycles of issue, a 16-byte load ~30) they kept the matrix pipe empty for
-      //      260 / 820 / 1050 cycles of the three barrier steps (profiles/r4_conv_phase_steps.jsonl) ----
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        constexpr int UPP = (8 + NPL - 1) / NPL;          // quad loads per plane slot
-        const int rn = gs < 8 ? (gs + 1) / 3 : 0, sn = gs < 8 ? (gs + 1) % 3 : 0;
-        const int setn = gs < 8 ? (gs + 1) % 3 : 0;
-        const int wbn = rn * WROW, pbn = gs < 8 ? pcur : pnxt;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-          if (!(EMO_S_ABLATE & 8)) EMO_S_LOAD_FRAGS_PLANE(setn, pl, wbn, pbn, rn, sn)
-          if (s == 2) {
-            if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(cg1, r, pl)
-            if (r == 1 && !(EMO_S_ABLATE & 2)) EMO_S_ISSUE_LOADS(pl * UPP, (pl + 1) * UPP < 8 ? (pl + 1) * UPP : 8)
-          }
-        }
         if (s == 2) {
-          if (!(EMO_S_ABLATE & 1)) {
-#pragma unroll
-            for (int i = NPL; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(cg1, r, i)
+          if (EMO_S_ABLATE & 5) { EMO_S_LOOP_BARRIER(0) }       // (ablation builds issue fewer loads: drain instead of counting)
+          else if (r == 1) { EMO_S_LOOP_BARRIER(Cfg::NDMA + 8) } else { EMO_S_LOOP_BARRIER(Cfg::NDMA) }
+          if (r == 0) {
+            EMO_S_SET_STAGE_STEP(cg2);
+            EMO_S_ISSUE_BEGIN(par)
           }
-          if (r == 1 && !(EMO_S_ABLATE & 2)) EMO_S_QUAD_TABLE()
+          if (r == 2) EMO_S_TOUCH_QUAD(par)
         }
-      }
-      if (!(EMO_S_ABLATE & 2)) {
-        if (gs == 2) {           // (the registers landed behind MIDBAR(cg, 0); they are re-issued at the top of step 5)
-          EMO_S_TOUCH_QUAD()
-          EMO_S_STORE_QUAD(pnxt, 0, 2)
-        } else if (gs == 3) {
-          EMO_S_STORE_QUAD(pnxt, 2, 1)
-        } else if (gs == 4) {
-          EMO_S_STORE_QUAD(pnxt, 3, 1)
-        }
-      }
+        // ---- one step: the fragments of the NEXT step, half a pixel of conversion, 4 * NPROD MFMAs.  The order inside the step
+        //      is pinned with sched_group_barrier: the compiler left to itself sinks the fragment reads to their first use
+        //      (LDS latency in front of every MFMA) and emits the conversion as one VALU burst.  The step's vector-memory
+        //      instructions -- the NDMA weight pieces behind a MIDBAR, the 8 quad loads behind MIDBAR(cg, 0) -- sit BETWEEN the
+        //      planes of the fragment reads: their asm statements order against the LDS reads on both sides, which the pinning
+        //      spreads one per MFMA, so they issue among the MFMAs instead of as a burst behind the barrier ----
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          constexpr int UPP = (8 + NPL - 1) / NPL;          // quad loads per plane slot
+          const int rn = gs < 8 ? (gs + 1) / 3 : 0, sn = gs < 8 ? (gs + 1) % 3 : 0;
+          const int wbn = Cfg::OFF_W + rn * WROW, pbn = gs < 8 ? pcur : pnxt;
 #pragma unroll
-      for (int p = 0; p < NPROD; ++p) {
-        const int pa = SPLIT == 2 ? PA3[p] : PA6[p + 6 - NPROD], pb = SPLIT == 2 ? PB3[p] : PB6[p + 6 - NPROD];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TP; ++j) {
-            // operands swapped: the result tile is [position][channel] (conv_epilogue).  The leading product accumulates in
-            // acc_lo, the small ones in acc_hi (header comment)
-            floatx16& acc_ = (pa == 0 && pb == 0) ? acc_lo[i][j] : acc_hi[i][j];
-            if constexpr (SPLIT == 3) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_, 0, 0, 0);
-            else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[gs % 3][pb][j], fa_[gs % 3][pa][i], acc_, 0, 0, 0);
+          for (int pl = 0; pl < NPL; ++pl) {
+            EMO_S_LOAD_FRAGS_PLANE(fnxt, pl, wbn, pbn, rn, sn)
+            if (s == 2) {
+              if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(cg1, r, pl)
+              if (r == 0 && !(EMO_S_ABLATE & 4)) EMO_S_ISSUE_LOADS(par, pl * UPP, (pl + 1) * UPP < 8 ? (pl + 1) * UPP : 8)
+            }
           }
-      }
-      if (EMO_S_PIN) {
-        // { MFMA, fragment read, <= 5 VALU } for the 4 * NPL reads of the step, then { MFMA, <= 6 VALU, LDS store }
+          if (s == 2) {
 #pragma unroll
-        for (int k = 0; k < 4 * NPL; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            for (int i = NPL; i < Cfg::NDMA; ++i) { if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(cg1, r, i) }
+          }
+        }
+        if (gs < 8) {
+          EMO_S_CONV_HALF(par ^ 1, pnxt, gs >> 1, gs & 1)
+          // scale / shift of the NEXT step's four channels, read behind this step's last use of the registers: a read at the top
+          // of the step that uses it stalls the step's first VALU -- and, in order, every MFMA behind it -- for the LDS latency
+          // (+130 cycles per step, profiles/r4_conv_phase_steps_spread.jsonl)
+          if (gs < 7) { EMO_S_HALF_TABLE(par ^ 1, (gs + 1) & 1) } else { EMO_S_HALF_TABLE(par, 0) }
         }
 #pragma unroll
-        for (int k = 4 * NPL; k < 4 * NPROD; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        for (int p = 0; p < NPROD; ++p) {
+          const int pa = SPLIT == 2 ? PA3[p] : PA6[p + 6 - NPROD], pb = SPLIT == 2 ? PB3[p] : PB6[p + 6 - NPROD];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+              // operands swapped: the result tile is [position][channel] (conv_epilogue).  The leading product accumulates in
+              // acc_lo, the small ones in acc_hi (header comment)
+              floatx16& acc_ = (pa == 0 && pb == 0) ? acc_lo[i][j] : acc_hi[i][j];
+              if constexpr (SPLIT == 3) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[fcur][pb][j], fa_[fcur][pa][i], acc_, 0, 0, 0);
+              else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[fcur][pb][j], fa_[fcur][pa][i], acc_, 0, 0, 0);
+            }
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        if (EMO_S_PIN) {
+          // { MFMA, fragment read, <= 5 VALU } for the 4 * NPL reads of the step, then { MFMA, <= 6 VALU, LDS store }
+#pragma unroll
+          for (int k = 0; k < 4 * NPL; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+#pragma unroll
+          for (int k = 4 * NPL; k < 4 * NPROD; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #if EMO_S_TIMING == 3
-      tstep[gs] += __builtin_amdgcn_s_memtime() - ts0_;
+        tstep[gs] += __builtin_amdgcn_s_memtime() - ts0_;
 #endif
+      }
+      if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
-    if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
   }
   EMO_S_STAMP(2)
   EMO_S_WAIT(0);      // the re-issued loads / DMA of the clamped last stages are dead: drain them
@@ -725,16 +771,16 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #undef EMO_S_SET_STAGE_STEP
 #undef EMO_S_ISSUE_BEGIN
 #undef EMO_S_ISSUE_LOADS
-#undef EMO_S_DMA_PIECE
-#undef EMO_S_LOAD_FRAGS_PLANE
-#undef EMO_S_ISSUE_QUAD
-#undef EMO_S_QUAD_TABLE
-#undef EMO_S_SPLIT8
-#undef EMO_S_STORE_QUAD
+#undef EMO_S_HALF_TABLE
+#undef EMO_S_B_OFF
+#undef EMO_S_CONV_HALF
 #undef EMO_S_TOUCH_QUAD
+#undef EMO_S_DMA_PIECE
 #undef EMO_S_DMA_ROW
 #undef EMO_S_WAIT
 #undef EMO_S_BARRIER
+#undef EMO_S_LOOP_BARRIER
+#undef EMO_S_LOAD_FRAGS_PLANE
 #undef EMO_S_LOAD_FRAGS
 
   {

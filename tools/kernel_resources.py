@@ -144,7 +144,10 @@ def loop_scratch(src):
                 mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
                 first_asm = next((i for i, l in enumerate(lines) if "#ASMSTART" in l), None)   # first pinned load (prologue)
                 sc = [i for i, l in enumerate(lines) if "scratch_" in l and not l.lstrip().startswith(";")]
-                lo = min(first_asm if first_asm is not None else 10 ** 9, mf[0] if mf else 10 ** 9)
+                # scratch traffic of the K loop proper (first to last MFMA).  Spills in the prologue are judged by
+                # inflight_reads alone: it walks the prologue too, counts the compiler's own scratch operations in the
+                # vmcnt model, and flags a copy or spill of any register whose pinned load may not have landed
+                lo = mf[0] if mf else 10 ** 9
                 inside = [i for i in sc if mf and lo < i < mf[-1]]
                 out.append((name, len(inside), len(sc), inflight_reads(lines)))
             m = re.search(r"Begin function (\S+)", line)
