@@ -259,18 +259,23 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
     # batch-1 latency of the hot path (what one reference-style forward() call costs on the device)
     t = _time_loop(lambda: ops.pack_rgb8(hp.driver_pass(ccl, idt, pose[:1], theta[:1])))
     out["latency_b1_ms"] = round(t * 1e3, 3)
-    if hp.precision != "f32":
-        # the same pass with the exact-fp32 MFMA kernel in every convolution (EMO_CONV_PRECISION=f32)
-        hp32 = nets.HotPath(sd, cfg, dev, with_source=False, precision="f32")
-        t = _time_loop(lambda: ops.pack_rgb8(hp32.driver_pass(ccl, idt, pose, theta)))
-        out["fp32_mfma_everywhere_fps"] = round(B / t, 2)
-        del hp32
-    # opt-in: the two-term fp16 split of the scaled operands in the same 3x3 layers (half the matrix work, fp32-level error,
-    # inputs beyond +-2047 saturate: include/emo_hip.h emo_conv_igemm_f16x2) -- never the headline
-    hpx = nets.HotPath(sd, cfg, dev, with_source=False, precision="f16x2")
-    t = _time_loop(lambda: ops.pack_rgb8(hpx.driver_pass(ccl, idt, pose, theta)))
-    out["f16x2_split_fps"] = round(B / t, 2)
-    del hpx
+    # the same step in the other fp32 conv modes (nets.HotPath precision=): exact-fp32 MFMA everywhere, the exact three-term bf16
+    # split (round 3's default), the device-checked two-term fp16 split (the default), and the latter WITHOUT its range check and
+    # guarded recomputation launches (what the contract costs)
+    for mode, key in (("f32", "fp32_mfma_everywhere_fps"), ("bf16x3", "bf16x3_split_fps"), ("f16x2", "f16x2_split_fps")):
+        if mode == hp.precision:
+            continue
+        hpm = nets.HotPath(sd, cfg, dev, with_source=False, precision=mode)
+        t = _time_loop(lambda: ops.pack_rgb8(hpm.driver_pass(ccl, idt, pose, theta)))
+        out[key] = round(B / t, 2)
+        del hpm
+    if hp.precision == "f16x2":
+        ops.F16X2_GUARD = False
+        try:
+            t = _time_loop(lambda: ops.pack_rgb8(hp.driver_pass(ccl, idt, pose, theta)))
+            out["f16x2_without_range_check_fps"] = round(B / t, 2)
+        finally:
+            ops.F16X2_GUARD = True
     # stage 2 at 512x512 (notebooks/infer_s2.py:351-376), 8 frames per call
     g = torch.Generator().manual_seed(11)
     s2cfg = stage2.stage2_config(overrides=dict(output_size_s2=512))
@@ -279,16 +284,17 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
     m8 = (torch.rand(8, 1, 512, 512, generator=g) > 0.1).float().to(dev)
     f8 = (torch.rand(8, 1, 512, 512, generator=g) > 0.3).float().to(dev)
     s2 = {}
-    for prec in ("f32", "bf16x3", "f16"):
+    for prec in ("f32", "bf16x3", "f16x2", "f16"):
         s2[prec] = stage2.Stage2(s2sd, s2cfg, dev, precision=prec)
         t = _time_loop(lambda: s2[prec].refine(img8, m8, f8))
         out[f"stage2_{prec}_fps"] = round(8 / t, 2)
     if S == 512:
-        # stage 1 + stage 2 per frame: exact fp32, and BASELINE configs[4]'s mode (fp16 MFMA operands in both stages)
+        # stage 1 + stage 2 per frame, both stages in the bench's conv mode (the key names it); and BASELINE configs[4]'s
+        # reduced-precision reading (fp16 MFMA operands in both stages)
         mask = torch.ones(B, 1, S, S, device=dev)
-        # (stage 1 in the bench's conv mode, stage 2 in the same mode)
-        t = _time_loop(lambda: ops.pack_rgb8(s2[hp.precision if hp.precision in s2 else "f32"].refine(hp.driver_pass(ccl, idt, pose, theta), mask, mask)))
-        out["stage1_plus_stage2_f32_fps"] = round(B / t, 2)
+        both = s2[hp.precision if hp.precision in s2 else "f32"]
+        t = _time_loop(lambda: ops.pack_rgb8(both.refine(hp.driver_pass(ccl, idt, pose, theta), mask, mask)))
+        out[f"stage1_plus_stage2_{both.precision}_fps"] = round(B / t, 2)
         hp16 = nets.HotPath(sd, cfg, dev, with_source=False, precision="f16")
         t = _time_loop(lambda: ops.pack_rgb8(s2["f16"].refine(hp16.driver_pass(ccl, idt, pose, theta), mask, mask)))
         out["stage1_plus_stage2_f16_operands_fps"] = round(B / t, 2)
@@ -296,6 +302,32 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
         out["stage1_f16_operands_fps"] = round(B / t, 2)
         del hp16
     del s2
+    # BASELINE configs[1]: "256x256 1-src -> 64-driver batch, HIP 3-D grid_sample only": the two sampler calls of the driver pass
+    # (uv warp of the shared canonical volume, then the head-pose rotation; latent volume [96, 16, 64, 64] at R256 as at R512)
+    # on 64 frames, algorithmic bytes of SURVEY.md section 8(d) / time
+    try:
+        c_, d_, s_ = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
+        gs_ = torch.Generator().manual_seed(15)
+        N64 = 64
+        delta64 = (torch.tanh(torch.randn(N64, 3, d_, s_, s_, generator=gs_)) * 0.02).to(dev)
+        th64 = ops.pose_theta(*[x.to(dev) for x in (1 + 0.05 * torch.randn(N64, 3, generator=gs_), 0.3 * torch.randn(N64, 3, generator=gs_),
+                                                    0.05 * torch.randn(N64, 3, generator=gs_))])[:, :3].contiguous()
+        al64 = torch.empty((N64, c_, d_, s_, s_), device=dev)
+
+        def sampler_pair():
+            for a0 in range(0, N64, hp.sampler_chunk):
+                w_ = ops.grid_sample3d(ccl, delta=delta64[a0:a0 + hp.sampler_chunk], padding_mode=hp.pad, in_layout="ndhwc", out_layout="ndhwc")
+                ops.grid_sample3d(w_, theta=th64[a0:a0 + hp.sampler_chunk], padding_mode=hp.pad, in_layout="ndhwc", out_layout="ncdhw",
+                                  out=al64[a0:a0 + hp.sampler_chunk])
+            return al64
+        t = _time_loop(sampler_pair)
+        vol_b = c_ * d_ * s_ * s_ * 4
+        # per frame: uv call = shared volume / N + delta (3 planes) + warped out; rotation call = warped in + aligned out
+        byts = N64 * (vol_b / N64 + 3 * d_ * s_ * s_ * 4 + vol_b) + N64 * 2 * vol_b
+        out["sampler_only_n64"] = {"frames": N64, "us_per_frame": round(t / N64 * 1e6, 2), "frames_per_s": round(N64 / t, 1),
+                                   "GBps_algorithmic": round(byts / t / 1e9, 1), "frac_of_8TBps": round(byts / t / 1e9 / PEAK_HBM_GBPS, 4)}
+    except Exception as e:
+        out["sampler_only_n64"] = {"error": repr(e)}
     # R256 (BASELINE configs[0]/[1] size): same hot path, 32 frames per step
     cfg256 = config.hot_path_config(overrides={"image_size": 256})
     sd256 = random_init.trained_like_state_dict(cfg256, seed=0, with_source=False)
@@ -347,9 +379,13 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
             w.forward(custome_target_pose_embed=e, custome_target_theta_embed=p, crop=False)
     t = _time_loop(emo_loop, seconds=3.0)
     out["emotion_driver_forward_fps"] = round(16 / t, 2)
-    out["what"] = ("latency_b1_ms: one driver frame through the hot path; fp32_mfma_everywhere_fps: the bench step with the exact-fp32 "
-                   "MFMA kernel in every convolution; f16x2_split_fps: the bench step with the opt-in two-term fp16 operand split; stage2_*: Stage2.refine at 512x512, 8 frames per call (f32 = exact-fp32 MFMA, bf16x3 = fp32 on the bf16 pipes: the default mode, f16 = fp16 operands, configs[4]); "
-                   "stage1_plus_stage2_*: driver pass + refinement + uint8 pack, B frames per call; r256_fps: R256 driver pass, 32 frames "
+    out["what"] = ("latency_b1_ms: one driver frame through the hot path; fp32_mfma_everywhere_fps / bf16x3_split_fps / f16x2_split_fps: "
+                   "the bench step in the fp32 conv modes that are not the headline's (exact-fp32 MFMA everywhere; exact 3-term bf16 split; "
+                   "device-checked 2-term fp16 split); f16x2_without_range_check_fps: the headline mode without its overflow words and "
+                   "guarded recomputation launches; stage2_*: Stage2.refine at 512x512, 8 frames per call (f32 / bf16x3 / f16x2: fp32 "
+                   "modes as above, f16 = reduced precision, fp16 operands, configs[4]); sampler_only_n64: BASELINE configs[1], the two "
+                   "3-D grid_sample calls of the driver pass on 64 frames; "
+                   "stage1_plus_stage2_<mode>_fps: driver pass + refinement + uint8 pack in the named conv mode, B frames per call; r256_fps: R256 driver pass, 32 frames "
                    "per call; pipeline_frames_in_out_fps: InferenceWrapper.animate_frames (uint8 in, embedders, hot path, uint8 out); "
                    "emotion_driver_forward_fps: forward(custome_target_pose_embed=, custome_target_theta_embed=) per frame, PIL out")
     return out
@@ -567,6 +603,7 @@ def main():
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dtype_note": f"tensors, norms, epilogue and accumulation fp32; conv operand form: {hp.precision} (config.conv_arithmetic)",
         "config": {"workload": f"released stage-1 architecture R{S}, full HIP driver pass (pose theta, warp embed, uv WarpGenerator, "
                                f"2x 3-D grid_sample, decoder, uint8 pack), 1 source identity, {B} driver frames per GPU per step",
                    "image_size": S, "frames_per_gpu_per_step": B,

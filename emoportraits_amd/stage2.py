@@ -209,7 +209,8 @@ class Stage2:
     def __init__(self, state_dict, cfg, device="cuda:0", precision=None):
         """precision 'f16': the "fp16 MFMA convs" mode of BASELINE.json configs[4] (fp16 operands, fp32 accumulation,
         fp32 tensors); 'f32': exact-fp32 MFMA everywhere; 'bf16x3': fp32 on the bf16 matrix pipes in the 3x3 layers
-        (csrc/conv_igemm_bf16x3.h).  None: EMO_CONV_PRECISION, else nets.DEFAULT_PRECISION (as nets.HotPath)."""
+        (csrc/conv_igemm_bf16x3.h); 'f16x2': the same layers as the device-checked two-term fp16 split with guarded bf16x3
+        recomputation (nets.DEFAULT_PRECISION).  None: EMO_CONV_PRECISION, else nets.DEFAULT_PRECISION (as nets.HotPath)."""
         import os
         from . import nets
         from .pack import conv_precision
@@ -226,6 +227,8 @@ class Stage2:
     def refine(self, img, mask, face_mask, keep=False):
         """img [B,3,S2,S2] in [0,1] (stage-1 output at output_size_s2), mask = matte [B,1,S2,S2], face_mask [B,1,S2,S2]
         -> clamp(img + decoder(encoder(img*mask)) * (mask*face_mask), 0, 1)     (infer_s2.py:365-375)"""
+        if self.precision == "f16x2":
+            ops.clear_overflow_flags(self.device)       # (range-check words of the fp16-split layers: nets.HotPath._clear_flags)
         lat = self.encoder(ops.mul_mask(img, mask))
         add = self.decoder(lat)
         out = ops.stage2_compose(img, add, mask, face_mask)

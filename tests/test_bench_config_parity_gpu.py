@@ -12,7 +12,7 @@ the other R512 graphs that only existed at R256 in the round-1 tests:
     what that does to the sampled volume.
 
 Tolerances are the ones of tests/test_nets_gpu.py (stage-wise 5e-5 of max / image 5e-4 abs; end to end 1e-3 / 5e-3 abs);
-measured values are printed as PARITY lines and collected into profiles/r2_parity.txt.
+measured values are printed as PARITY lines and collected into profiles/r<round>_parity.txt (tools/collect_profiles.py).
 """
 import os
 import sys
@@ -81,9 +81,9 @@ def test_driver_pass_R512_B16_trained_like_checkpoint_vs_oracle():
     for i in frames:
         with torch.no_grad():
             refs[i] = O.driver_pass(sd, cfg, x["canonical"], x["idt"], x["pose_t"][i:i + 1], x["th_t"][i:i + 1])
-    # every fp32 conv mode is held to the same bound: the default (bf16x3: fp32 on the bf16 matrix pipes), the exact-fp32 MFMA
-    # kernel everywhere, and the opt-in two-term fp16 split
-    for mode in (None, "f32", "f16x2"):
+    # every fp32 conv mode is held to the same bound: the default (f16x2: the device-checked two-term fp16 split), the exact
+    # three-term bf16 split, and the exact-fp32 MFMA kernel everywhere
+    for mode in (None, "bf16x3", "f32"):
         hp = nets.HotPath(sd, cfg, DEV, with_source=False, precision=mode)
         ccl = hp.prepare_canonical(d(x["canonical"]))
         got = hp.driver_pass(ccl, d(x["idt"]), d(x["pose_t"]), d(x["th_t"]), keep=True)
@@ -107,6 +107,8 @@ def test_driver_pass_R512_B16_trained_like_checkpoint_vs_oracle():
             worst["u8_same"] = min(worst["u8_same"], e["u8_same"])
         assert worst["delta_vox"] < 1.5 and worst["saturated"] < 0.05, worst      # the checkpoint is what it claims to be
         assert worst["img_abs"] <= 2e-4 and worst["batch1_abs"] <= 2e-4 and worst["u8_same"] >= 0.999, (hp.precision, worst)
+        if hp.precision == "f16x2":
+            assert hp.overflow_events() == {}, "the trained-like checkpoint tripped the fp16 split's range check"
         if mode is not None:
             del hp
     hp = nets.HotPath(sd, cfg, DEV, with_source=False)

@@ -330,14 +330,15 @@ def test_split_convolution_arithmetic_on_the_cpu():
     assert err(f16x2) < e32
 
 
-@pytest.mark.parametrize("mode,expect", [(None, {"emo_conv_igemm_bf16x3": 26, "emo_conv_igemm_f32": 16}),
+@pytest.mark.parametrize("mode,expect", [("bf16x3", {"emo_conv_igemm_bf16x3": 26, "emo_conv_igemm_f32": 16}),
                                           ("f32", {"emo_conv_igemm_f32": 42}),
                                           # (every fp16-split launch is followed by its guarded bf16x3 recomputation launch)
-                                          ("f16x2", {"emo_conv_igemm_f16x2": 26, "emo_conv_igemm_bf16x3": 26, "emo_conv_igemm_f32": 16})])
+                                          (None, {"emo_conv_igemm_f16x2": 26, "emo_conv_igemm_bf16x3": 26, "emo_conv_igemm_f32": 16})])
 def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect):
     """the host side of the released R512 driver pass without a GPU (tools/host_overhead.py: every kernel entry point of the
-    library returns at once): the launch plan sends the 26 3x3 layers the split kernel covers to it in the default mode, the
-    1x1 / narrow 3-D / head convolutions to the fp32 MFMA kernel, and the whole pass is 95 C-ABI calls"""
+    library returns at once): the launch plan sends the 26 3x3 layers the split kernel covers to it (default mode: as the
+    fp16 split, each launch followed by its guarded bf16x3 launch), the 1x1 / narrow 3-D / head convolutions to the fp32 MFMA
+    kernel, and the whole pass is 95 C-ABI calls (+ 26 guards)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import host_overhead
     from emoportraits_amd import nets
@@ -346,7 +347,7 @@ def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect)
     cfg = config.hot_path_config(overrides={"image_size": 512})
     sd = random_init.trained_like_state_dict(cfg, seed=0, with_source=False)
     hp = nets.HotPath(sd, cfg, "cpu", with_source=False, precision=mode)
-    assert hp.precision == (mode or nets.DEFAULT_PRECISION) and nets.DEFAULT_PRECISION == "bf16x3"
+    assert hp.precision == (mode or nets.DEFAULT_PRECISION) and nets.DEFAULT_PRECISION == "f16x2"
     B = 16
     ccl = hp.prepare_canonical(torch.empty(1, 96, 16, 64, 64))
     stub.calls.clear()
@@ -354,4 +355,4 @@ def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect)
     assert tuple(img.shape) == (B, 3, 512, 512)
     convs = {k: v for k, v in stub.calls.items() if k.startswith("emo_conv_igemm")}
     assert convs == expect, convs
-    assert sum(stub.calls.values()) == 95 + (26 if mode == "f16x2" else 0), dict(stub.calls)
+    assert sum(stub.calls.values()) == 95 + (26 if mode is None else 0), dict(stub.calls)
