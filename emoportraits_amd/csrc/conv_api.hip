@@ -148,7 +148,7 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   a.gn_stats = gn_stats;
   a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0;
   a.in_scale = in_scale; a.out_scale = 1.0f / (in_scale * w_scale);
-  a.sat_flag = sat_flag; a.run_if = run_if; a.stagger_window = 0;
+  a.sat_flag = sat_flag; a.run_if = run_if;
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;

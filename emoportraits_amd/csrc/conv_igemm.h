@@ -82,7 +82,6 @@ struct ConvArgs {
                        // applied by conv_splitk_epilogue_kernel (conv_api.hip), which adds the splits in fixed order
   float* gn_stats;     // or null (needs ksplit == 1): [N][position tiles][Cout][2] = (mean, centred sum of squares) of
                        // the 128 final output values of every (sample, position tile, channel)
-  int stagger_window;  // conv_igemm_bf16x3.h: > 0: the first block of every CU starts up to this many shader cycles late (see there)
   int* sat_flag;       // conv_igemm_bf16x3.h, fp16 two-term split only, or null: set to 1 when a staged value left the fp16 range
   const int* run_if;   // conv_igemm_bf16x3.h, or null: the launch does nothing unless *run_if != 0 (guarded fallback of a layer
                        // whose fp16-split launch raised its sat_flag)

@@ -73,9 +73,6 @@ static __device__ unsigned long long emo_s_tlog[EMO_S_TLOG_N * EMO_S_TLOG_W];
 #else
 #define EMO_S_STAMP(k_)
 #endif
-#ifndef EMO_S_STAGGER_DEFAULT
-#define EMO_S_STAGGER_DEFAULT 0   /* EMO_CONV_STAGGER overrides at run time */
-#endif
 #ifndef EMO_S_PRODUCTS
 #define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
 #endif
@@ -329,56 +326,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 
   if (a.run_if != nullptr && *a.run_if == 0) return;   // guarded fallback launch: the fp16-split launch of the layer stayed in range
   float sat_m = 0.0f;                                    // SPLIT == 2: largest |scaled staged value| this thread has seen
-  // De-phasing.  With one block per CU and blocks of equal length, all 256 CUs run their prologues (patch + weight fetch) and
-  // their epilogues (64 KiB of output each) at the same moment, launch after launch: 16.8 MB bursts that the memory system
-  // serves at its burst rate while the matrix pipes idle (tools/conv_phase_timing.py: prologue 7-9 k cycles, epilogue 12 k,
-  // of a 76-111 k block).  The first block of every CU therefore starts late by its share of `stagger_window`; a CU takes its
-  // next block when the previous one ends, so the offsets persist for the whole launch and the bursts spread out.
-  if (a.stagger_window > 0 && blockIdx.x < 256u) {
-    const unsigned long long until = __builtin_amdgcn_s_memtime() + (((unsigned long long)((blockIdx.x * 97u) & 255u) * (unsigned)a.stagger_window) >> 8);
-    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(16);
-  }
 
-  // work item -> (sample, position tile, channel tile, K split): XCD-contiguous order, channel tile fastest (conv_igemm.h).
-  // A block walks the work items of its XCD's contiguous range with a stride: gridDim.x == n_work (default) is one item per
-  // block; EMO_CONV_BF16X3_PERSISTENT=1 launches min(n_work, CUs) persistent blocks instead.  Measured (profiles/
-  // r3_bf16x3_persistent_ab.txt): +-2 % on six decoder shapes -- the launch of the next workgroup is not what the 12 us of
-  // per-block fixed cost are made of -- and 2.7x SLOWER on one (512 -> 320 with upsample: the CUs of a persistent grid stay in
-  // lock step and ask L2 for the same weight rows at the same moment); parity-tested, off.
-  const int q8 = a.n_work >> 3, r8 = a.n_work & 7;
-  const int xcd = blockIdx.x & 7;
-  const int n_mine = q8 + (xcd < r8 ? 1 : 0);
-  const int l_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int l_stride = (gridDim.x + 7) >> 3;
-  for (int idx8 = blockIdx.x >> 3; idx8 < n_mine; idx8 += l_stride) {
-  int ks = 0;
-  const int L = l_base + idx8;
-#if EMO_S_TIMING
-  unsigned long long tstamp[12];
-  for (int k = 0; k < 12; ++k) tstamp[k] = 0;
-  unsigned long long tw_wait = 0, tw_bar = 0, tw_n = 0;
-  unsigned long long tstep[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // EMO_S_TIMING == 3: cycles per step index of the K loop, summed
-#endif
-  EMO_S_STAMP(0)
-  const int cotile = L % a.n_cotiles;
-  int rest = L / a.n_cotiles;
-  if (a.ksplit > 1) {
-    ks = rest % a.ksplit;
-    rest /= a.ksplit;
-  }
-  const int nptiles = a.tiles_x * a.tiles_y * a.tiles_z;
-  const int n = rest / nptiles;
-  int bx = rest - n * nptiles;
-  const int ptile = bx;
-  const int tx = bx % a.tiles_x; bx /= a.tiles_x;
-  const int ty = bx % a.tiles_y; bx /= a.tiles_y;
-  const int tz = bx;
-  const int x0 = tx * TW, y0 = ty * TR, z0 = tz;
-  const int x0s = UPS ? x0 >> 1 : x0, y0s = UPS ? y0 >> 1 : y0;   // tile origin in source pixels
 
+  // ---- constants of the launch and of the thread ----
   const int HW = a.H * a.W;
   const long DHW = (long)a.D * HW;
-  const float* xn = a.x + (long)n * a.Cin * DHW;
   const bool has_affine = a.scale != nullptr;
   const float in_scale = SPLIT == 3 ? 1.0f : a.in_scale;
   const int padD = a.KD >> 1;
@@ -387,11 +339,8 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   // inf - inf to NaN; +-inf inputs therefore saturate at +-3.39e38, include/emo_hip.h)
   constexpr float CLAMP_HI = SPLIT == 3 ? 3.3895313892515355e38f : 65504.0f;
   const float clamp_lo = a.relu_in ? 0.0f : -CLAMP_HI;
-
   const int nstages_all = a.n_cchunks * a.KD;
-  const int st_begin = ks * a.stages_per_split;
-  const int st_end = min(nstages_all, st_begin + a.stages_per_split);
-  const char* wsrc = reinterpret_cast<const char*>(a.wpk) + ((long)cotile * nstages_all) * (3 * Cfg::WROW_BYTES);
+  const int nptiles = a.tiles_x * a.tiles_y * a.tiles_z;
 
   // ---- staging map: thread t belongs to channel group t / QPG; within the group, lane u < PR * NQ owns interior quad u (4
   //      consecutive pixels of one patch row), lane PR * NQ + 2 * row + side owns one halo pixel.  A halo lane issues the SAME
@@ -408,26 +357,69 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const int h_side = hq & 1;
   const int q_r = is_quad ? q_u / NQ : (is_halo ? hq >> 1 : 0);
   const int q_c = is_quad ? q_u - q_r * NQ : 0;
-  const int q_y = y0s - 1 + q_r;
-  const int q_x = is_quad ? x0s + 4 * q_c : (h_side ? x0s + TWS : x0s - 4);     // first pixel of the lane's 16-byte load
-  const bool q_ok = (is_quad || is_halo) && (unsigned)q_y < (unsigned)a.H && q_x >= 0 && q_x < a.W;
-  const unsigned q_off = q_ok ? (unsigned)(q_y * a.W + q_x) * 4u : 0u;
-  int q_sl[4];                                                                    // LDS slot of pixel i (+ plane * PPL)
+  int q_slb[4];                                           // byte offsets of the lane's four staging slots inside a patch buffer
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int dump = q_g * CHS + i * SUB + PR * NQ1 + (q_u & 3);
     const int own = is_quad ? q_g * CHS + i * SUB + q_r * NQ1 + q_c : q_g * CHS + h_side * SUB + q_r * NQ1 + NQ;
-    q_sl[i] = (is_quad || (is_halo && i == (h_side ? 0 : 3))) ? own : dump;
+    q_slb[i] = ((is_quad || (is_halo && i == (h_side ? 0 : 3))) ? own : dump) * 16;
   }
 
   constexpr int TPH = TP;
   floatx16 acc_lo[TM][TPH], acc_hi[TM][TPH];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TPH; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
+
+  // ---- work items.  Item -> (sample, position tile, channel tile, K split): XCD-contiguous order, channel tile fastest
+  //      (conv_igemm.h).  A block walks the items of its XCD's contiguous range with a stride: min(n_work, CUs) persistent
+  //      blocks by default (no workgroup launch between two items: 3.5-4 k cycles of a 50-110 k cycle item), one block per item
+  //      with EMO_CONV_BF16X3_PERSISTENT=0 (conv_igemm_bf16x3_launch).
+  //      Tried and removed this round: CHAINING consecutive items through one pipeline (the last two stages of an item fetch
+  //      the kernel rows and load / convert the patch of the next item's first stages, so that the next K loop starts behind
+  //      the epilogue without a prologue).  With the loads of the next item's second stage (32 registers) and the cursor state
+  //      live across the epilogue the register allocation of the K loop degraded (260 AGPR spill moves per stage pair against
+  //      47) and the saved prologue was paid back there: 305 vs 303 and 354 vs 361 TF on the two largest layers in the fp16
+  //      split (tools/session/r4_call13.sh) ----
+  const int q8 = a.n_work >> 3, r8 = a.n_work & 7;
+  const int xcd = blockIdx.x & 7;
+  const int n_mine = q8 + (xcd < r8 ? 1 : 0);
+  const int l_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int l_stride = (gridDim.x + 7) >> 3;
+  // the item being computed (it_*) and the tile of its patch loads (lq_*)
+  int it_L = 0, it_cotile = 0, it_ks = 0, it_n = 0, it_ptile = 0, it_x0 = 0, it_y0 = 0, it_z0 = 0, it_st_begin = 0, it_st_end = 0;
+  const char* it_wsrc = nullptr;
+  unsigned lq_off = 0;
+  bool lq_ok = false;
+  int lq_z0 = 0;
+#define EMO_S_DECODE(P_, L_)                                                                          \
+  {                                                                                                   \
+    P_##L = (L_);                                                                                     \
+    P_##cotile = P_##L % a.n_cotiles;                                                                 \
+    int rest_ = P_##L / a.n_cotiles;                                                                  \
+    P_##ks = 0;                                                                                       \
+    if (a.ksplit > 1) {                                                                               \
+      P_##ks = rest_ % a.ksplit;                                                                      \
+      rest_ /= a.ksplit;                                                                              \
+    }                                                                                                 \
+    P_##n = rest_ / nptiles;                                                                          \
+    int bx_ = rest_ - P_##n * nptiles;                                                                \
+    P_##ptile = bx_;                                                                                  \
+    const int tx_ = bx_ % a.tiles_x; bx_ /= a.tiles_x;                                                \
+    const int ty_ = bx_ % a.tiles_y; bx_ /= a.tiles_y;                                                \
+    P_##x0 = tx_ * TW; P_##y0 = ty_ * TR; P_##z0 = bx_;                                               \
+    P_##st_begin = P_##ks * a.stages_per_split;                                                       \
+    P_##st_end = min(nstages_all, P_##st_begin + a.stages_per_split);                                 \
+    P_##wsrc = reinterpret_cast<const char*>(a.wpk) + ((long)P_##cotile * nstages_all) * (3 * Cfg::WROW_BYTES); \
+  }
+// points the patch-load cursor at the tile of item P_: the lane's 16-byte load (its quad, or the aligned quad that contains its
+// halo pixel) and whether it lies inside the image.  Per-lane values are derived where the cursor moves, not carried per item
+#define EMO_S_CURSOR_TO(P_)                                                                           \
+  {                                                                                                   \
+    const int x0s_ = UPS ? P_##x0 >> 1 : P_##x0, y0s_ = UPS ? P_##y0 >> 1 : P_##y0;   /* tile origin in source pixels */ \
+    const int q_y_ = y0s_ - 1 + q_r;                                                                  \
+    const int q_x_ = is_quad ? x0s_ + 4 * q_c : (h_side ? x0s_ + TWS : x0s_ - 4);   /* first pixel of the lane's 16-byte load */ \
+    lq_ok = (is_quad || is_halo) && (unsigned)q_y_ < (unsigned)a.H && q_x_ >= 0 && q_x_ < a.W;        \
+    lq_off = lq_ok ? (unsigned)(q_y_ * a.W + q_x_) * 4u : 0u;                                         \
+    lq_z0 = P_##z0;                                                                                   \
+  }
 
   // LDS byte offsets of the lane's operands: weight fragment (+ row buffer / plane / tap column immediates) and, for every tap,
   // the patch slot of the lane's output pixel (+ half * CHS: the lane's 8-channel group; + buffer / plane immediates)
@@ -453,9 +445,6 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   }
 #define EMO_S_B_OFF(j_, r_, s_) (UPS ? ((r_) == 2 ? b_off[j_][0][s_] + NQ1 * 16 : b_off[j_][(r_) < NBR ? (r_) : 0][s_]) \
                                      : b_off[j_][0][s_] + (r_) * NQ1 * 16)
-  int q_slb[4];                                           // byte offsets of the lane's four staging slots inside a patch buffer
-#pragma unroll
-  for (int i = 0; i < 4; ++i) q_slb[i] = q_sl[i] * 16;
 
   const char* const lds_c = reinterpret_cast<const char*>(smem);
   char* const lds_w = reinterpret_cast<char*>(smem);
@@ -482,7 +471,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   int q_tix[2];
   floatx4 q_sc, q_sh;                       // scale / shift of the four channels being converted (read at the top of the step)
   opx8 cv_h, cv_m, cv_l;                    // the pixel under conversion: 8 channels per plane, filled in two halves
-  const emo_intx4 xrs = emo_raw_buffer(xn);
+  emo_intx4 xrs = emo_raw_buffer(a.x);      // (re-based on the item's sample by the prologue)
   unsigned usoff[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)u * (unsigned)DHW * 4u));
@@ -493,7 +482,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #define EMO_S_SET_STAGE_VARS()                                                                        \
   {                                                                                                   \
     n_ci0 = ld_cc * KC;                                                                               \
-    n_zu = z0 + ld_kd - padD;                                                                         \
+    n_zu = lq_z0 + ld_kd - padD;                                                                      \
     n_zv = (unsigned)n_zu < (unsigned)a.D;                                                            \
   }
 #define EMO_S_SET_STAGE_INIT(stage_)                                                                  \
@@ -518,10 +507,10 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     const int c0_ = n_ci0 + q_g * 8;                                                                  \
     const bool cv_ = c0_ < a.Cin;                                                                     \
     const int cs_ = cv_ ? c0_ : 0;                                                                    \
-    const bool keep_ = q_ok && cv_ && n_zv;                                                           \
+    const bool keep_ = lq_ok && cv_ && n_zv;                                                          \
     q_lo[b_] = keep_ ? clamp_lo : 0.0f;                                                               \
     q_hi[b_] = keep_ ? CLAMP_HI : 0.0f;                                                               \
-    q_vo = q_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;         \
+    q_vo = lq_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;        \
     q_tix[b_] = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                     \
   }
 #define EMO_S_ISSUE_LOADS(b_, u0_, u1_)                                                               \
@@ -568,15 +557,15 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     }                                                                                                 \
   }
 // one kernel row of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
-#define EMO_S_DMA_PIECE(stage_, row_, i_)                                                             \
+#define EMO_S_DMA_PIECE(ptr_, row_, i_)                                                               \
   {                                                                                                   \
-    const char* ws_ = wsrc + ((long)(stage_) * 3 + (row_)) * Cfg::WROW_BYTES;                         \
+    const char* ws_ = (ptr_) + (row_) * Cfg::WROW_BYTES;                                              \
     const int j = (SPLIT == 2 || (i_) < 4) ? wave + 4 * (i_) : 16 + (wave & 1);                       \
     emo_dma16_pinned(ws_ + j * 1024 + lane * 16,                                                      \
                      smem_lds + (unsigned)(Cfg::OFF_W * 16 + (row_) * Cfg::WROW_BYTES + j * 1024));   \
   }
-#define EMO_S_DMA_ROW(stage_, row_)                                                                   \
-  { _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(stage_, row_, i) }
+#define EMO_S_DMA_ROW(ptr_, row_)                                                                     \
+  { _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(ptr_, row_, i) }
 #define EMO_S_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #if EMO_S_TIMING == 2
 // measurement build: how long every wave sits in the waitcnt of a K-loop barrier (memory / LDS latency it did not hide) and in
@@ -596,6 +585,30 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #endif
 #define EMO_S_LOOP_BARRIER(n_) { if (EMO_S_ABLATE & 2) { EMO_S_WAIT(n_); } else { EMO_S_BARRIER(n_); } }
 
+
+  // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
+  constexpr int NPROD = SPLIT == 3 ? EMO_S_PRODUCTS : 3;
+  constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
+
+  for (int idx8 = blockIdx.x >> 3; idx8 < n_mine; idx8 += l_stride) {
+  EMO_S_DECODE(it_, l_base + idx8)
+#if EMO_S_TIMING
+  unsigned long long tstamp[12];
+  for (int k = 0; k < 12; ++k) tstamp[k] = 0;
+  unsigned long long tw_wait = 0, tw_bar = 0, tw_n = 0;
+  unsigned long long tstep[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // EMO_S_TIMING == 3: cycles per step index of the K loop, summed
+#endif
+  EMO_S_STAMP(0)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TPH; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
+
+  xrs = emo_raw_buffer(a.x + (long)it_n * a.Cin * DHW);
+  EMO_S_CURSOR_TO(it_)
   // ---- prologue: the kernel rows of the first stage by DMA, the loads of the first two stages, the first patch converted into
   //      P[0]; it leaves the state every stage leaves to the next: buffer 1 holds the landed loads of the second stage, the
   //      tables are that stage's, DMA(first stage, row 2) is in flight, fragment set 0 holds step 0 ----
@@ -608,20 +621,20 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   for (int k = 0; k < NTE; ++k) {
     const int c = tid + 256 * k;
     const bool real = has_affine && c < a.Cin;
-    te_sc[k] = real ? a.scale[(long)n * a.Cin + c] : 1.0f;
-    te_sh[k] = real ? a.shift[(long)n * a.Cin + c] : 0.0f;
+    te_sc[k] = real ? a.scale[(long)it_n * a.Cin + c] : 1.0f;
+    te_sh[k] = real ? a.shift[(long)it_n * a.Cin + c] : 0.0f;
   }
   if (tid < BM && a.bias != nullptr && a.partial == nullptr) {
-    const int co_ = cotile * BM + tid;
+    const int co_ = it_cotile * BM + tid;
     te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];
   }
-  EMO_S_DMA_ROW(st_begin, 0);
-  EMO_S_DMA_ROW(st_begin, 1);
-  EMO_S_SET_STAGE_INIT(st_begin);
+  EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 0);
+  EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 1);
+  EMO_S_SET_STAGE_INIT(it_st_begin);
   EMO_S_ISSUE_BEGIN(0)
   EMO_S_ISSUE_LOADS(0, 0, 8)
   {
-    const int st1 = (st_begin + 1) < st_end ? (st_begin + 1) : st_begin;
+    const int st1 = (it_st_begin + 1) < it_st_end ? (it_st_begin + 1) : it_st_begin;
     EMO_S_SET_STAGE_STEP(st1);
   }
   EMO_S_ISSUE_BEGIN(1)
@@ -648,14 +661,8 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     EMO_S_CONV_HALF(0, Cfg::OFF_P, i, 1)
   }
   EMO_S_HALF_TABLE(1, 0)                 // (what step 0 of the first stage converts with)
-  EMO_S_DMA_ROW(st_begin, 2);
+  EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 2);
   EMO_S_BARRIER(Cfg::NDMA);              // (LDS stores of P[0] visible; DMA(first stage, 2) stays in flight)
-  EMO_S_LOAD_FRAGS(0, Cfg::OFF_W, Cfg::OFF_P, 0, 0)
-
-  // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
-  constexpr int NPROD = SPLIT == 3 ? EMO_S_PRODUCTS : 3;
-  constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
-  constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
 
   // ---- K loop, two stages per iteration (buffer parities and fragment sets are compile-time constants).  Stage cg, parity par:
   //        steps 0 .. 7   half a pixel each of the patch of stage cg + 1 is converted from qv[par ^ 1] into P[par ^ 1]
@@ -667,15 +674,16 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   //                       DMA(cg + 1, 2) and the first fragments of stage cg + 1 from P[par ^ 1]
   //      every wave issues exactly NDMA pieces per row and 8 quad loads per stage, so the counts are uniform ----
   EMO_S_STAMP(1)
-  const int st_last = st_end - 1;
-  for (int cg0 = st_begin; cg0 < st_end; cg0 += 2) {
+  EMO_S_LOAD_FRAGS(0, Cfg::OFF_W, Cfg::OFF_P, 0, 0)
+  for (int cg0 = it_st_begin; cg0 < it_st_end; cg0 += 2) {
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       const int cg = cg0 + par;
-      if (cg >= st_end) break;
+      if (cg >= it_st_end) break;
       const int pcur = Cfg::OFF_P + par * PBUF, pnxt = Cfg::OFF_P + (par ^ 1) * PBUF;
-      const int cg1 = (cg + 1) < st_end ? (cg + 1) : st_last;     // clamped on the last stages: harmless re-stage
-      const int cg2 = (cg + 2) < st_end ? (cg + 2) : st_last;
+      // stage cg + 1 (its weight rows are fetched during this stage) and stage cg + 2 (its patch is loaded during this stage),
+      // clamped to the last stage: a harmless re-stage
+      const char* const dma_ptr = it_wsrc + (long)((cg + 1) < it_st_end ? cg + 1 : it_st_end - 1) * (3 * Cfg::WROW_BYTES);
       if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int gs = 0; gs < 9; ++gs) {
@@ -688,7 +696,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
           if (EMO_S_ABLATE & 5) { EMO_S_LOOP_BARRIER(0) }       // (ablation builds issue fewer loads: drain instead of counting)
           else if (r == 1) { EMO_S_LOOP_BARRIER(Cfg::NDMA + 8) } else { EMO_S_LOOP_BARRIER(Cfg::NDMA) }
           if (r == 0) {
-            EMO_S_SET_STAGE_STEP(cg2);
+            EMO_S_SET_STAGE_STEP((cg + 2) < it_st_end ? cg + 2 : it_st_end - 1);
             EMO_S_ISSUE_BEGIN(par)
           }
           if (r == 2) EMO_S_TOUCH_QUAD(par)
@@ -708,13 +716,13 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
           for (int pl = 0; pl < NPL; ++pl) {
             EMO_S_LOAD_FRAGS_PLANE(fnxt, pl, wbn, pbn, rn, sn)
             if (s == 2) {
-              if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(cg1, r, pl)
+              if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(dma_ptr, r, pl)
               if (r == 0 && !(EMO_S_ABLATE & 4)) EMO_S_ISSUE_LOADS(par, pl * UPP, (pl + 1) * UPP < 8 ? (pl + 1) * UPP : 8)
             }
           }
           if (s == 2) {
 #pragma unroll
-            for (int i = NPL; i < Cfg::NDMA; ++i) { if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(cg1, r, i) }
+            for (int i = NPL; i < Cfg::NDMA; ++i) { if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(dma_ptr, r, i) }
           }
         }
         if (gs < 8) {
@@ -762,10 +770,59 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     }
   }
   EMO_S_STAMP(2)
-  EMO_S_WAIT(0);      // the re-issued loads / DMA of the clamped last stages are dead: drain them
+  // the re-issued loads / DMA of the clamped last stages are dead: drain them (from here on nothing pinned is in flight, the
+  // epilogue is ordinary compiler-scheduled code)
+  EMO_S_WAIT(0);
   EMO_S_STAMP(5)
-  __syncthreads();    // ... and the LDS they target is reused by the epilogue
+  __syncthreads();    // every wave is past its last fragment read of this item's last stage: its patch buffer is the epilogue's scratch
   EMO_S_STAMP(6)
+
+  {
+    // transposition scratch: the patch buffer of the last stage, or a region of its own
+    const int last_par = (it_st_end - it_st_begin - 1) & 1;
+    float* const scratch = smem + (Cfg::EPI_IN_PATCH ? (Cfg::OFF_P + last_par * PBUF) * 4 : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
+    conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(a, acc_lo, acc_hi, scratch, smem + Cfg::OFF_BIAS_F,
+                                                                      smem + Cfg::OFF_STAT_F, it_n, it_cotile, it_ptile, it_ks, it_x0,
+                                                                      it_y0, it_z0, wp, half, l32, lane, tid
+#if EMO_S_TIMING
+                                                                      , tstamp
+#endif
+                                                                      );
+  }
+  if constexpr (SPLIT == 2) {
+    if (a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
+  }
+#if EMO_S_TIMING
+  EMO_S_STAMP(3)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  EMO_S_STAMP(4)
+  if (tid == 0 && it_L < EMO_S_TLOG_N) {
+    unsigned long long* t_ = emo_s_tlog + (long)it_L * EMO_S_TLOG_W;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) t_[k] = tstamp[k];
+    t_[12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+    t_[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+    t_[14] = (unsigned long long)blockIdx.x;
+  }
+#if EMO_S_TIMING == 3
+  if (lane == 0 && it_L < EMO_S_TLOG_N / 8) {   // per-step cycles of every wave (rows N/4 .. 3N/4)
+    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)it_L * 4 + wave) * EMO_S_TLOG_W;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w_[k] = tstep[k];
+    w_[9] = (unsigned long long)(it_st_end - it_st_begin);
+  }
+#endif
+#if EMO_S_TIMING == 2
+  if (lane == 0 && it_L < EMO_S_TLOG_N / 8) {   // per-wave barrier accounting in rows N/4 .. 3N/4 of the log (first N/8 items)
+    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)it_L * 4 + wave) * EMO_S_TLOG_W;
+    w_[0] = tw_wait; w_[1] = tw_bar; w_[2] = tw_n; w_[3] = tstamp[2] - tstamp[1];
+  }
+#endif
+#endif
+  // the next prologue overwrites the tables, the statistics exchange and (conversion) the patch buffer the epilogue transposed
+  // through: every wave must be out of the epilogue first
+  __syncthreads();
+  }
 #undef EMO_S_SET_STAGE_VARS
 #undef EMO_S_SET_STAGE_INIT
 #undef EMO_S_SET_STAGE_STEP
@@ -783,50 +840,8 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #undef EMO_S_LOAD_FRAGS_PLANE
 #undef EMO_S_LOAD_FRAGS
 
-  {
-    // transposition scratch: the patch buffer of the last stage (every wave is past its last fragment read: barrier above)
-    const int last_par = (st_end - st_begin - 1) & 1;
-    float* const scratch = smem + (Cfg::EPI_IN_PATCH ? (Cfg::OFF_P + last_par * PBUF) * 4 : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
-    conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(a, acc_lo, acc_hi, scratch, smem + Cfg::OFF_BIAS_F,
-                                                                      smem + Cfg::OFF_STAT_F, n, cotile, ptile, ks, x0, y0, z0, wp,
-                                                                      half, l32, lane, tid
-#if EMO_S_TIMING
-                                                                      , tstamp
-#endif
-                                                                      );
-  }
-  if constexpr (SPLIT == 2) {
-    if (a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
-  }
-#if EMO_S_TIMING
-  EMO_S_STAMP(3)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  EMO_S_STAMP(4)
-  if (tid == 0 && L < EMO_S_TLOG_N) {
-    unsigned long long* t_ = emo_s_tlog + (long)L * EMO_S_TLOG_W;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) t_[k] = tstamp[k];
-    t_[12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
-    t_[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
-    t_[14] = (unsigned long long)blockIdx.x;
-  }
-#if EMO_S_TIMING == 3
-  if (lane == 0 && L < EMO_S_TLOG_N / 8) {   // per-step cycles of every wave (rows N/4 .. 3N/4)
-    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)L * 4 + wave) * EMO_S_TLOG_W;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) w_[k] = tstep[k];
-    w_[9] = (unsigned long long)(st_end - st_begin);
-  }
-#endif
-#if EMO_S_TIMING == 2
-  if (lane == 0 && L < EMO_S_TLOG_N / 8) {   // per-wave barrier accounting in rows N/4 .. 3N/4 of the log (first N/8 items)
-    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)L * 4 + wave) * EMO_S_TLOG_W;
-    w_[0] = tw_wait; w_[1] = tw_bar; w_[2] = tw_n; w_[3] = tstamp[2] - tstamp[1];
-  }
-#endif
-#endif
-  __syncthreads();    // the next work item's prologue overwrites the LDS the epilogue exchanged its statistics through
-  }
+#undef EMO_S_DECODE
+#undef EMO_S_CURSOR_TO
 }
 
 template <int TR, int TW, bool UPS, int SPLIT = 3>
@@ -847,7 +862,9 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   auto kern = conv_igemm_bf16x3_kernel<TR, TW, UPS, SPLIT>;
   const int rc = emo_raise_dynamic_lds(kern);
   if (rc != EMO_OK) return rc;
-  static const int persistent = [] { const char* e = getenv("EMO_CONV_BF16X3_PERSISTENT"); return e ? atoi(e) : 0; }();
+  // persistent blocks (min(n_work, CUs)) by default: no workgroup launch between the items of a CU (kernel comment; measured
+  // +2 % on the bench step, tools/session/r4_call12.sh); EMO_CONV_BF16X3_PERSISTENT=0 launches one block per item (A/B)
+  static const int persistent = [] { const char* e = getenv("EMO_CONV_BF16X3_PERSISTENT"); return e ? atoi(e) : 1; }();
   static const int ncu = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
@@ -859,16 +876,6 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
   if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
   a.n_work = (int)(nt * cot * a.N * a.ksplit);
-  {
-    // de-phasing window (kernel comment): a block lasts about stages x 9 steps x 4 * NPROD MFMAs x 40 cycles + 25 k; spread the
-    // CUs over one block length, but never spend more than ~1 % of the launch on it (half the window is lost at the tail)
-    static const int stagger = [] { const char* e = getenv("EMO_CONV_STAGGER"); return e ? atoi(e) : EMO_S_STAGGER_DEFAULT; }();
-    const long t_block = (long)a.stages_per_split * 9 * 4 * Cfg::NPROD * 40 + 25000;
-    const long per_cu = (a.n_work + ncu - 1) / ncu;
-    long win = t_block < per_cu * t_block / 50 ? t_block : per_cu * t_block / 50;
-    if (per_cu < 2) win = 0;
-    a.stagger_window = stagger ? (int)(win > 0x3fffffffL ? 0x3fffffffL : win) : 0;
-  }
   // (a guarded fallback launch is normally skipped: min(n_work, CUs) blocks read the flag and leave instead of n_work)
   const int grid = (persistent || a.run_if != nullptr) && a.n_work > ncu ? ncu : a.n_work;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)Cfg::LDS_BYTES, s, a);

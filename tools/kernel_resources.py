@@ -23,7 +23,7 @@ from emoportraits_amd import build as B  # noqa: E402
 
 
 def resources(src):
-    cmd = [B.HIPCC] + B.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
+    cmd = [B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(os.path.basename(src), []) + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     cur, rows = None, []
     for line in r.stderr.splitlines():
@@ -135,7 +135,8 @@ def inflight_reads(lines):
 def loop_scratch(src):
     """per kernel of `src`: (name, scratch instructions between the first pinned load and the last MFMA, scratch instructions in
     total, reads of possibly-in-flight load destinations)"""
-    cmd = [B.HIPCC] + B.FLAGS + ["--cuda-device-only", "-S", src, "-o", "-"]
+    # (the per-file flags of the build: the listing audited is the code that ships)
+    cmd = [B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(os.path.basename(src), []) + ["--cuda-device-only", "-S", src, "-o", "-"]
     asm = subprocess.run(cmd, capture_output=True, text=True).stdout.splitlines()
     out, name, lines = [], None, []
     for line in asm + ["\t.end_of_file -- Begin function"]:
