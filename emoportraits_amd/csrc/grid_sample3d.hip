@@ -210,6 +210,12 @@ __device__ __forceinline__ void stage_taps(TapRec* __restrict__ recs, const floa
   }
 }
 
+// FMA (variant bit 4 of the channels-last kernels, opt-in): coordinates, floor, corner indices and the eight weights are the
+// same bit-exact arithmetic; only the accumulation changes from ATen's separate multiply and add per corner (64 VALU
+// instructions per item) to acc = fma(v, w, acc) in packed form (16 v_pk_fma_f32).  Values then differ from ATen's CPU kernel
+// by the product roundings that are skipped: <= 8 * 2^-24 * max |v w| absolute (tests/test_grid_sample_gpu.py).
+typedef float emo_f2 __attribute__((ext_vector_type(2)));
+template <bool FMA = false>
 __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, const TapRec& r, unsigned row_bytes,
                                               unsigned qbyte) {
   float4 v[8];
@@ -221,6 +227,26 @@ __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, c
   for (int k = 0; k < 8; ++k)
     v[k] = *reinterpret_cast<const float4*>(vbytes + ((unsigned)r.off[k] * row_bytes + qbyte));
 #endif
+  if constexpr (FMA) {
+    emo_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    if (__all(r.inb == 0xffu)) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const emo_f2 w2 = {r.w[k], r.w[k]};
+        a01 = __builtin_elementwise_fma(emo_f2{v[k].x, v[k].y}, w2, a01);
+        a23 = __builtin_elementwise_fma(emo_f2{v[k].z, v[k].w}, w2, a23);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool in = (r.inb >> k) & 1u;
+        const emo_f2 w2 = {r.w[k], r.w[k]};
+        a01 = __builtin_elementwise_fma(emo_f2{in ? v[k].x : 0.0f, in ? v[k].y : 0.0f}, w2, a01);
+        a23 = __builtin_elementwise_fma(emo_f2{in ? v[k].z : 0.0f, in ? v[k].w : 0.0f}, w2, a23);
+      }
+    }
+    return make_float4(a01[0], a01[1], a23[0], a23[1]);
+  }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   // wave-uniform: does every lane of this wave have all 8 corners in range?
   if (__all(r.inb == 0xffu)) {
@@ -262,7 +288,7 @@ struct ItemWalk {
 };
 
 // NDHWC -> NDHWC, 1-D grid of N * ceil(nvox/VPB) blocks
-template <int PAD, int MODE, int VPB, int ORDER>
+template <int PAD, int MODE, int VPB, int ORDER, bool FMA>
 __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -282,7 +308,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
   ItemWalk w(threadIdx.x, LPV);
   for (int item = threadIdx.x; item < nitems; item += 256, w.next()) {
     const TapRec r = recs[w.v];
-    EMO_GS3D_STORE(&obase[item], gather_quad(vbytes, r, row_bytes, (unsigned)w.q * 16u));
+    EMO_GS3D_STORE(&obase[item], gather_quad<FMA>(vbytes, r, row_bytes, (unsigned)w.q * 16u));
   }
 }
 
@@ -315,7 +341,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_brick_kernel(
 }
 
 // NDHWC -> NCDHW, 1-D grid; dynamic LDS = VPB tap records + C * (VPB + 1) floats (transpose tile)
-template <int PAD, int MODE, int VPB, int ORDER>
+template <int PAD, int MODE, int VPB, int ORDER, bool FMA>
 __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
     const float* __restrict__ lin_x, const float* __restrict__ lin_y, const float* __restrict__ lin_z,
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
   for (int item = threadIdx.x; item < nitems; item += 256, w.next()) {
     const int v = w.v, q = w.q;
     const TapRec r = recs[v];
-    const float4 acc = gather_quad(vbytes, r, row_bytes, (unsigned)q * 16u);
+    const float4 acc = gather_quad<FMA>(vbytes, r, row_bytes, (unsigned)q * 16u);
     const int c = q * 4;
     tile[(c + 0) * LD + v] = acc.x;
     tile[(c + 1) * LD + v] = acc.y;
@@ -362,7 +388,7 @@ __global__ __launch_bounds__(256) void gs3d_cl2ncdhw_v2_kernel(
 
 constexpr int CL_VPB = 64;      // output voxels per block of the row-shaped kernels
 
-template <int PAD, int MODE, int ORDER>
+template <int PAD, int MODE, int ORDER, bool FMA = false>
 int launch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                  const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                  long vol_bstride, bool out_cl, hipStream_t s, int nt_out = 0) {
@@ -371,15 +397,15 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
   const long total = (long)bps * N;
   if (total > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
   if (ORDER == 3 && ((N & 7) || (bps % Do) || (nvox % CL_VPB) || ((bps / Do) % 8)))   // whole slices / groups, N % 8 == 0
-    return launch_cl_v2<PAD, MODE, 1>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
-                                      out_cl, s, nt_out);
+    return launch_cl_v2<PAD, MODE, 1, FMA>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                           out_cl, s, nt_out);
   if (out_cl) {
-    hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, CL_VPB, ORDER>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
+    hipLaunchKernelGGL((gs3d_cl_v2_kernel<PAD, MODE, CL_VPB, ORDER, FMA>), dim3((unsigned)total), dim3(256), 0, s, vol, grid,
                        theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
   } else {
     const size_t lds = CL_VPB * sizeof(TapRec) + (size_t)C * (CL_VPB + 1) * sizeof(float);
     if (lds > 64 * 1024) return EMO_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, CL_VPB, ORDER>), dim3((unsigned)total), dim3(256), lds, s, vol,
+    hipLaunchKernelGGL((gs3d_cl2ncdhw_v2_kernel<PAD, MODE, CL_VPB, ORDER, FMA>), dim3((unsigned)total), dim3(256), lds, s, vol,
                        grid, theta, lin_x, lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps, nt_out);
   }
   return emo_launch_status();
@@ -389,13 +415,14 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
 // Do / Ho / Wo multiples of 4): half the L1 fills per voxel, the uv call alone 11.7 instead of 12.3 us per frame -- but the
 // rotation call that reads its output back is then 0.6-0.8 us slower (its blocks walk the volume in row order), so the pair
 // is 1.3 us per frame slower: opt-in.  2 = non-temporal stores of an NCDHW output (the driver pass's rotation call).
+// 4 = fused multiply-add accumulation (gather_quad<true>: taps bit-identical, values within 8 * 2^-24 * max|v w| of ATen).
 // Default: 64-voxel rows, XCD-contiguous, and for a volume shared by N % 8 == 0 samples also row-group-major over the XCD's
 // samples.  (profiles/r3_sampler_nt_stores_ab.jsonl, r3_sampler_nt_out_ab.jsonl)
 template <int PAD, int MODE>
 int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                    const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                    long vol_bstride, bool out_cl, int variant, hipStream_t s) {
-  if (variant < 0 || variant > 3) return EMO_ERR_BAD_ARG;
+  if (variant < 0 || variant > 7) return EMO_ERR_BAD_ARG;
   const int nt_out = (variant & 2) && !out_cl;
   if ((variant & 1) && out_cl && !(Do & 3) && !(Ho & 3) && !(Wo & 3)) {
     const int bps = (Do * Ho * Wo) >> 6;
@@ -404,6 +431,13 @@ int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, cons
     hipLaunchKernelGGL((gs3d_cl_brick_kernel<PAD, MODE, 1>), dim3((unsigned)total), dim3(256), 0, s, vol, grid, theta, lin_x,
                        lin_y, lin_z, out, C, D, H, W, Do, Ho, Wo, vol_bstride, bps);
     return emo_launch_status();
+  }
+  if (variant & 4) {      // fused multiply-add accumulation (gather_quad<true>): row kernels only
+    if (vol_bstride == 0 && N >= 8)
+      return launch_cl_v2<PAD, MODE, 3, true>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                              out_cl, s, nt_out);
+    return launch_cl_v2<PAD, MODE, 1, true>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,
+                                            out_cl, s, nt_out);
   }
   if (vol_bstride == 0 && N >= 8)
     return launch_cl_v2<PAD, MODE, 3>(vol, grid, theta, lin_x, lin_y, lin_z, out, N, C, D, H, W, Do, Ho, Wo, vol_bstride,

@@ -75,7 +75,9 @@ const char* emo_build_info(void);
  *         (networks/volumetric_avatar/warp_generator_resnet.py:178) consumed without materialising `warp`.
  *   variant    0 = default kernels.  NCDHW -> NCDHW: channels per block of the direct gather (1..C).  NDHWC input, bits:
  *         1 = 4 x 4 x 4 output bricks per block instead of 64-voxel rows (NDHWC output); 2 = non-temporal stores of an
- *         NCDHW output (a result that is read much later: the driver pass's rotation call).
+ *         NCDHW output (a result that is read much later: the driver pass's rotation call); 4 = fused multiply-add accumulation
+ *         of the eight corners (opt-in: coordinates, floor, corner indices and weights stay bit-identical to ATen's CPU kernel,
+ *         the sampled VALUES differ from it by the skipped product roundings, <= 8 * 2^-24 * max |v w| absolute).
  *         For the LDS-staged tile kernels (in_layout EMO_LAYOUT_P4, or NCDHW -> NCDHW with bit 30 set) it is a tuning word:
  *         bits 3..0 / 7..4 / 11..8 log2 of the output tile extents x / y / z (all 0: default), 16..12 channel units per
  *         block, 24..17 LDS per block in KiB, bit 25: 512-thread blocks.  tile voxels = threads or 2 * threads.

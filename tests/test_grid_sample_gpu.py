@@ -87,6 +87,42 @@ def test_random_shapes_vs_torch_cpu(pm, shape):
         assert torch.equal(got, ref), f"{name} {pm} {shape}"
 
 
+@pytest.mark.parametrize("pm", PADS)
+def test_fma_accumulation_mode_keeps_the_taps_and_stays_within_the_product_roundings(pm):
+    """variant bit 4 of the channels-last kernels (include/emo_hip.h): the index arithmetic is untouched -- a lattice-aligned grid
+    (every weight 0 or 1) therefore reproduces ATen bit for bit, which pins the corner selection -- and on a generic grid the
+    values differ from ATen's separate multiply / add by at most the eight skipped product roundings"""
+    g = torch.Generator().manual_seed(21)
+    N, C, D, H, W = 3, 24, 6, 10, 12
+    vol = torch.randn(N, C, D, H, W, generator=g)
+    vcl = ops.volume_to_channels_last(vol.to(DEV))
+    # (1) grid points exactly on voxel centres (unnormalised coordinate integral): one corner has weight 1
+    zi, yi, xi = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    exact = torch.stack([(2 * xi + 1) / W - 1, (2 * yi + 1) / H - 1, (2 * zi + 1) / D - 1], -1).float()[None].expand(N, -1, -1, -1, -1).contiguous()
+    for out_layout in ("ndhwc", "ncdhw"):
+        ref = F.grid_sample(vol, exact, padding_mode=pm, align_corners=False)
+        got = ops.grid_sample3d(vcl, exact.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout=out_layout, variant=4)
+        got = ops.volume_to_channels_first(got).cpu() if out_layout == "ndhwc" else got.cpu()
+        plain = ops.grid_sample3d(vcl, exact.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw").cpu()
+        assert torch.equal(plain, ref)
+        assert (got - ref).abs().max().item() <= 2.0 ** -22 * vol.abs().max().item()      # weights 1 - eps roundings only
+    # (2) generic grid with out-of-range points
+    grid = torch.rand(N, 5, 7, 9, 3, generator=g) * 2.6 - 1.3
+    ref = F.grid_sample(vol, grid, padding_mode=pm, align_corners=False)
+    for out_layout in ("ndhwc", "ncdhw"):
+        got = ops.grid_sample3d(vcl, grid.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout=out_layout, variant=4)
+        got = ops.volume_to_channels_first(got).cpu() if out_layout == "ndhwc" else got.cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= 8 * 2.0 ** -24 * vol.abs().max().item(), err
+        assert not torch.equal(got, ref) or pm == "zeros"        # (it IS a different rounding sequence)
+    # shared volume + analytic head-pose warp (the driver pass's second call)
+    th = torch.eye(4)[None, :3].repeat(8, 1, 1) + 0.05 * torch.randn(8, 3, 4, generator=g)
+    v1 = ops.volume_to_channels_last(vol[:1].to(DEV))
+    a = ops.grid_sample3d(v1, theta=th.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw").cpu()
+    b = ops.grid_sample3d(v1, theta=th.to(DEV), padding_mode=pm, in_layout="ndhwc", out_layout="ncdhw", variant=4).cpu()
+    assert (a - b).abs().max().item() <= 8 * 2.0 ** -24 * vol.abs().max().item()
+
+
 def test_tile_tuning_word_with_too_little_lds_is_rejected():
     """lds_kib below header + scratch + a minimal stage: EMO_ERR_BAD_ARG instead of an unsigned underflow of the stage size
     (gs3d_tile_launch.h); the same word is fine where no scratch is needed"""
