@@ -104,8 +104,12 @@ struct ConvCfgS {
   static constexpr int OFF_P = 0;                        // the two patch buffers first: with the buffer a compile-time constant
                                                          // (stage loop unrolled by two) every fragment read but one plane's is
                                                          // lane base + immediate offset (ds_read offsets reach 64 KiB)
-  static constexpr int OFF_W = 2 * PBUF;                 // the three kernel-row weight buffers
-  static constexpr int OFF_SCT = OFF_W + 3 * WROW;       // scale / shift tables (fp32)
+  static constexpr int OFF_W = 2 * PBUF;                 // the kernel-row weight buffers: three rows, recycled row by row behind
+                                                         // three barriers per stage (NWB = 1) -- or, where LDS has the room (the
+                                                         // two-plane fp16 split), two whole stages: ONE barrier per stage
+  static constexpr int NWB = SPLIT == 2 ? 2 : 1;
+  static constexpr int WSTAGE = 3 * WROW;                // one stage of weights (three kernel rows)
+  static constexpr int OFF_SCT = OFF_W + NWB * WSTAGE;   // scale / shift tables (fp32)
   static constexpr int SCT = 1024;
   // epilogue (conv_epilogue_rows): per-block bias table, the GroupNorm (mean, M2) exchange, and per wave a [32 channels][64
   // positions] fp32 transposition scratch.  The scratch lives in the patch buffer the last stage has just finished with when
@@ -116,7 +120,8 @@ struct ConvCfgS {
   static constexpr int OFF_STAT_F = OFF_BIAS_F + BM;                   // [WGP][BM][2]
   static constexpr int OFF_EPI_F = OFF_STAT_F + 2 * WGP * BM;
   static constexpr bool EPI_IN_PATCH = PBUF * 4 >= WGP * EPI_WAVE;
-  static constexpr int LDS_BYTES = (OFF_EPI_F + (EPI_IN_PATCH ? 0 : WGP * EPI_WAVE)) * 4;
+  static constexpr bool EPI_IN_W = !EPI_IN_PATCH && NWB == 2 && WSTAGE * 4 >= WGP * EPI_WAVE;   // the idle weight stage buffer
+  static constexpr int LDS_BYTES = (OFF_EPI_F + ((EPI_IN_PATCH || EPI_IN_W) ? 0 : WGP * EPI_WAVE)) * 4;
   // LDS-DMA instructions EVERY wave issues per kernel row (1 KiB each).  3 planes: 18 pieces, waves 2, 3 re-copy pieces 16,
   // 17 (uniform vmcnt counts); 2 planes: 12 pieces, 3 per wave
   static constexpr int NDMA = SPLIT == 3 ? 5 : 3;
@@ -461,6 +466,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 
   float* const sct = smem + Cfg::OFF_SCT * 4;
   const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem);
+  const unsigned lane16 = (unsigned)lane * 16u;
 
   // raw patch registers, double-buffered by stage parity: the loads of stage k + 2 are issued (into buffer k & 1) while the
   // conversion of stage k + 1 still reads buffer (k + 1) & 1 -- that lets the conversion spread over eight steps of a stage,
@@ -557,15 +563,17 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     }                                                                                                 \
   }
 // one kernel row of one stage by LDS-DMA (1 KiB per wave-instruction), lane-linear = the packed order
-#define EMO_S_DMA_PIECE(ptr_, row_, i_)                                                               \
+#define EMO_S_DMA_PIECE_TO(ptr_, wb_, row_, i_)                                                       \
   {                                                                                                   \
-    const char* ws_ = (ptr_) + (row_) * Cfg::WROW_BYTES;                                              \
     const int j = (SPLIT == 2 || (i_) < 4) ? wave + 4 * (i_) : 16 + (wave & 1);                       \
-    emo_dma16_pinned(ws_ + j * 1024 + lane * 16,                                                      \
-                     smem_lds + (unsigned)(Cfg::OFF_W * 16 + (row_) * Cfg::WROW_BYTES + j * 1024));   \
+    emo_dma16_pinned_s((ptr_) + ((row_) * Cfg::WROW_BYTES + j * 1024), lane16,                        \
+                       smem_lds + (unsigned)((Cfg::OFF_W + (wb_) * Cfg::WSTAGE) * 16 + (row_) * Cfg::WROW_BYTES + j * 1024)); \
   }
+#define EMO_S_DMA_PIECE(ptr_, row_, i_) EMO_S_DMA_PIECE_TO(ptr_, 0, row_, i_)
 #define EMO_S_DMA_ROW(ptr_, row_)                                                                     \
   { _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(ptr_, row_, i) }
+// piece k = 0 .. 3 * NDMA - 1 of a whole stage (one-barrier schedule): row k / NDMA, piece k % NDMA of that row
+#define EMO_S_DMA_STAGE_PIECE(ptr_, wb_, k_) EMO_S_DMA_PIECE_TO(ptr_, wb_, (k_) / Cfg::NDMA, (k_) % Cfg::NDMA)
 #define EMO_S_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #if EMO_S_TIMING == 2
 // measurement build: how long every wave sits in the waitcnt of a K-loop barrier (memory / LDS latency it did not hide) and in
@@ -587,6 +595,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 
 
   // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
+  constexpr bool ONEBAR = Cfg::NWB == 2;      // two whole weight stages in LDS: one barrier per stage (ConvCfgS)
   constexpr int NPROD = SPLIT == 3 ? EMO_S_PRODUCTS : 3;
   constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
   constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
@@ -630,6 +639,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   }
   EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 0);
   EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 1);
+  if constexpr (ONEBAR) EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 2);
   EMO_S_SET_STAGE_INIT(it_st_begin);
   EMO_S_ISSUE_BEGIN(0)
   EMO_S_ISSUE_LOADS(0, 0, 8)
@@ -661,8 +671,18 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     EMO_S_CONV_HALF(0, Cfg::OFF_P, i, 1)
   }
   EMO_S_HALF_TABLE(1, 0)                 // (what step 0 of the first stage converts with)
-  EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 2);
-  EMO_S_BARRIER(Cfg::NDMA);              // (LDS stores of P[0] visible; DMA(first stage, 2) stays in flight)
+  if constexpr (ONEBAR) {
+    // the first two pieces of the second stage's weights (its other seven follow in steps 0 .. 4 of the first stage)
+    const char* const w1_ = it_wsrc + (long)((it_st_begin + 1) < it_st_end ? it_st_begin + 1 : it_st_begin) * (3 * Cfg::WROW_BYTES);
+    EMO_S_DMA_STAGE_PIECE(w1_, 1, 0)
+    EMO_S_DMA_STAGE_PIECE(w1_, 1, 1)
+    EMO_S_BARRIER(2);                    // (LDS stores of P[0] visible; the two pieces stay in flight)
+  } else {
+    // the first two pieces of the first stage's kernel row 2 (its other three follow in steps 0 and 1)
+    EMO_S_DMA_PIECE(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 2, 0)
+    EMO_S_DMA_PIECE(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 2, 1)
+    EMO_S_BARRIER(2);                    // (LDS stores of P[0] visible; the two pieces stay in flight)
+  }
 
   // ---- K loop, two stages per iteration (buffer parities and fragment sets are compile-time constants).  Stage cg, parity par:
   //        steps 0 .. 7   half a pixel each of the patch of stage cg + 1 is converted from qv[par ^ 1] into P[par ^ 1]
@@ -674,7 +694,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   //                       DMA(cg + 1, 2) and the first fragments of stage cg + 1 from P[par ^ 1]
   //      every wave issues exactly NDMA pieces per row and 8 quad loads per stage, so the counts are uniform ----
   EMO_S_STAMP(1)
-  EMO_S_LOAD_FRAGS(0, Cfg::OFF_W, Cfg::OFF_P, 0, 0)
+  EMO_S_LOAD_FRAGS(0, Cfg::OFF_W, Cfg::OFF_P, 0, 0)       // (first stage: W[0], P[0])
   for (int cg0 = it_st_begin; cg0 < it_st_end; cg0 += 2) {
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -684,6 +704,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       // stage cg + 1 (its weight rows are fetched during this stage) and stage cg + 2 (its patch is loaded during this stage),
       // clamped to the last stage: a harmless re-stage
       const char* const dma_ptr = it_wsrc + (long)((cg + 1) < it_st_end ? cg + 1 : it_st_end - 1) * (3 * Cfg::WROW_BYTES);
+      const char* const dma_ptr2 = it_wsrc + (long)((cg + 2) < it_st_end ? cg + 2 : it_st_end - 1) * (3 * Cfg::WROW_BYTES);
       if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int gs = 0; gs < 9; ++gs) {
@@ -692,37 +713,67 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #if EMO_S_TIMING == 3
         const unsigned long long ts0_ = __builtin_amdgcn_s_memtime();
 #endif
-        if (s == 2) {
+        // ---- barriers.  Every vector-memory instruction of a stage has a fixed step (table below), at most four per step and
+        //      wave: issued in bursts behind the barriers (5 weight pieces + 8 loads at once, by all four waves) they queued at
+        //      the CU's address unit (one wave-instruction per ~17 cycles) and the waves -- in-order -- stood with them:
+        //      260 / 820 / 1050 cycles on top of the 768 of a barrier step (profiles/r4_conv_phase_steps*.jsonl) ----
+        if (ONEBAR) {
+          // one-barrier schedule (two whole weight stages in LDS): the only barrier of the stage, at the top of step 8.  Every
+          // wave has read its last fragments of this stage (buffers W[par], P[par] are free behind it), stored its share of
+          // the next patch, and drained ALL its loads -- the next stage's weights and the patch registers of the one behind
+          // it were issued by step 4 at the latest, three steps ago (vmcnt(0): nothing to count)
+          if (gs == 8) { EMO_S_LOOP_BARRIER(0) }
+        } else if (s == 2) {
+          // MIDBAR(cg, r), three-row schedule.  Issue order of a stage and wave (R = weight pieces of a kernel row, Q = quad loads):
+          //   step 8 (stage cg - 1)  R2(cg) x2      step 0  R2(cg) x2, Q x2     step 1  R2(cg) x1, Q x2
+          //   step 2  R0(cg + 1) x2, Q x2           step 3  R0(cg + 1) x2, Q x2  step 4  R0(cg + 1) x1
+          //   step 5  R1(cg + 1) x2                 step 6  R1(cg + 1) x2        step 7  R1(cg + 1) x1
+          //   MIDBAR(cg, 0), top of step 2: needs R1(cg) (steps 5 - 7 of the stage before); behind it 2 + 4 + 3 = 9 may fly
+          //   MIDBAR(cg, 1), top of step 5: needs R2(cg) (last piece: first instruction of step 1); behind it 2 + 4 + 4 + 1 = 11
+          //   MIDBAR(cg, 2), top of step 8: needs R0(cg + 1) and every Q (last: step 4); behind it 2 + 2 + 1 = 5
           if (EMO_S_ABLATE & 5) { EMO_S_LOOP_BARRIER(0) }       // (ablation builds issue fewer loads: drain instead of counting)
-          else if (r == 1) { EMO_S_LOOP_BARRIER(Cfg::NDMA + 8) } else { EMO_S_LOOP_BARRIER(Cfg::NDMA) }
-          if (r == 0) {
-            EMO_S_SET_STAGE_STEP((cg + 2) < it_st_end ? cg + 2 : it_st_end - 1);
-            EMO_S_ISSUE_BEGIN(par)
-          }
-          if (r == 2) EMO_S_TOUCH_QUAD(par)
+          else if (r == 0) { EMO_S_LOOP_BARRIER(9) } else if (r == 1) { EMO_S_LOOP_BARRIER(11) } else { EMO_S_LOOP_BARRIER(5) }
+        }
+        if (gs == 8) EMO_S_TOUCH_QUAD(par)       // (the loads of stage cg + 2 have landed behind the barrier above)
+        if (gs == 0) {
+          EMO_S_SET_STAGE_STEP((cg + 2) < it_st_end ? cg + 2 : it_st_end - 1);
+          EMO_S_ISSUE_BEGIN(par)
         }
         // ---- one step: the fragments of the NEXT step, half a pixel of conversion, 4 * NPROD MFMAs.  The order inside the step
         //      is pinned with sched_group_barrier: the compiler left to itself sinks the fragment reads to their first use
         //      (LDS latency in front of every MFMA) and emits the conversion as one VALU burst.  The step's vector-memory
-        //      instructions -- the NDMA weight pieces behind a MIDBAR, the 8 quad loads behind MIDBAR(cg, 0) -- sit BETWEEN the
-        //      planes of the fragment reads: their asm statements order against the LDS reads on both sides, which the pinning
-        //      spreads one per MFMA, so they issue among the MFMAs instead of as a burst behind the barrier ----
+        //      instructions sit BETWEEN the planes of the fragment reads: their asm statements order against the LDS reads on
+        //      both sides, which the pinning spreads one per MFMA, so they issue among the MFMAs ----
         __builtin_amdgcn_sched_barrier(0);
         {
-          constexpr int UPP = (8 + NPL - 1) / NPL;          // quad loads per plane slot
           const int rn = gs < 8 ? (gs + 1) / 3 : 0, sn = gs < 8 ? (gs + 1) % 3 : 0;
-          const int wbn = Cfg::OFF_W + rn * WROW, pbn = gs < 8 ? pcur : pnxt;
+          const int wbn = Cfg::OFF_W + (ONEBAR ? (gs < 8 ? par : par ^ 1) * Cfg::WSTAGE : 0) + rn * WROW, pbn = gs < 8 ? pcur : pnxt;
+          const char* const dma_ptr0 = it_wsrc + (long)cg * (3 * Cfg::WROW_BYTES);       // this stage (three-row schedule: its row 2)
 #pragma unroll
-          for (int pl = 0; pl < NPL; ++pl) {
-            EMO_S_LOAD_FRAGS_PLANE(fnxt, pl, wbn, pbn, rn, sn)
-            if (s == 2) {
-              if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(dma_ptr, r, pl)
-              if (r == 0 && !(EMO_S_ABLATE & 4)) EMO_S_ISSUE_LOADS(par, pl * UPP, (pl + 1) * UPP < 8 ? (pl + 1) * UPP : 8)
+          for (int pl = 0; pl < NPL + 1; ++pl) {
+            if (pl < NPL) EMO_S_LOAD_FRAGS_PLANE(fnxt, pl, wbn, pbn, rn, sn)
+            if (ONEBAR) {
+              // weights of stage cg + 1 into W[par ^ 1]: pieces 2 .. 8 in steps 0 .. 4; the first two pieces of stage cg + 2 into
+              // W[par] behind the barrier of step 8; the quad loads two per step in steps 0 .. 3
+              static_assert(!ONEBAR || (NPL == 2 && Cfg::NDMA == 3), "piece schedule of the one-barrier stage");
+              if (gs == 8 && pl < 2) EMO_S_DMA_STAGE_PIECE(dma_ptr2, par, pl)
+              if (gs < 4 && pl == 0) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 2 + gs)
+              if (gs < 4 && pl == 1) EMO_S_ISSUE_LOADS(par, 2 * gs, 2 * gs + 2)
+              if (gs == 4) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 6 + pl)
+            } else if (!(EMO_S_ABLATE & 1)) {
+              static_assert(ONEBAR || (NPL == 3 && Cfg::NDMA == 5), "piece schedule of the three-row stage");
+              if (gs == 8 && pl < 2) EMO_S_DMA_PIECE(dma_ptr, 2, pl)                      // row 2 of stage cg + 1
+              if (gs == 0 && pl < 2) EMO_S_DMA_PIECE(dma_ptr0, 2, 2 + pl)                 // row 2 of THIS stage, continued
+              if (gs == 1 && pl == 0) EMO_S_DMA_PIECE(dma_ptr0, 2, 4)
+              if ((gs == 2 || gs == 3) && pl < 2) EMO_S_DMA_PIECE(dma_ptr, 0, 2 * (gs - 2) + pl)
+              if (gs == 4 && pl == 0) EMO_S_DMA_PIECE(dma_ptr, 0, 4)
+              if ((gs == 5 || gs == 6) && pl < 2) EMO_S_DMA_PIECE(dma_ptr, 1, 2 * (gs - 5) + pl)
+              if (gs == 7 && pl == 0) EMO_S_DMA_PIECE(dma_ptr, 1, 4)
             }
-          }
-          if (s == 2) {
-#pragma unroll
-            for (int i = NPL; i < Cfg::NDMA; ++i) { if (!(EMO_S_ABLATE & 1)) EMO_S_DMA_PIECE(dma_ptr, r, i) }
+            if (!ONEBAR && !(EMO_S_ABLATE & 4)) {
+              if ((gs == 0 || gs == 2 || gs == 3) && pl == 2) EMO_S_ISSUE_LOADS(par, gs == 0 ? 0 : 2 * gs, gs == 0 ? 2 : 2 * gs + 2)
+              if (gs == 1 && pl == 1) EMO_S_ISSUE_LOADS(par, 2, 4)
+            }
           }
         }
         if (gs < 8) {
@@ -778,9 +829,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   EMO_S_STAMP(6)
 
   {
-    // transposition scratch: the patch buffer of the last stage, or a region of its own
+    // transposition scratch: the patch buffer of the last stage; the weight stage buffer the last stage did not read (one-barrier
+    // schedule: it holds the dead re-staged rows); or a region of its own
     const int last_par = (it_st_end - it_st_begin - 1) & 1;
-    float* const scratch = smem + (Cfg::EPI_IN_PATCH ? (Cfg::OFF_P + last_par * PBUF) * 4 : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
+    float* const scratch = smem + (Cfg::EPI_IN_PATCH ? (Cfg::OFF_P + last_par * PBUF) * 4
+                                   : Cfg::EPI_IN_W ? (Cfg::OFF_W + (last_par ^ 1) * Cfg::WSTAGE) * 4 : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
     conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(a, acc_lo, acc_hi, scratch, smem + Cfg::OFF_BIAS_F,
                                                                       smem + Cfg::OFF_STAT_F, it_n, it_cotile, it_ptile, it_ks, it_x0,
                                                                       it_y0, it_z0, wp, half, l32, lane, tid
@@ -833,6 +886,8 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #undef EMO_S_CONV_HALF
 #undef EMO_S_TOUCH_QUAD
 #undef EMO_S_DMA_PIECE
+#undef EMO_S_DMA_PIECE_TO
+#undef EMO_S_DMA_STAGE_PIECE
 #undef EMO_S_DMA_ROW
 #undef EMO_S_WAIT
 #undef EMO_S_BARRIER

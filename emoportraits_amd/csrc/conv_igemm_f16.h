@@ -94,6 +94,14 @@ __device__ __forceinline__ void emo_dma16_pinned(const void* gsrc, unsigned lds_
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// the same with a wave-uniform source base in SGPRs and a 32-bit per-lane byte offset: no 64-bit vector address arithmetic per
+// piece (the offset lane * 16 is one loop-invariant register)
+__device__ __forceinline__ void emo_dma16_pinned_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // raw buffer loads hidden from the compiler: address = resource base + soff (SGPR) + voff (VGPR), both in bytes.  The
 // eight channel planes of a staging item differ only in soff, which is loop-invariant: no address arithmetic per load.
 __device__ __forceinline__ float emo_bload_pinned(emo_intx4 rsrc, unsigned voff, unsigned soff) {
