@@ -14,10 +14,13 @@ pass runs on rank 0 and its canonical volume is broadcast over RCCL once per ide
 (reported as source_pass_ms / broadcast_ms).
 
 The JSON line also carries
-  roofline      the dominant kernel -- conv_igemm_bf16x3_kernel (fp32 3x3 convolution on the bf16 matrix pipes, default) or, with
-                EMO_CONV_PRECISION=f32, conv_igemm_kernel (fp32 MFMA): algorithmic FLOPs of its launches in the timed region /
-                their duration measured with HIP events on the launch stream, vs 2500 / 6 TF (six bf16 products per fp32
-                product) resp. the 157.3 TF fp32 MFMA peak; roofline_other_convs: the same for the remaining conv launches
+  roofline      the dominant kernel -- conv_igemm_bf16x3_kernel (fp32 3x3 convolution on the 16-bit matrix pipes: the two-term
+                fp16 split with its device-checked range by default, the three-term bf16 split with EMO_CONV_PRECISION=bf16x3)
+                or, with EMO_CONV_PRECISION=f32, conv_igemm_kernel (fp32 MFMA): algorithmic FLOPs of its launches in the timed
+                region / their duration measured with HIP events on the launch stream (in the default mode the pair of
+                launches of a layer: the fp16-split launch and the guarded bf16x3 launch that exits when the range check
+                passed), vs 2500 / 3 TF (three fp16 products per fp32 product), 2500 / 6 TF resp. the 157.3 TF fp32 MFMA
+                peak; roofline_other_convs: the same for the remaining conv launches
   roofline_sampler  the 3-D grid_sample kernels, algorithmic bytes / event time vs 8 TB/s
   cpu_baseline  the oracle (oracle/restate.py, a port of the reference's PyTorch forward) timed on this box's host cores
                 on a bounded sample (rank 0, N=1 only)
@@ -547,6 +550,9 @@ def main():
     torch.cuda.synchronize()
     elapsed_metered = sum(x.elapsed_time(y) for x, y in spans) * 1e-3
 
+    # fp16-split layers whose device-side range check fired during the last step (their guarded bf16x3 launch then recomputed
+    # them: correct, but the step was not the fp16 split's): none on the bench checkpoint
+    recomputed = sorted(v for v in hp.overflow_events().values() if v) if hp.precision == "f16x2" else []
     if rank != 0:
         return
     frames = world * B * a.steps
@@ -619,6 +625,7 @@ def main():
                                                 "(tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
                                        "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution"}[hp.precision],
                    "step_launch": step_launch,
+                   "f16x2_layers_recomputed_after_range_check": recomputed,
                    "metered_pass": (f"roofline figures: the same {a.steps} steps launched eagerly with HIP events around every conv / "
                                     f"sampler launch, each behind two graph replays so that the host is ahead of the GPU; "
                                     f"{elapsed_metered / a.steps * 1e3:.2f} ms of GPU time per metered step"),

@@ -35,7 +35,9 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_n1.json"), (f"{tag}_bench25
                  (f"{tag}_bf16x3_512c_pmc_conv.json", f"{tag}_bf16x3_pmc_sq_conv_512to512_at64.json"),
                  (f"{tag}_bf16x3_128c_pmc_conv.json", f"{tag}_bf16x3_pmc_sq_conv_128to128_at512.json"),
                  (f"{tag}_driver512_f32.jsonl", f"{tag}_driver_breakdown_r512_fp32_mfma.jsonl"),
-                 (f"{tag}_driver512_f16x2.jsonl", f"{tag}_driver_breakdown_r512_f16x2.jsonl")):
+                 (f"{tag}_driver512_f16x2.jsonl", f"{tag}_driver_breakdown_r512_f16x2.jsonl"),
+                 (f"{tag}_driver512_bf16x3.jsonl", f"{tag}_driver_breakdown_r512_bf16x3.jsonl"),
+                 (f"{tag}_bench_bf16x3.json", f"{tag}_bench_n1_bf16x3.json")):
     if os.path.exists(g + src):
         if dst.endswith(".json") and "bench" in dst:      # keep the JSON line only (gloo prints a banner to stdout)
             lines = [l for l in open(g + src, errors="replace") if l.lstrip().startswith("{")]
@@ -51,9 +53,11 @@ for n, d in (("fetch", f), ("write", w), ("mfma", m)):
 rows = list(csv.DictReader(open(p + f"{tag}_bench_kernel_stats.csv")))
 
 
-def traffic(prefix, label, dst):
-    """per-launch HBM traffic + MFMA utilisation of the kernels whose name starts with `prefix` (all instantiations)"""
-    conv = [k for k in f if k.startswith(prefix)]
+def traffic(prefix, label, dst, suffix=None):
+    """per-launch HBM traffic + MFMA utilisation of the kernels whose name starts with `prefix` (all instantiations; `suffix`
+    narrows them to one template argument list ending, e.g. the SPLIT = 2 instantiations of the split kernel)"""
+    pick = lambda k: k.startswith(prefix) and (suffix is None or suffix in k)
+    conv = [k for k in f if pick(k)]
     if not conv:
         return None
     n = sum(f[k]["FETCH_SIZE"]["launches"] for k in conv)
@@ -61,12 +65,13 @@ def traffic(prefix, label, dst):
     tw = sum(w[k]["WRITE_SIZE"]["sum"] for k in conv)
     mf = sum(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] for k in conv)
     gui = sum(m[k]["GRBM_GUI_ACTIVE"]["sum"] for k in conv)
-    ct = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith(prefix))
-    cc = sum(int(r["Calls"]) for r in rows if r["Name"].startswith(prefix))
+    ct = sum(float(r["TotalDurationNs"]) for r in rows if pick(r["Name"]))
+    cc = sum(int(r["Calls"]) for r in rows if pick(r["Name"]))
     out = {
         "kernel": label,
         "pmc_run": "rocprofv3 --pmc <one counter set> (separate passes for FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE) "
                    "-- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-source-pass (batch 16, as the bench)",
+        "git_head": os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip(),
         "launches": n, "fetch_size_kib_per_launch": tf / n, "write_size_kib_per_launch": tw / n,
         "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream "
                       "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated (it equals the output tensor bytes exactly on the large layers)",
@@ -81,5 +86,11 @@ def traffic(prefix, label, dst):
 
 
 traffic("conv_igemm_kernel", "conv_igemm_kernel (fp32 MFMA, all instantiations)", f"{tag}_pmc_conv_traffic.json")
-traffic("conv_igemm_bf16x3_kernel", "conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes, all instantiations)",
-        f"{tag}_pmc_conv_bf16x3_traffic.json")
+# the split kernel's two operand modes are instantiations of one template: <TR, TW, UPS, SPLIT>.  A default (f16x2) run also holds
+# the guarded bf16x3 launches, which leave at once: they would dilute a per-launch figure, so only a bf16x3 run's trace is used
+if any(k.startswith("conv_igemm_bf16x3_kernel") and ", 2>" in k for k in f):
+    traffic("conv_igemm_bf16x3_kernel", "conv_igemm_bf16x3_kernel<SPLIT = 2> (fp32 3x3 conv on the fp16 matrix pipes: two-term split, device-checked range)",
+            f"{tag}_pmc_conv_f16x2_traffic.json", suffix=", 2>")
+else:
+    traffic("conv_igemm_bf16x3_kernel", "conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes, all instantiations)",
+            f"{tag}_pmc_conv_bf16x3_traffic.json", suffix=", 3>")

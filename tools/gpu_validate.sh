@@ -19,12 +19,13 @@ tail -3 gpurun_out/${TAG}_pytest.log; tail -1 gpurun_out/${TAG}_smoke.log
 fi
 [ $PART = tests ] && exit 0
 SHORT=0; [ $PART = bench-short ] && SHORT=1
-timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+EMO_CONV_PRECISION=bf16x3 timeout 600 python bench.py --no-extras --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16x3.json 2>> gpurun_out/${TAG}_bench.err
 EMO_DIST_BACKEND=gloo EMO_FORCE_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 --batch 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_2ranks_1gpu.json 2>> gpurun_out/${TAG}_bench.err
 timeout 400 python tools/bench_conv.py 16 --bf16x3 --f16x2 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_conv.jsonl
 timeout 300 python tools/bench_driver.py 512 1 4 16 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_driver512.jsonl
 timeout 300 python tools/bench_driver.py 512 1 16 --f32 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_driver512_f32.jsonl
-timeout 300 python tools/bench_driver.py 512 1 16 --f16x2 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_driver512_f16x2.jsonl
+timeout 300 python tools/bench_driver.py 512 1 16 --bf16x3 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_driver512_bf16x3.jsonl
 [ -x tools/microbench/mfma_stream ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -Wno-unused-value tools/microbench/mfma_stream.hip -o tools/microbench/mfma_stream 2>/dev/null
 timeout 60 tools/microbench/mfma_stream > gpurun_out/${TAG}_mfma_stream.jsonl 2>&1
 bash tools/profile_bench.sh ${TAG}
