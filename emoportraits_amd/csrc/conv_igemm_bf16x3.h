@@ -70,8 +70,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define EMO_S_TLOG_W 16
 static __device__ unsigned long long emo_s_tlog[EMO_S_TLOG_N * EMO_S_TLOG_W];
 #define EMO_S_STAMP(k_) if (EMO_S_TIMING) { tstamp[k_] = __builtin_amdgcn_s_memtime(); }
+#define EMO_S_TSTAMP_ARG , tstamp
 #else
 #define EMO_S_STAMP(k_)
+#define EMO_S_TSTAMP_ARG
 #endif
 #ifndef EMO_S_PRODUCTS
 #define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
@@ -142,6 +144,39 @@ __device__ __forceinline__ float emo_row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
   return v;
+}
+
+// One accumulator element, read where it is used.  The MFMA results live in accumulation registers; left to itself the compiler
+// copies all 128 of them to ordinary registers at the K loop's exit, and the epilogue then runs out of registers: residual
+// values and addresses are spilled to scratch, and every scratch reload (a vector-memory load as well) drags a vmcnt(0) in
+// front of the next store.  The caller is many instructions (a waitcnt, a barrier) behind the last MFMA.
+__device__ __forceinline__ float emo_acc_read(float acc_element) {
+  float v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc_element));
+  return v;
+}
+
+// Tile statistics, second half (both epilogues below): the WGP waves' (mean, M2) of a channel combined with the equal-count update
+template <int TP, int WGP, int BM>
+__device__ __forceinline__ void conv_epilogue_rows_stats(const ConvArgs& a, const float* st_lds, int n, int cotile, int ptile, int tid) {
+  __syncthreads();
+  if (tid < BM) {
+    const int co = cotile * BM + tid;
+    if (co < a.Cout) {
+      float mean = 0.0f, m2 = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WGP; ++w) mean += st_lds[(w * BM + tid) * 2 + 0];
+      mean *= 1.0f / (float)WGP;
+#pragma unroll
+      for (int w = 0; w < WGP; ++w) {
+        const float d = st_lds[(w * BM + tid) * 2 + 0] - mean;
+        m2 += st_lds[(w * BM + tid) * 2 + 1] + (float)(TP * 32) * d * d;
+      }
+      const long nptiles = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+      float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)n * nptiles + ptile) * a.Cout + co;
+      *dst = make_float2(mean, m2);
+    }
+  }
 }
 
 // Epilogue of the split kernel.  conv_epilogue (conv_igemm.h) stores straight from the accumulator layout -- a lane owns one
@@ -239,7 +274,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, floatx16 (
         floatx4 c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float sum = acc_lo[i][j][4 * q + e] + acc_hi[i][j][4 * q + e];
+          const float sum = emo_acc_read(acc_lo[i][j][4 * q + e]) + emo_acc_read(acc_hi[i][j][4 * q + e]);
           c[e] = SPLIT == 3 ? sum : sum * a.out_scale;
         }
         *reinterpret_cast<floatx4*>(scratch + l32 * ROWF + j * 32 + 8 * q + 4 * half) = c;
@@ -287,26 +322,112 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, floatx16 (
     }
   }
   EMO_S_STAMP(9)
-  if (want_stats) {
-    __syncthreads();
-    if (tid < BM) {
-      const int co = cotile * BM + tid;
-      if (co < a.Cout) {
-        float mean = 0.0f, m2 = 0.0f;
+  if (want_stats) conv_epilogue_rows_stats<TP, WGP, BM>(a, st_lds, n, cotile, ptile, tid);
+}
+
+// The same epilogue for the launch form the decoders use almost everywhere -- final output (no K split), no activation, a full
+// 64-channel tile, 16-byte aligned tensors, offsets inside 2^31 bytes per sample -- with every one of those a compile-time fact.
+// conv_epilogue_rows tests them per element: its per-value activation switch alone is four taken branches per stored value, and
+// the residual registers of its three alignment cases meet in phi nodes, so the compiler waits for every load right behind its
+// issue (ISA: `s_waitcnt vmcnt(15) ... vmcnt(2)` + moves): 20-21 k cycles per tile whatever the layer, 30 % of a 128 -> 128 tile
+// of the fp16 split (profiles/r4_conv_phase_timing_final.jsonl).  Here the path is straight-line code:
+//   conv_epilogue_fast_issue   the residual loads of 32 channels (8 per lane); the first 32 are issued in front of the closing
+//                              barrier of the K loop, the second 32 behind the first half's accumulator -> LDS stores;
+//   conv_epilogue_fast_finish  LDS transposition, + bias (+ residual), stores (one scalar base + a 32-bit lane offset), tile
+//                              statistics.
+// RES: 0 no residual, 1 residual of the output's size (16-byte aligned), 2 half-size residual, nearest x2 (8-byte aligned).
+// Arithmetic per element identical to conv_epilogue_rows (same operations in the same order): the two are bit-identical.
+template <int TW, int TP, int BM, int RES, int I>
+__device__ __forceinline__ void conv_epilogue_fast_issue(const ConvArgs& a, floatx4 (&rv)[8], int n, int cotile, int x0, int y0,
+                                                         int z0, int wp, int lane) {
+  if constexpr (RES != 0) {
+    const int g = lane >> 4, t = lane & 15;
+    const int p = wp * (TP * 32) + 4 * t;
+    const int y = y0 + p / TW, x = x0 + p % TW;
+    const unsigned Hr = RES == 2 ? a.Hl >> 1 : a.Hl, Wr = RES == 2 ? a.Wl >> 1 : a.Wl;
+    const unsigned rvol = (unsigned)a.Dl * Hr * Wr;
+    const unsigned rsp = RES == 2 ? ((unsigned)z0 * Hr + (y >> 1)) * Wr + (x >> 1) : ((unsigned)z0 * Hr + y) * Wr + x;
+    const float* rbase = a.res + ((long)n * a.Cout + (long)cotile * BM) * rvol;      // wave-uniform
+    const unsigned roff = (unsigned)g * rvol + rsp;
 #pragma unroll
-        for (int w = 0; w < WGP; ++w) mean += st_lds[(w * BM + tid) * 2 + 0];
-        mean *= 1.0f / (float)WGP;
+    for (int it = 0; it < 8; ++it) {
+      const float* rp = rbase + (roff + (unsigned)(I * 32 + 4 * it) * rvol);
+      if constexpr (RES == 1) rv[it] = *reinterpret_cast<const floatx4*>(rp);
+      else { const float2 r2 = *reinterpret_cast<const float2*>(rp); rv[it] = floatx4{r2.x, r2.y, 0.0f, 0.0f}; }
+    }
+  }
+}
+
+template <int TW, int TM, int TP, int WGP, int BM, int SPLIT, int ROWF, int RES>
+__device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, floatx16 (&acc_lo)[TM][TP], floatx16 (&acc_hi)[TM][TP],
+                                                          floatx4 (&rv0)[8], float* scratch, const float* sbias,
+                                                          float* st_lds, int n, int cotile, int ptile, int x0, int y0, int z0, int wp,
+                                                          int half, int l32, int lane, int tid, unsigned long long* tstamp = nullptr) {
+  static_assert(TP == 2 && TM == 2 && BM == 64, "wave tile of 64 channels x 64 positions");
+  constexpr int NIT = 8;
+  const int g = lane >> 4, t = lane & 15;
+  const bool want_stats = a.gn_stats != nullptr;
+  const unsigned plane = (unsigned)a.Hl * a.Wl, ovol = (unsigned)a.Dl * plane;
+  const int p = wp * (TP * 32) + 4 * t;
+  const int y = y0 + p / TW, x = x0 + p % TW;
+  float* const obase = a.out + ((long)n * a.Cout + (long)cotile * BM) * ovol;          // wave-uniform
+  const unsigned off = (unsigned)g * ovol + (unsigned)z0 * plane + (unsigned)y * a.Wl + x;
+  floatx4 rv1[8];
+  EMO_S_STAMP(7)
 #pragma unroll
-        for (int w = 0; w < WGP; ++w) {
-          const float d = st_lds[(w * BM + tid) * 2 + 0] - mean;
-          m2 += st_lds[(w * BM + tid) * 2 + 1] + (float)(TP * 32) * d * d;
+  for (int i = 0; i < TM; ++i) {
+    if (i == 1) { EMO_S_STAMP(8) }
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        floatx4 c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sum = emo_acc_read(acc_lo[i][j][4 * q + e]) + emo_acc_read(acc_hi[i][j][4 * q + e]);
+          c[e] = SPLIT == 3 ? sum : sum * a.out_scale;
         }
-        const long nptiles = (long)a.tiles_x * a.tiles_y * a.tiles_z;
-        float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)n * nptiles + ptile) * a.Cout + co;
-        *dst = make_float2(mean, m2);
+        *reinterpret_cast<floatx4*>(scratch + l32 * ROWF + j * 32 + 8 * q + 4 * half) = c;
+      }
+    // the second half's residual: issued now, into the registers the first half's accumulators have just left (with all 16
+    // loads in flight from the start the compiler spills the landed values to scratch and waits vmcnt(0) before every store)
+    if (i == 0) conv_epilogue_fast_issue<TW, TP, BM, RES, 1>(a, rv1, n, cotile, x0, y0, z0, wp, lane);
+    floatx4 (&rv)[8] = i == 0 ? rv0 : rv1;
+    floatx4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const floatx4*>(scratch + (4 * it + g) * ROWF + 4 * t);
+    const floatx4 b0 = *reinterpret_cast<const floatx4*>(sbias + i * 32 + g * 8);
+    const floatx4 b1 = *reinterpret_cast<const floatx4*>(sbias + i * 32 + g * 8 + 4);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const float bs = it < 4 ? b0[it & 3] : b1[it & 3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = v[it][e] + bs;
+        if constexpr (RES == 1) u += rv[it][e];
+        if constexpr (RES == 2) u += rv[it][e >> 1];
+        v[it][e] = u;
+      }
+      float* const op = obase + (off + (unsigned)(i * 32 + 4 * it) * ovol);
+      if (EMO_CONV_NT_STORE) __builtin_nontemporal_store(v[it], reinterpret_cast<floatx4*>(op));
+      else *reinterpret_cast<floatx4*>(op) = v[it];
+    }
+    if (want_stats) {
+      constexpr float inv_cnt = 1.0f / (float)(TP * 32);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const float s4 = (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+        const float mean = emo_row16_sum(s4) * inv_cnt;
+        float m2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[it][e] - mean; m2 = __fmaf_rn(d, d, m2); }
+        m2 = emo_row16_sum(m2);
+        if (t == 0) *reinterpret_cast<float2*>(st_lds + (wp * BM + i * 32 + 4 * it + g) * 2) = make_float2(mean, m2);
       }
     }
   }
+  EMO_S_STAMP(9)
+  if (want_stats) conv_epilogue_rows_stats<TP, WGP, BM>(a, st_lds, n, cotile, ptile, tid);
 }
 
 template <int TR, int TW, bool UPS, int SPLIT>
@@ -337,6 +458,14 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const int HW = a.H * a.W;
   const long DHW = (long)a.D * HW;
   const bool has_affine = a.scale != nullptr;
+  // epilogue form (wave-uniform, see conv_epilogue_fast_finish): 0 / 1 / 2 = the straight-line form without / with a same-size /
+  // with a half-size residual, -1 = the general one
+  const int epi_mode = __builtin_amdgcn_readfirstlane(
+      (a.partial != nullptr || a.act != EMO_ACT_NONE || a.Cout % BM != 0 || (a.Wl & 3) != 0 ||
+       (long)a.Dl * a.Hl * a.Wl > (1l << 23) || (reinterpret_cast<unsigned long long>(a.out) & 15ull) != 0) ? -1
+      : a.res == nullptr ? 0
+      : !a.res_ups ? ((reinterpret_cast<unsigned long long>(a.res) & 15ull) == 0 ? 1 : -1)
+      : ((reinterpret_cast<unsigned long long>(a.res) & 7ull) == 0 ? 2 : -1));
   const float in_scale = SPLIT == 3 ? 1.0f : a.in_scale;
   const int padD = a.KD >> 1;
   // bounds of the staged value: ReLU or none; the fp16 split saturates at the fp16 range (of the scaled value)
@@ -821,26 +950,42 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     }
   }
   EMO_S_STAMP(2)
-  // the re-issued loads / DMA of the clamped last stages are dead: drain them (from here on nothing pinned is in flight, the
-  // epilogue is ordinary compiler-scheduled code)
-  EMO_S_WAIT(0);
-  EMO_S_STAMP(5)
-  __syncthreads();    // every wave is past its last fragment read of this item's last stage: its patch buffer is the epilogue's scratch
-  EMO_S_STAMP(6)
-
   {
     // transposition scratch: the patch buffer of the last stage; the weight stage buffer the last stage did not read (one-barrier
     // schedule: it holds the dead re-staged rows); or a region of its own
     const int last_par = (it_st_end - it_st_begin - 1) & 1;
     float* const scratch = smem + (Cfg::EPI_IN_PATCH ? (Cfg::OFF_P + last_par * PBUF) * 4
                                    : Cfg::EPI_IN_W ? (Cfg::OFF_W + (last_par ^ 1) * Cfg::WSTAGE) * 4 : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
-    conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(a, acc_lo, acc_hi, scratch, smem + Cfg::OFF_BIAS_F,
-                                                                      smem + Cfg::OFF_STAT_F, it_n, it_cotile, it_ptile, it_ks, it_x0,
-                                                                      it_y0, it_z0, wp, half, l32, lane, tid
-#if EMO_S_TIMING
-                                                                      , tstamp
-#endif
-                                                                      );
+    // Between the K loop and the epilogue: the re-issued loads / DMA of the clamped last stages are dead and are drained (from
+    // there on nothing pinned is in flight, the epilogue is ordinary compiler-scheduled code), and every wave must be past its
+    // last fragment read of the item's last stage before its patch buffer becomes the epilogue's scratch.  The fast forms issue
+    // the first half's residual loads in front of that barrier
+#define EMO_S_EPI_FAST(RES_)                                                                                                      \
+    {                                                                                                                              \
+      floatx4 rv_[8];                                                                                                              \
+      EMO_S_WAIT(0);                                                                                                               \
+      EMO_S_STAMP(5)                                                                                                               \
+      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0>(a, rv_, it_n, it_cotile, it_x0, it_y0, it_z0, wp, lane);                       \
+      __syncthreads();                                                                                                             \
+      EMO_S_STAMP(6)                                                                                                               \
+      conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_>(a, acc_lo, acc_hi, rv_, scratch,                  \
+                                                                                 smem + Cfg::OFF_BIAS_F, smem + Cfg::OFF_STAT_F, it_n, \
+                                                                                 it_cotile, it_ptile, it_x0, it_y0, it_z0, wp, half, \
+                                                                                 l32, lane, tid EMO_S_TSTAMP_ARG);                  \
+    }
+    if (epi_mode == 1) EMO_S_EPI_FAST(1)
+    else if (epi_mode == 2) EMO_S_EPI_FAST(2)
+    else if (epi_mode == 0) EMO_S_EPI_FAST(0)
+    else {
+      EMO_S_WAIT(0);
+      EMO_S_STAMP(5)
+      __syncthreads();
+      EMO_S_STAMP(6)
+      conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(a, acc_lo, acc_hi, scratch, smem + Cfg::OFF_BIAS_F,
+                                                                        smem + Cfg::OFF_STAT_F, it_n, it_cotile, it_ptile, it_ks, it_x0,
+                                                                        it_y0, it_z0, wp, half, l32, lane, tid EMO_S_TSTAMP_ARG);
+    }
+#undef EMO_S_EPI_FAST
   }
   if constexpr (SPLIT == 2) {
     if (a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
