@@ -129,18 +129,29 @@ __device__ __forceinline__ float emo_act(float v, int act) {
   return v;
 }
 
+// A vector-memory instruction must not read a scalar register within five wait states of a VECTOR-ALU write of it (CDNA3 ISA,
+// "manually inserted wait states": v_readlane / v_readfirstlane / v_cmp -> VMEM).  The compiler pads its own instructions; it
+// cannot see into an asm statement, and it reloads spilled scalars with v_readlane wherever it likes -- also right in front of
+// one (found in A/B builds of the split convolution that computed garbage or faulted: `v_readlane_b32 s85, ...` directly before
+// `buffer_load_dwordx4 ..., s85 offen`; tools/kernel_resources.py --audit now checks every listing for it).  Every asm
+// statement that names a scalar operand in a vector-memory instruction therefore starts with the five wait states itself.
+#ifndef EMO_SGPR_HAZARD_NOP
+#define EMO_SGPR_HAZARD_NOP "s_nop 4\n\t"     /* (-DEMO_SGPR_HAZARD_NOP='""': the audit's self-test) */
+#endif
+
+
 // global_load_dword with a scalar base and a 32-bit per-lane byte offset, hidden from the compiler's vmcnt
 // bookkeeping and from its scheduler (stays where it is written; cdna_hip_programming.md section 5.7).  The destination
 // is valid only after emo_wait_vmem0() + emo_touch().
 __device__ __forceinline__ float emo_gload_pinned(const float* sbase, unsigned voff) {
   float v;
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile(EMO_SGPR_HAZARD_NOP "global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   return v;
 }
 // 16-byte form (e.g. four consecutive per-channel scale values through a wave-uniform address: every lane gets the same 4)
 __device__ __forceinline__ floatx4 emo_gload4_pinned(const float* sbase, unsigned voff) {
   floatx4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile(EMO_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   return v;
 }
 __device__ __forceinline__ void emo_touch4(floatx4& v) { asm volatile("" : "+v"(v)); }

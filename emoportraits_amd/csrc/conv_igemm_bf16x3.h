@@ -75,6 +75,18 @@ static __device__ unsigned long long emo_s_tlog[EMO_S_TLOG_N * EMO_S_TLOG_W];
 #define EMO_S_STAMP(k_)
 #define EMO_S_TSTAMP_ARG
 #endif
+#ifndef EMO_S_CHAIN
+#define EMO_S_CHAIN 1   /* fp16 split: consecutive items of a persistent block run through one pipeline (0: A/B builds) */
+#endif
+#ifndef EMO_S_ACC_PLAIN
+#define EMO_S_ACC_PLAIN 0
+#endif
+#ifndef EMO_S_NOKILL
+#define EMO_S_NOKILL 0
+#endif
+#ifndef EMO_S_STAGGER
+#define EMO_S_STAGGER 0
+#endif
 #ifndef EMO_S_PRODUCTS
 #define EMO_S_PRODUCTS 6   /* measurement builds: 3 = (h,h) (h,m) (m,h) only (error 2^-16: NOT fp32-equivalent), 1 = plain bf16 */
 #endif
@@ -122,7 +134,13 @@ struct ConvCfgS {
   static constexpr int OFF_STAT_F = OFF_BIAS_F + BM;                   // [WGP][BM][2]
   static constexpr int OFF_EPI_F = OFF_STAT_F + 2 * WGP * BM;
   static constexpr bool EPI_IN_PATCH = PBUF * 4 >= WGP * EPI_WAVE;
-  static constexpr bool EPI_IN_W = !EPI_IN_PATCH && NWB == 2 && WSTAGE * 4 >= WGP * EPI_WAVE;   // the idle weight stage buffer
+  // (both patch buffers together: they are adjacent and both idle behind the K loop's closing barrier)
+  // CHAIN (kernel comment "work items"): the one-barrier schedule only.  A chained item transposes through the weight stage
+  // buffer its last stage read (W[1]: the other one already holds the next item's first stage); an unchained one through the
+  // idle stage buffer, which holds the dead re-staged rows
+  static constexpr bool CHAIN = EMO_S_CHAIN && NWB == 2;
+  static constexpr bool EPI_IN_W = !EPI_IN_PATCH && NWB == 2 && WSTAGE * 4 >= WGP * EPI_WAVE;
+  static_assert(!CHAIN || EPI_IN_W, "a chained epilogue needs the free weight stage buffer");
   static constexpr int LDS_BYTES = (OFF_EPI_F + ((EPI_IN_PATCH || EPI_IN_W) ? 0 : WGP * EPI_WAVE)) * 4;
   // LDS-DMA instructions EVERY wave issues per kernel row (1 KiB each).  3 planes: 18 pieces, waves 2, 3 re-copy pieces 16,
   // 17 (uniform vmcnt counts); 2 planes: 12 pieces, 3 per wave
@@ -151,9 +169,13 @@ __device__ __forceinline__ float emo_row16_sum(float v) {
 // values and addresses are spilled to scratch, and every scratch reload (a vector-memory load as well) drags a vmcnt(0) in
 // front of the next store.  The caller is many instructions (a waitcnt, a barrier) behind the last MFMA.
 __device__ __forceinline__ float emo_acc_read(float acc_element) {
+#if EMO_S_ACC_PLAIN
+  return acc_element;
+#else
   float v;
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc_element));
   return v;
+#endif
 }
 
 // Tile statistics, second half (both epilogues below): the WGP waves' (mean, M2) of a channel combined with the equal-count update
@@ -331,8 +353,8 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, floatx16 (
 // the residual registers of its three alignment cases meet in phi nodes, so the compiler waits for every load right behind its
 // issue (ISA: `s_waitcnt vmcnt(15) ... vmcnt(2)` + moves): 20-21 k cycles per tile whatever the layer, 30 % of a 128 -> 128 tile
 // of the fp16 split (profiles/r4_conv_phase_timing_final.jsonl).  Here the path is straight-line code:
-//   conv_epilogue_fast_issue   the residual loads of 32 channels (8 per lane); the first 32 are issued in front of the closing
-//                              barrier of the K loop, the second 32 behind the first half's accumulator -> LDS stores;
+//   conv_epilogue_fast_issue   the residual loads of 32 channels (8 per lane): the first 32 at the top, the second 32 behind the
+//                              first half's accumulator -> LDS stores;
 //   conv_epilogue_fast_finish  LDS transposition, + bias (+ residual), stores (one scalar base + a 32-bit lane offset), tile
 //                              statistics.
 // RES: 0 no residual, 1 residual of the output's size (16-byte aligned), 2 half-size residual, nearest x2 (8-byte aligned).
@@ -451,6 +473,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const int m0 = 0, p0 = wp * TP * 32;
 
   if (a.run_if != nullptr && *a.run_if == 0) return;   // guarded fallback launch: the fp16-split launch of the layer stayed in range
+#if EMO_S_STAGGER
+  // measurement builds: the persistent blocks of an XCD start in four groups, EMO_S_STAGGER cycles apart -- identical items on
+  // every CU otherwise keep the whole chip in lock-step (every CU in its memory-heavy prologue / epilogue at the same time)
+  for (int k = 0; k < (int)((blockIdx.x >> 3) & 3) * (EMO_S_STAGGER / 4096); ++k) __builtin_amdgcn_s_sleep(64);
+#endif
   float sat_m = 0.0f;                                    // SPLIT == 2: largest |scaled staged value| this thread has seen
 
 
@@ -519,41 +546,50 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   const int l_stride = (gridDim.x + 7) >> 3;
   // the item being computed (it_*) and the tile of its patch loads (lq_*)
   int it_L = 0, it_cotile = 0, it_ks = 0, it_n = 0, it_ptile = 0, it_x0 = 0, it_y0 = 0, it_z0 = 0, it_st_begin = 0, it_st_end = 0;
-  const char* it_wsrc = nullptr;
   unsigned lq_off = 0;
   bool lq_ok = false;
   int lq_z0 = 0;
+// (every result through readfirstlane: the uniform divisions run on the vector ALU, and once these variables are carried from
+// one iteration of the item loop to the next the compiler would otherwise keep the whole web in vector registers -- which the
+// "s" operands of the pinned loads cannot take)
 #define EMO_S_DECODE(P_, L_)                                                                          \
   {                                                                                                   \
     P_##L = (L_);                                                                                     \
-    P_##cotile = P_##L % a.n_cotiles;                                                                 \
+    int cot_ = P_##L % a.n_cotiles;                                                                   \
     int rest_ = P_##L / a.n_cotiles;                                                                  \
-    P_##ks = 0;                                                                                       \
+    int ks_ = 0;                                                                                      \
     if (a.ksplit > 1) {                                                                               \
-      P_##ks = rest_ % a.ksplit;                                                                      \
+      ks_ = rest_ % a.ksplit;                                                                         \
       rest_ /= a.ksplit;                                                                              \
     }                                                                                                 \
-    P_##n = rest_ / nptiles;                                                                          \
-    int bx_ = rest_ - P_##n * nptiles;                                                                \
-    P_##ptile = bx_;                                                                                  \
+    const int n_ = rest_ / nptiles;                                                                   \
+    int bx_ = rest_ - n_ * nptiles;                                                                   \
+    P_##ptile = __builtin_amdgcn_readfirstlane(bx_);                                                  \
     const int tx_ = bx_ % a.tiles_x; bx_ /= a.tiles_x;                                                \
     const int ty_ = bx_ % a.tiles_y; bx_ /= a.tiles_y;                                                \
-    P_##x0 = tx_ * TW; P_##y0 = ty_ * TR; P_##z0 = bx_;                                               \
-    P_##st_begin = P_##ks * a.stages_per_split;                                                       \
-    P_##st_end = min(nstages_all, P_##st_begin + a.stages_per_split);                                 \
-    P_##wsrc = reinterpret_cast<const char*>(a.wpk) + ((long)P_##cotile * nstages_all) * (3 * Cfg::WROW_BYTES); \
+    P_##cotile = __builtin_amdgcn_readfirstlane(cot_);                                                \
+    P_##ks = __builtin_amdgcn_readfirstlane(ks_);                                                     \
+    P_##n = __builtin_amdgcn_readfirstlane(n_);                                                       \
+    P_##x0 = __builtin_amdgcn_readfirstlane(tx_ * TW);                                                \
+    P_##y0 = __builtin_amdgcn_readfirstlane(ty_ * TR);                                                \
+    P_##z0 = __builtin_amdgcn_readfirstlane(bx_);                                                     \
+    P_##st_begin = __builtin_amdgcn_readfirstlane(P_##ks * a.stages_per_split);                       \
+    P_##st_end = __builtin_amdgcn_readfirstlane(min(nstages_all, P_##st_begin + a.stages_per_split)); \
   }
+// the packed kernel rows of an item's channel tile
+#define EMO_S_WSRC(P_) (reinterpret_cast<const char*>(a.wpk) + ((long)P_##cotile * nstages_all) * (3 * Cfg::WROW_BYTES))
+#define it_wsrc EMO_S_WSRC(it_)
 // points the patch-load cursor at the tile of item P_: the lane's 16-byte load (its quad, or the aligned quad that contains its
 // halo pixel) and whether it lies inside the image.  Per-lane values are derived where the cursor moves, not carried per item
-#define EMO_S_CURSOR_TO(P_)                                                                           \
+#define EMO_S_CURSOR_OF(P_, ok_, off_)                                                                \
   {                                                                                                   \
     const int x0s_ = UPS ? P_##x0 >> 1 : P_##x0, y0s_ = UPS ? P_##y0 >> 1 : P_##y0;   /* tile origin in source pixels */ \
     const int q_y_ = y0s_ - 1 + q_r;                                                                  \
     const int q_x_ = is_quad ? x0s_ + 4 * q_c : (h_side ? x0s_ + TWS : x0s_ - 4);   /* first pixel of the lane's 16-byte load */ \
-    lq_ok = (is_quad || is_halo) && (unsigned)q_y_ < (unsigned)a.H && q_x_ >= 0 && q_x_ < a.W;        \
-    lq_off = lq_ok ? (unsigned)(q_y_ * a.W + q_x_) * 4u : 0u;                                         \
-    lq_z0 = P_##z0;                                                                                   \
+    ok_ = (is_quad || is_halo) && (unsigned)q_y_ < (unsigned)a.H && q_x_ >= 0 && q_x_ < a.W;          \
+    off_ = ok_ ? (unsigned)(q_y_ * a.W + q_x_) * 4u : 0u;                                             \
   }
+#define EMO_S_CURSOR_TO(P_) { EMO_S_CURSOR_OF(P_, lq_ok, lq_off) lq_z0 = P_##z0; }
 
   // LDS byte offsets of the lane's operands: weight fragment (+ row buffer / plane / tap column immediates) and, for every tap,
   // the patch slot of the lane's output pixel (+ half * CHS: the lane's 8-channel group; + buffer / plane immediates)
@@ -649,7 +685,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     q_tix[b_] = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                     \
   }
 #define EMO_S_ISSUE_LOADS(b_, u0_, u1_)                                                               \
-  { _Pragma("unroll") for (int u = (u0_); u < (u1_); ++u) qv[b_][u] = emo_bload4_pinned(xrs, q_vo, usoff[u]); }
+  { _Pragma("unroll") for (int u = (u0_); u < (u1_); u += 2) emo_bload4x2_pinned(xrs, q_vo, usoff[u], usoff[u + 1], qv[b_][u], qv[b_][u + 1]); }
 #define EMO_S_HALF_TABLE(b_, hf_)                                                                     \
   {                                                                                                   \
     const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix[b_] + (hf_);                   \
@@ -729,8 +765,59 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
   constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
 
+  // ---- prologue, first part: everything that is only ISSUED -- the scale / shift / bias table entries (through registers: their
+  //      global loads go out BEFORE the pinned loads and are stored to LDS behind them, one memory round trip for everything;
+  //      while pinned loads are in flight the compiler must never copy or spill a register whose load has not landed,
+  //      tools/kernel_resources.py --audit), the kernel rows of the first stage by DMA, the patch loads of the first two stages.
+  //      A persistent block runs this part for its NEXT item behind the closing barrier of the current item's K loop, in front
+  //      of the epilogue: the raw patch registers and the weight buffers are idle there, and the round trip to memory (most of the
+  //      7-10 k cycles a prologue took, profiles/r4_conv_phase_timing_final.jsonl) hides behind the epilogue's own traffic ----
+  constexpr int NTE = Cfg::SCT / 256;
+  float te_sc[NTE], te_sh[NTE], te_b = 0.0f;
+#define EMO_S_PROLOGUE_ISSUE(P_, LOADS_)                                                              \
+  {                                                                                                   \
+    xrs = emo_raw_buffer(a.x + (long)P_##n * a.Cin * DHW);                                            \
+    EMO_S_CURSOR_TO(P_)                                                                               \
+    if (LOADS_) {                                                                                     \
+      _Pragma("unroll") for (int k = 0; k < NTE; ++k) {                                               \
+        const int c = tid + 256 * k;                                                                  \
+        const bool real = has_affine && c < a.Cin;                                                    \
+        te_sc[k] = real ? a.scale[(long)P_##n * a.Cin + c] : 1.0f;                                    \
+        te_sh[k] = real ? a.shift[(long)P_##n * a.Cin + c] : 0.0f;                                    \
+      }                                                                                               \
+      if (tid < BM && a.bias != nullptr && a.partial == nullptr) {                                    \
+        const int co_ = P_##cotile * BM + tid;                                                        \
+        te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];                                               \
+      }                                                                                               \
+      EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 0);                  \
+      EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 1);                  \
+      if constexpr (ONEBAR) EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 2); \
+    }                                                                                                 \
+    EMO_S_SET_STAGE_INIT(P_##st_begin);                                                               \
+    EMO_S_ISSUE_BEGIN(0)                                                                              \
+    if (LOADS_) EMO_S_ISSUE_LOADS(0, 0, 8)                                                            \
+    {                                                                                                 \
+      const int st1 = (P_##st_begin + 1) < P_##st_end ? (P_##st_begin + 1) : P_##st_begin;            \
+      EMO_S_SET_STAGE_STEP(st1);                                                                      \
+    }                                                                                                 \
+    EMO_S_ISSUE_BEGIN(1)                                                                              \
+    if (LOADS_) EMO_S_ISSUE_LOADS(1, 0, 8)                                                            \
+  }
+
+  // ---- the item loop.  CHAINED items (fp16 split): when the block's next item belongs to the same sample (same scale / shift
+  //      tables) and both have an even number >= 2 of stages (buffer parities line up), the stage pipeline simply runs on into
+  //      it -- the loads, kernel rows and conversion that the last two stages of an item issue for "stage + 1 / + 2" were dead
+  //      re-stages of the last stage; they now fetch the next item's first two stages, at no extra instruction in the K loop.
+  //      Behind the epilogue the next item then starts with a four-line prologue (accumulators, bias, two weight pieces, one
+  //      barrier) instead of the full one (7-10 k cycles of a 57 k cycle item, bound by what one CU can pull from L2 in a burst:
+  //      issuing the same loads in front of the epilogue or de-phasing the CUs moved that time, it did not remove it --
+  //      tools/session/r4_call24.sh, r4_call25.sh).
+  //      No uniform state is carried around the loop except the flag: the item and its successor are decoded afresh in every
+  //      iteration (a web of loop-carried uniform values ends up in vector registers, which the "s" operands of the pinned
+  //      loads cannot take) ----
+  constexpr bool CHAIN = Cfg::CHAIN;
+  bool chained_in = false;                 // this item's first two stages were staged by the previous item's last two
   for (int idx8 = blockIdx.x >> 3; idx8 < n_mine; idx8 += l_stride) {
-  EMO_S_DECODE(it_, l_base + idx8)
 #if EMO_S_TIMING
   unsigned long long tstamp[12];
   for (int k = 0; k < 12; ++k) tstamp[k] = 0;
@@ -738,46 +825,54 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   unsigned long long tstep[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // EMO_S_TIMING == 3: cycles per step index of the K loop, summed
 #endif
   EMO_S_STAMP(0)
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TPH; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
-
-  xrs = emo_raw_buffer(a.x + (long)it_n * a.Cin * DHW);
-  EMO_S_CURSOR_TO(it_)
-  // ---- prologue: the kernel rows of the first stage by DMA, the loads of the first two stages, the first patch converted into
-  //      P[0]; it leaves the state every stage leaves to the next: buffer 1 holds the landed loads of the second stage, the
-  //      tables are that stage's, DMA(first stage, row 2) is in flight, fragment set 0 holds step 0 ----
-  // (the table entries travel through registers: their global loads are issued BEFORE the pinned loads and stored to LDS
-  // behind them -- one memory round trip for everything, and while pinned loads are in flight the compiler has nothing to do
-  // but a few LDS stores: it must never copy or spill a register whose load has not landed, tools/kernel_resources.py --audit)
-  constexpr int NTE = Cfg::SCT / 256;
-  float te_sc[NTE], te_sh[NTE], te_b = 0.0f;
-#pragma unroll
-  for (int k = 0; k < NTE; ++k) {
-    const int c = tid + 256 * k;
-    const bool real = has_affine && c < a.Cin;
-    te_sc[k] = real ? a.scale[(long)it_n * a.Cin + c] : 1.0f;
-    te_sh[k] = real ? a.shift[(long)it_n * a.Cin + c] : 0.0f;
+  EMO_S_DECODE(it_, l_base + idx8)
+  int nx_L = 0, nx_cotile = 0, nx_ks = 0, nx_n = 0, nx_ptile = 0, nx_x0 = 0, nx_y0 = 0, nx_z0 = 0, nx_st_begin = 0, nx_st_end = 0;
+  bool chain_out = false, nxq_ok = false;
+  unsigned nxq_off = 0;
+  int nx_cc0 = 0, nx_kd0 = 0;
+  if (CHAIN && idx8 + l_stride < n_mine) {
+    EMO_S_DECODE(nx_, l_base + idx8 + l_stride)
+    const int nst_ = it_st_end - it_st_begin, nxst_ = nx_st_end - nx_st_begin;
+    chain_out = nx_n == it_n && nst_ >= 2 && (nst_ & 1) == 0 && nxst_ >= 2 && (nxst_ & 1) == 0;
+    // the next item's load cursor, ready for the stage that switches to it (the K loop stays free of branches: with one
+    // around the switch the compiler moved 109 accumulators to ordinary registers and back in every stage pair)
+    EMO_S_CURSOR_OF(nx_, nxq_ok, nxq_off)
+    nx_cc0 = __builtin_amdgcn_readfirstlane(nx_st_begin / a.KD);
+    nx_kd0 = nx_st_begin - nx_cc0 * a.KD;
   }
-  if (tid < BM && a.bias != nullptr && a.partial == nullptr) {
-    const int co_ = it_cotile * BM + tid;
-    te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];
-  }
-  EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 0);
-  EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 1);
-  if constexpr (ONEBAR) EMO_S_DMA_ROW(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 2);
-  EMO_S_SET_STAGE_INIT(it_st_begin);
-  EMO_S_ISSUE_BEGIN(0)
-  EMO_S_ISSUE_LOADS(0, 0, 8)
-  {
-    const int st1 = (it_st_begin + 1) < it_st_end ? (it_st_begin + 1) : it_st_begin;
-    EMO_S_SET_STAGE_STEP(st1);
-  }
-  EMO_S_ISSUE_BEGIN(1)
-  EMO_S_ISSUE_LOADS(1, 0, 8)
+  // (what no path below reads before writing it -- the fragment sets, the first raw patch buffer, the pixel under conversion --
+  // is declared dead here: carried around the item loop as live values, the allocator kept second copies of ~100 registers in
+  // accumulation registers, refreshed in every stage pair of the K loop)
+#if !EMO_S_NOKILL
+#pragma unroll
+  for (int st_ = 0; st_ < 2; ++st_)
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(fa_[st_][pl][i]));
+#pragma unroll
+      for (int j = 0; j < TP; ++j) asm volatile("" : "=v"(fb_[st_][pl][j]));
+    }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) asm volatile("" : "=v"(qv[0][u]));
+  asm volatile("" : "=v"(cv_h));
+  asm volatile("" : "=v"(cv_m));
+  if constexpr (SPLIT == 3) asm volatile("" : "=v"(cv_l));
+#endif
+  if (CHAIN && chained_in) {
+    // P[0] holds the converted patch of the first stage, W[0] its kernel rows, qv[1] the landed loads of the second stage, q_sc /
+    // q_sh its first table entries (the state every stage leaves to the next); the tables are the sample's.  What is left:
+    xrs = emo_raw_buffer(a.x + (long)it_n * a.Cin * DHW);
+    if (tid < BM) smem[Cfg::OFF_BIAS_F + (tid >> 5) * 32 + (tid & 3) * 8 + ((tid & 31) >> 2)] = te_b;
+    const char* const w1_ = it_wsrc + (long)(it_st_begin + 1) * (3 * Cfg::WROW_BYTES);
+    EMO_S_DMA_STAGE_PIECE(w1_, 1, 0)
+    EMO_S_DMA_STAGE_PIECE(w1_, 1, 1)
+    EMO_S_BARRIER(2);
+  } else {
+  EMO_S_PROLOGUE_ISSUE(it_, true)
+  // ---- prologue, second part: the tables into LDS, the first patch converted into P[0]; it leaves the state every stage leaves
+  //      to the next: buffer 1 holds the landed loads of the second stage, the tables are that stage's, DMA(first stage, row 2)
+  //      is in flight, fragment set 0 holds step 0 ----
 #pragma unroll
   for (int k = 0; k < NTE; ++k) {       // (without an affine the index wraps at SCT: identity entries)
     const int c = tid + 256 * k;
@@ -812,6 +907,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     EMO_S_DMA_PIECE(it_wsrc + (long)it_st_begin * (3 * Cfg::WROW_BYTES), 2, 1)
     EMO_S_BARRIER(2);                    // (LDS stores of P[0] visible; the two pieces stay in flight)
   }
+  }
 
   // ---- K loop, two stages per iteration (buffer parities and fragment sets are compile-time constants).  Stage cg, parity par:
   //        steps 0 .. 7   half a pixel each of the patch of stage cg + 1 is converted from qv[par ^ 1] into P[par ^ 1]
@@ -823,6 +919,15 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   //                       DMA(cg + 1, 2) and the first fragments of stage cg + 1 from P[par ^ 1]
   //      every wave issues exactly NDMA pieces per row and 8 quad loads per stage, so the counts are uniform ----
   EMO_S_STAMP(1)
+  // (the accumulators are cleared HERE, in the block in front of the K loop: cleared in front of the two prologue forms, the
+  // compiler carried them through both as ordinary registers and moved 109 of them to their accumulation registers and back
+  // in every stage pair)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TPH; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_lo[i][j][r] = 0.0f; acc_hi[i][j][r] = 0.0f; }
   EMO_S_LOAD_FRAGS(0, Cfg::OFF_W, Cfg::OFF_P, 0, 0)       // (first stage: W[0], P[0])
   for (int cg0 = it_st_begin; cg0 < it_st_end; cg0 += 2) {
 #pragma unroll
@@ -832,8 +937,18 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       const int pcur = Cfg::OFF_P + par * PBUF, pnxt = Cfg::OFF_P + (par ^ 1) * PBUF;
       // stage cg + 1 (its weight rows are fetched during this stage) and stage cg + 2 (its patch is loaded during this stage),
       // clamped to the last stage: a harmless re-stage
-      const char* const dma_ptr = it_wsrc + (long)((cg + 1) < it_st_end ? cg + 1 : it_st_end - 1) * (3 * Cfg::WROW_BYTES);
-      const char* const dma_ptr2 = it_wsrc + (long)((cg + 2) < it_st_end ? cg + 2 : it_st_end - 1) * (3 * Cfg::WROW_BYTES);
+      // (chained: past the item's end the sequence continues with the next item's stages)
+      const bool nx1_ = CHAIN && par == 1 && chain_out && cg + 1 >= it_st_end, nx2_ = CHAIN && chain_out && cg + 2 >= it_st_end;
+      // (pointers from a SELECTED stage index -- 32-bit selects, no branch in the loop; the packed rows of (channel tile c, stage
+      // k) sit at index c * nstages_all + k)
+      const int g1_ = nx1_ ? nx_cotile * nstages_all + nx_st_begin + (cg + 1 - it_st_end)
+                           : it_cotile * nstages_all + ((cg + 1) < it_st_end ? cg + 1 : it_st_end - 1);
+      const int g2_ = nx2_ ? nx_cotile * nstages_all + nx_st_begin + (cg + 2 - it_st_end)
+                           : it_cotile * nstages_all + ((cg + 2) < it_st_end ? cg + 2 : it_st_end - 1);
+      const char* const dma_ptr = reinterpret_cast<const char*>(a.wpk) + (long)g1_ * (3 * Cfg::WROW_BYTES);
+      const char* const dma_ptr2 = reinterpret_cast<const char*>(a.wpk) + (long)g2_ * (3 * Cfg::WROW_BYTES);
+      // (the last stage of a chained item leaves W[1] alone: it is the epilogue's scratch; the chained prologue fetches the pieces)
+      const bool skip_w2_ = CHAIN && par == 1 && chain_out && cg + 1 >= it_st_end;
       if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int gs = 0; gs < 9; ++gs) {
@@ -865,7 +980,26 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
         }
         if (gs == 8) EMO_S_TOUCH_QUAD(par)       // (the loads of stage cg + 2 have landed behind the barrier above)
         if (gs == 0) {
-          EMO_S_SET_STAGE_STEP((cg + 2) < it_st_end ? cg + 2 : it_st_end - 1);
+          // the patch loads of stage cg + 2 (clamped to the last stage: a harmless re-stage).  Chained item: past its end they
+          // are the next item's first two stages -- stage counts of chained items are even, so the cursor moves on to the next
+          // item's tile in a stage of parity 0 (selects, no branch) and takes a plain step in the stage behind it
+          const bool sw_ = CHAIN && par == 0 && chain_out && cg + 2 == it_st_end;
+          const int tgt_ = (CHAIN && par == 1 && chain_out && cg + 2 > it_st_end) ? nx_st_begin + 1
+                           : (cg + 2) < it_st_end ? cg + 2 : it_st_end - 1;
+          if (CHAIN && par == 0) {
+            lq_ok = sw_ ? nxq_ok : lq_ok;
+            lq_off = sw_ ? nxq_off : lq_off;
+            lq_z0 = sw_ ? nx_z0 : lq_z0;
+            const int adv_ = (!sw_ && tgt_ != ld_stage) ? 1 : 0;
+            int kd_ = ld_kd + adv_, cc_ = ld_cc;
+            if (kd_ == a.KD) { kd_ = 0; ++cc_; }
+            ld_stage = sw_ ? nx_st_begin : ld_stage + adv_;
+            ld_cc = sw_ ? nx_cc0 : cc_;
+            ld_kd = sw_ ? nx_kd0 : kd_;
+            EMO_S_SET_STAGE_VARS()
+          } else {
+            EMO_S_SET_STAGE_STEP(tgt_);
+          }
           EMO_S_ISSUE_BEGIN(par)
         }
         // ---- one step: the fragments of the NEXT step, half a pixel of conversion, 4 * NPROD MFMAs.  The order inside the step
@@ -885,7 +1019,13 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
               // weights of stage cg + 1 into W[par ^ 1]: pieces 2 .. 8 in steps 0 .. 4; the first two pieces of stage cg + 2 into
               // W[par] behind the barrier of step 8; the quad loads two per step in steps 0 .. 3
               static_assert(!ONEBAR || (NPL == 2 && Cfg::NDMA == 3), "piece schedule of the one-barrier stage");
-              if (gs == 8 && pl < 2) EMO_S_DMA_STAGE_PIECE(dma_ptr2, par, pl)
+              if (gs == 8 && pl < 2) {
+                // (chained item, last stage: the two pieces go to the patch buffer this stage has finished with, a dump)
+                const int j_ = wave + 4 * pl;
+                const unsigned dst_ = smem_lds + (skip_w2_ ? (unsigned)((Cfg::OFF_P + par * PBUF) * 16 + j_ * 1024)
+                                                           : (unsigned)((Cfg::OFF_W + par * Cfg::WSTAGE) * 16 + j_ * 1024));
+                emo_dma16_pinned_s(dma_ptr2 + j_ * 1024, lane16, dst_);
+              }
               if (gs < 4 && pl == 0) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 2 + gs)
               if (gs < 4 && pl == 1) EMO_S_ISSUE_LOADS(par, 2 * gs, 2 * gs + 2)
               if (gs == 4) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 6 + pl)
@@ -949,42 +1089,45 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       if (EMO_CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
   }
+  const int ep_L = it_L, ep_nst = it_st_end - it_st_begin;   // (measurement builds log under the item's own index)
   EMO_S_STAMP(2)
   {
-    // transposition scratch: the patch buffer of the last stage; the weight stage buffer the last stage did not read (one-barrier
-    // schedule: it holds the dead re-staged rows); or a region of its own
+    // transposition scratch: the patch buffer of the last stage; a weight stage buffer (one-barrier schedule: the one the last
+    // stage did not read, which holds the dead re-staged rows -- chained item: the one it did read, the other holds the next
+    // item's first stage); or a region of its own
     const int last_par = (it_st_end - it_st_begin - 1) & 1;
     float* const scratch = smem + (Cfg::EPI_IN_PATCH ? (Cfg::OFF_P + last_par * PBUF) * 4
-                                   : Cfg::EPI_IN_W ? (Cfg::OFF_W + (last_par ^ 1) * Cfg::WSTAGE) * 4 : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
-    // Between the K loop and the epilogue: the re-issued loads / DMA of the clamped last stages are dead and are drained (from
-    // there on nothing pinned is in flight, the epilogue is ordinary compiler-scheduled code), and every wave must be past its
-    // last fragment read of the item's last stage before its patch buffer becomes the epilogue's scratch.  The fast forms issue
-    // the first half's residual loads in front of that barrier
+                                   : Cfg::EPI_IN_W ? (Cfg::OFF_W + ((CHAIN && chain_out) ? last_par : (last_par ^ 1)) * Cfg::WSTAGE) * 4
+                                   : Cfg::OFF_EPI_F) + wave * Cfg::EPI_WAVE;
+    // the item the epilogue writes
+    const int ep_n = it_n, ep_cotile = it_cotile, ep_ptile = it_ptile, ep_ks = it_ks, ep_x0 = it_x0, ep_y0 = it_y0, ep_z0 = it_z0;
+    // Between the K loop and the epilogue: the re-issued loads / DMA of the clamped last stages are dead and are drained (a
+    // chained item's are the next item's first stages: they have landed behind this), and every wave must be past its last
+    // fragment read of the item's last stage before its buffers become the epilogue's scratch
+    EMO_S_WAIT(0);
+    EMO_S_STAMP(5)
+    __syncthreads();
+    EMO_S_STAMP(6)
+    if (CHAIN && chain_out && tid < BM && a.bias != nullptr && a.partial == nullptr) {   // the next item's bias entries
+      const int co_ = nx_cotile * BM + tid;
+      te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];
+    }
 #define EMO_S_EPI_FAST(RES_)                                                                                                      \
     {                                                                                                                              \
       floatx4 rv_[8];                                                                                                              \
-      EMO_S_WAIT(0);                                                                                                               \
-      EMO_S_STAMP(5)                                                                                                               \
-      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0>(a, rv_, it_n, it_cotile, it_x0, it_y0, it_z0, wp, lane);                       \
-      __syncthreads();                                                                                                             \
-      EMO_S_STAMP(6)                                                                                                               \
+      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0>(a, rv_, ep_n, ep_cotile, ep_x0, ep_y0, ep_z0, wp, lane);                       \
       conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_>(a, acc_lo, acc_hi, rv_, scratch,                  \
-                                                                                 smem + Cfg::OFF_BIAS_F, smem + Cfg::OFF_STAT_F, it_n, \
-                                                                                 it_cotile, it_ptile, it_x0, it_y0, it_z0, wp, half, \
+                                                                                 smem + Cfg::OFF_BIAS_F, smem + Cfg::OFF_STAT_F, ep_n, \
+                                                                                 ep_cotile, ep_ptile, ep_x0, ep_y0, ep_z0, wp, half, \
                                                                                  l32, lane, tid EMO_S_TSTAMP_ARG);                  \
     }
     if (epi_mode == 1) EMO_S_EPI_FAST(1)
     else if (epi_mode == 2) EMO_S_EPI_FAST(2)
     else if (epi_mode == 0) EMO_S_EPI_FAST(0)
-    else {
-      EMO_S_WAIT(0);
-      EMO_S_STAMP(5)
-      __syncthreads();
-      EMO_S_STAMP(6)
+    else
       conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(a, acc_lo, acc_hi, scratch, smem + Cfg::OFF_BIAS_F,
-                                                                        smem + Cfg::OFF_STAT_F, it_n, it_cotile, it_ptile, it_ks, it_x0,
-                                                                        it_y0, it_z0, wp, half, l32, lane, tid EMO_S_TSTAMP_ARG);
-    }
+                                                                        smem + Cfg::OFF_STAT_F, ep_n, ep_cotile, ep_ptile, ep_ks, ep_x0,
+                                                                        ep_y0, ep_z0, wp, half, l32, lane, tid EMO_S_TSTAMP_ARG);
 #undef EMO_S_EPI_FAST
   }
   if constexpr (SPLIT == 2) {
@@ -994,8 +1137,8 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   EMO_S_STAMP(3)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   EMO_S_STAMP(4)
-  if (tid == 0 && it_L < EMO_S_TLOG_N) {
-    unsigned long long* t_ = emo_s_tlog + (long)it_L * EMO_S_TLOG_W;
+  if (tid == 0 && ep_L < EMO_S_TLOG_N) {
+    unsigned long long* t_ = emo_s_tlog + (long)ep_L * EMO_S_TLOG_W;
 #pragma unroll
     for (int k = 0; k < 12; ++k) t_[k] = tstamp[k];
     t_[12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
@@ -1003,16 +1146,16 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     t_[14] = (unsigned long long)blockIdx.x;
   }
 #if EMO_S_TIMING == 3
-  if (lane == 0 && it_L < EMO_S_TLOG_N / 8) {   // per-step cycles of every wave (rows N/4 .. 3N/4)
-    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)it_L * 4 + wave) * EMO_S_TLOG_W;
+  if (lane == 0 && ep_L < EMO_S_TLOG_N / 8) {   // per-step cycles of every wave (rows N/4 .. 3N/4)
+    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)ep_L * 4 + wave) * EMO_S_TLOG_W;
 #pragma unroll
     for (int k = 0; k < 9; ++k) w_[k] = tstep[k];
-    w_[9] = (unsigned long long)(it_st_end - it_st_begin);
+    w_[9] = (unsigned long long)ep_nst;
   }
 #endif
 #if EMO_S_TIMING == 2
-  if (lane == 0 && it_L < EMO_S_TLOG_N / 8) {   // per-wave barrier accounting in rows N/4 .. 3N/4 of the log (first N/8 items)
-    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)it_L * 4 + wave) * EMO_S_TLOG_W;
+  if (lane == 0 && ep_L < EMO_S_TLOG_N / 8) {   // per-wave barrier accounting in rows N/4 .. 3N/4 of the log (first N/8 items)
+    unsigned long long* w_ = emo_s_tlog + ((long)EMO_S_TLOG_N / 4 + (long)ep_L * 4 + wave) * EMO_S_TLOG_W;
     w_[0] = tw_wait; w_[1] = tw_bar; w_[2] = tw_n; w_[3] = tstamp[2] - tstamp[1];
   }
 #endif
@@ -1020,6 +1163,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   // the next prologue overwrites the tables, the statistics exchange and (conversion) the patch buffer the epilogue transposed
   // through: every wave must be out of the epilogue first
   __syncthreads();
+  chained_in = chain_out;
   }
 #undef EMO_S_SET_STAGE_VARS
 #undef EMO_S_SET_STAGE_INIT
@@ -1041,7 +1185,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #undef EMO_S_LOAD_FRAGS
 
 #undef EMO_S_DECODE
+#undef it_wsrc
+#undef EMO_S_WSRC
+#undef EMO_S_PROLOGUE_ISSUE
 #undef EMO_S_CURSOR_TO
+#undef EMO_S_CURSOR_OF
 }
 
 template <int TR, int TW, bool UPS, int SPLIT = 3>

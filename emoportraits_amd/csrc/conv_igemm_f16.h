@@ -95,10 +95,11 @@ __device__ __forceinline__ void emo_dma16_pinned(const void* gsrc, unsigned lds_
 }
 
 // the same with a wave-uniform source base in SGPRs and a 32-bit per-lane byte offset: no 64-bit vector address arithmetic per
-// piece (the offset lane * 16 is one loop-invariant register)
+// piece (the offset lane * 16 is one loop-invariant register).  (s_mov, s_mov, s_nop 2: the five wait states of
+// EMO_SGPR_HAZARD_NOP in front of the load that reads the base)
 __device__ __forceinline__ void emo_dma16_pinned_s(const void* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
@@ -106,13 +107,19 @@ __device__ __forceinline__ void emo_dma16_pinned_s(const void* sbase, unsigned v
 // eight channel planes of a staging item differ only in soff, which is loop-invariant: no address arithmetic per load.
 __device__ __forceinline__ float emo_bload_pinned(emo_intx4 rsrc, unsigned voff, unsigned soff) {
   float v;
-  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile(EMO_SGPR_HAZARD_NOP "buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   return v;
 }
 __device__ __forceinline__ floatx4 emo_bload4_pinned(emo_intx4 rsrc, unsigned voff, unsigned soff) {
   floatx4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile(EMO_SGPR_HAZARD_NOP "buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   return v;
+}
+// two loads that differ in soff only, one statement (one set of wait states)
+__device__ __forceinline__ void emo_bload4x2_pinned(emo_intx4 rsrc, unsigned voff, unsigned soff0, unsigned soff1, floatx4& v0,
+                                                    floatx4& v1) {
+  asm volatile(EMO_SGPR_HAZARD_NOP "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %5 offen"
+               : "=&v"(v0), "=&v"(v1) : "v"(voff), "s"(rsrc), "s"(soff0), "s"(soff1) : "memory");
 }
 __device__ __forceinline__ emo_intx4 emo_raw_buffer(const void* base) {
   const unsigned long long b = reinterpret_cast<unsigned long long>(base);

@@ -2,13 +2,16 @@
 emoportraits_amd/build.py).
 
     python tools/kernel_resources.py <file.hip> [...]      # table per file
-    python tools/kernel_resources.py --audit               # every conv_inst_*.hip: the kernels hide their global loads in inline
+    python tools/kernel_resources.py --audit [-DNAME=V]    # every conv_inst_*.hip: the kernels hide their global loads in inline
                                                            # asm, and a register the compiler spills or copies while such a load is
                                                            # in flight is silent corruption (cdna_hip_programming.md section 5.7).
                                                            # Invariant checked in the generated ISA: NO scratch access between the
                                                            # first pinned load (prologue) and the last MFMA of a kernel, and no
                                                            # instruction touches the destination of a load that the listing's
-                                                           # vmcnt waits have not yet covered.  Exit code 1 on a violation.
+                                                           # vmcnt waits have not yet covered; and no vector-memory
+                                                           # instruction of an asm statement reads a scalar register
+                                                           # within five wait states of a vector-ALU write of it (reloads
+                                                           # of spilled scalars).  Exit code 1 on a violation.
 """
 import concurrent.futures
 import glob
@@ -45,18 +48,19 @@ def show(row):
             f"scratch={row.get('ScratchSize [bytes/lane]')} occ={row.get('Occupancy [waves/SIMD]')}")
 
 
-_VREG = re.compile(r"\bv(\d+)\b")
-_VRANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
+_VREG = re.compile(r"\b([va])(\d+)\b")
+_VRANGE = re.compile(r"\b([va])\[(\d+):(\d+)\]")
 
 
 def _vregs(text):
-    regs = {int(m) for m in _VREG.findall(text)}
-    for a, b in _VRANGE.findall(text):
-        regs.update(range(int(a), int(b) + 1))
+    """vector registers named in an operand list; accumulation registers a<n> as 1000 + n (pinned loads may target them)"""
+    regs = {int(n) + (1000 if k == "a" else 0) for k, n in _VREG.findall(text)}
+    for k, a, b in _VRANGE.findall(text):
+        regs.update(range(int(a) + (1000 if k == "a" else 0), int(b) + 1 + (1000 if k == "a" else 0)))
     return regs
 
 
-def inflight_reads(lines):
+def inflight_reads(lines, walk_epilogue=False):
     """Instructions that touch the destination VGPR of a global load which, by the issue order and the vmcnt waits of the
     listing, may still be in flight.  The kernels issue loads in inline asm and wait with hand-counted `s_waitcnt vmcnt(N)`:
     a register copy or a too-small N corrupts data silently, so the listing itself is checked.  The K loop is walked
@@ -129,6 +133,79 @@ def inflight_reads(lines):
             break
         else:
             pc += 1
+    # Behind the last MFMA: a persistent block issues the pinned loads of its NEXT item in front of the epilogue
+    # (conv_igemm_bf16x3.h, EMO_S_PREFETCH_NEXT); they land at the top of the next iteration (vmcnt(0)).  The epilogue is branchy
+    # compiler-scheduled code: every path from such a load is walked (both outcomes of a conditional branch) until the in-flight
+    # set is empty, with the same rule -- nothing may touch a destination that the vmcnt waits on the path have not covered.
+    import copy
+    starts = [i for i in range(hi + 1, len(lines)) if in_asm[i] and lines[i].split(";")[0].strip().startswith(("buffer_load", "global_load"))
+              and not lines[i].split(";")[0].strip().startswith("global_load_lds") and " lds" not in lines[i]]
+    seen = set()
+    work = []
+    if starts and walk_epilogue:
+        # start at the first pinned load of every straight run of them (a run = the asm loads of one prefetch site)
+        runs = [i for k, i in enumerate(starts) if k == 0 or i - starts[k - 1] > 400]
+        for r in runs:
+            work.append((r, {"seq": 0, "ops": [], "skip": (0, 0)}))
+    steps = 0
+    while work and steps < 400000:
+        pc, st = work.pop()
+        state = st
+        while 0 <= pc < len(lines) and steps < 400000:
+            steps += 1
+            key = (pc, frozenset().union(*[frozenset(o[1]) for o in state["ops"]]) if state["ops"] else frozenset())
+            if key in seen:
+                break
+            seen.add(key)
+            step(pc)
+            t = lines[pc].split(";")[0].strip()
+            if t.startswith("s_endpgm"):
+                break
+            if pc not in starts and not state["ops"] and pc > starts[0] + 1 and not any(pc < s_ <= pc + 400 for s_ in starts):
+                break                                    # everything has landed and no further pinned load is near
+            m = re.match(r"s_(c?branch)\w*\s+(\.LBB\d+_\d+)", t)
+            tgt = labels.get(m.group(2)) if m else None
+            if tgt is not None and m.group(1) == "branch":
+                pc = tgt
+            elif tgt is not None:
+                work.append((tgt, copy.deepcopy(state)))
+                pc += 1
+            else:
+                pc += 1
+    return hits
+
+
+def sgpr_hazards(lines):
+    """Vector-memory instructions inside asm statements that read a scalar register fewer than five wait states behind a
+    vector-ALU write of it (v_readlane reloads of spilled scalars, v_readfirstlane, v_cmp): the compiler pads its own
+    instructions, not the contents of an asm statement.  Straight-line scan (a branch target is assumed to arrive with the
+    window the fall-through path leaves: conservative in the common case of a reload right in front of the statement)."""
+    def sregs(t):
+        r = {int(x) for x in re.findall(r"\bs(\d+)\b", t)}
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", t):
+            r.update(range(int(a), int(b) + 1))
+        return r
+    hits, recent, in_asm = [], [], False
+    for i, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            in_asm = True
+            continue
+        if "#ASMEND" in l:
+            in_asm = False
+            continue
+        t = l.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        ws = int(t.split()[1]) + 1 if op == "s_nop" else 1
+        if in_asm and re.match(r"(buffer|global|flat|scratch)_(load|store|atomic)", op):
+            used = sregs(t)
+            for age, regs in recent:
+                if used & regs and age < 5:
+                    hits.append((i + 1, t, sorted(used & regs), age))
+        recent = [(a + ws, r) for a, r in recent if a + ws < 8]
+        if re.match(r"v_readlane_b32|v_readfirstlane_b32|v_cmp", op):
+            recent.append((0, sregs(t.split()[1].rstrip(","))))
     return hits
 
 
@@ -150,7 +227,9 @@ def loop_scratch(src):
                 # vmcnt model, and flags a copy or spill of any register whose pinned load may not have landed
                 lo = mf[0] if mf else 10 ** 9
                 inside = [i for i in sc if mf and lo < i < mf[-1]]
-                out.append((name, len(inside), len(sc), inflight_reads(lines)))
+                out.append((name, len(inside), len(sc), inflight_reads(lines, walk_epilogue="conv_igemm_bf16x3_kernel" in name)
+                            + [(ln, t + "   [scalar operand %s written by the vector ALU %d wait states before]" % (r, a), [])
+                               for ln, t, r, a in sgpr_hazards(lines)]))
             m = re.search(r"Begin function (\S+)", line)
             name = m.group(1) if m else None
             lines = []
@@ -160,7 +239,8 @@ def loop_scratch(src):
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["--audit"]:
+    if sys.argv[1:2] == ["--audit"] and all(a.startswith("-D") for a in sys.argv[2:]):
+        B.FLAGS = B.FLAGS + sys.argv[2:]          # (A/B builds: python -m emoportraits_amd.build --variant x NAME=V  <->  --audit -DNAME=V)
         files = sorted(glob.glob(os.path.join(B.CSRC, "conv_inst_*.hip")))
         with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
             res = list(ex.map(loop_scratch, files))
@@ -175,7 +255,8 @@ if __name__ == "__main__":
                     if inside:
                         print(f"VIOLATION {os.path.basename(f)}: {nm[:110]}: {inside} scratch accesses inside the K loop")
                     for ln, t, regs in racy[:4]:
-                        print(f"VIOLATION {os.path.basename(f)}: {nm[:110]}: '{t}' touches v{regs} while its load may be in flight")
+                        what = f"touches v{regs} while its load may be in flight" if regs else "reads a scalar register too early"
+                        print(f"VIOLATION {os.path.basename(f)}: {nm[:110]}: '{t}' {what}")
         print(f"{total} kernels, {spilling} with scratch accesses outside the K loop (prologue / epilogue only), {bad} violations")
         sys.exit(1 if bad else 0)
     for src in sys.argv[1:]:
