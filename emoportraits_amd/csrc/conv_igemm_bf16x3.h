@@ -533,12 +533,11 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   //      (conv_igemm.h).  A block walks the items of its XCD's contiguous range with a stride: min(n_work, CUs) persistent
   //      blocks by default (no workgroup launch between two items: 3.5-4 k cycles of a 50-110 k cycle item), one block per item
   //      with EMO_CONV_BF16X3_PERSISTENT=0 (conv_igemm_bf16x3_launch).
-  //      Tried and removed this round: CHAINING consecutive items through one pipeline (the last two stages of an item fetch
-  //      the kernel rows and load / convert the patch of the next item's first stages, so that the next K loop starts behind
-  //      the epilogue without a prologue).  With the loads of the next item's second stage (32 registers) and the cursor state
-  //      live across the epilogue the register allocation of the K loop degraded (260 AGPR spill moves per stage pair against
-  //      47) and the saved prologue was paid back there: 305 vs 303 and 354 vs 361 TF on the two largest layers in the fp16
-  //      split (tools/session/r4_call13.sh) ----
+  //      Consecutive items of a block are chained through one stage pipeline in the fp16 split ("the item loop" below); a
+  //      first build of that, earlier this round, lost in the K loop what it saved in the prologue (260 accumulation-register
+  //      spill moves per stage pair against 47: tools/session/r4_call13.sh) and computed wrong tiles in the bf16 split -- the
+  //      former went away with the accumulators read where they are used and a branch-free loop, the latter was, in all
+  //      likelihood, the scalar-register hazard described at EMO_SGPR_HAZARD_NOP (conv_igemm.h) ----
   const int q8 = a.n_work >> 3, r8 = a.n_work & 7;
   const int xcd = blockIdx.x & 7;
   const int n_mine = q8 + (xcd < r8 ? 1 : 0);

@@ -108,12 +108,14 @@ GS_FN void glob_write16(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 // global_load_lds_dwordx4, saddr form: LDS destination = M0 (wave-uniform byte address) + lane * 16; source = SGPR base +
 // 32-bit VGPR byte offset.  M0 is compiler-reserved: written and restored inside the statement (cdna_hip_programming.md,
 // inline-asm rules).  hipcc does not count this load: the caller waits with s_waitcnt vmcnt(0) before the barrier.
+// (s_mov, s_mov, s_nop 2 = the five wait states a vector-memory read of a scalar register needs behind a vector-ALU write of
+// it -- sbase may have just been reloaded by v_readlane; the compiler does not pad asm statements)
 GS_FN void dma16(unsigned char* lds, int lds_wave_base, int /*lane*/, const float* sbase, int voff) {
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)lds_wave_base;
   const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
   unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(dst_u), "s"(sbase)
       : "memory");

@@ -339,10 +339,13 @@ def supports_f16(cout, cin, kd, kh, kw):
     return (kh, kw) in ((3, 3), (1, 1)) and kd in (1, 3) and not (kd == 3 and kh == 1) and cout >= 32 and cin % 8 == 0
 
 
-def supports_bf16x3(cout, cin, kd, kh, kw):
+def supports_bf16x3(cout, cin, kd, kh, kw, precision="bf16x3"):
     """layers the split-operand kernel takes: 3x3 / 3x3x3, whole 8-channel groups, and a 64-row channel tile that is at least
-    three quarters real (below that the exact-fp32 kernel's 32-row tiles win)"""
-    return (kh, kw) == (3, 3) and kd in (1, 3) and cin % 8 == 0 and cout / (-(-cout // BF16X3_BM) * BF16X3_BM) >= 0.75
+    three quarters real in the bf16 split (below that the exact-fp32 kernel's 32-row tiles win: six products on a half-empty
+    tile are twelve per useful one), at least half real in the fp16 split (three products: the 32-channel 3-D layers of the
+    WarpGenerator run 1.6x the fp32 MFMA kernel's speed on a half-empty tile)"""
+    fill = cout / (-(-cout // BF16X3_BM) * BF16X3_BM)
+    return (kh, kw) == (3, 3) and kd in (1, 3) and cin % 8 == 0 and fill >= (0.5 if precision == "f16x2" else 0.75)
 
 
 def bf16x3_launch_fits(Hl, Wl, ups=False):
@@ -381,7 +384,7 @@ class PackedConv:
         self.pinned_cfg = cfg
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
-        if precision in ("bf16x3", "f16x2") and not supports_bf16x3(cout, cin, kd, kh, kw):
+        if precision in ("bf16x3", "f16x2") and not supports_bf16x3(cout, cin, kd, kh, kw, precision):
             raise ValueError(f"{name}: the split-operand kernel covers 3x3 / 3x3x3 convolutions with a multiple of 8 input channels")
         if precision == "f16" and not supports_f16(cout, cin, kd, kh, kw):
             raise ValueError(f"{name}: the fp16-operand kernel covers 3x3 / 3x3x3 / 1x1 convolutions with >= 32 output "
@@ -459,6 +462,8 @@ class PackedConv:
         w, b = folded_conv(sd, prefix, kind)
         if precision is None:
             kd = w.shape[2] if w.dim() == 5 else 1
-            ok = supports_bf16x3 if _build_precision in ("bf16x3", "f16x2") else supports_f16
-            precision = _build_precision if ok(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1]) else "f32"
+            split = _build_precision in ("bf16x3", "f16x2")
+            ok = supports_bf16x3(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1], _build_precision) if split \
+                else supports_f16(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1])
+            precision = _build_precision if ok else "f32"
         return cls(prefix, w, b, device, cfg, precision)

@@ -31,6 +31,18 @@ CASES = [
 ]
 
 
+def test_fp16_split_on_a_half_empty_channel_tile():
+    """32 output channels on the 64-row tile (the WarpGenerator's last 3-D block: pack.supports_bf16x3(..., "f16x2")); the bf16
+    split declines such a layer"""
+    for case in (dict(N=2, Cin=64, Cout=32, dims=(4, 64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),
+                 dict(N=1, Cin=32, Cout=32, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, act="tanh")):
+        e, got, ref = run_conv(seed=23, precision="f16x2", **case)
+        print("PARITY conv f16x2, 32 of 64 tile rows:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+        assert e < 2e-5, e
+    with pytest.raises(ValueError):
+        pack.PackedConv("t", torch.randn(32, 64, 3, 3), None, DEV, precision="bf16x3")
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_bf16x3_meets_the_fp32_kernel_bound(case, precision):

@@ -82,18 +82,19 @@ def main():
             msh = timeit(lambda: ops.conv_igemm(x, lh, scale, shift, relu_in=True, ups=ups, out=out))
             rec["f16_cfg3_ms"] = round(msh, 3)
             rec["f16_cfg3_tflops"] = round(flops / msh / 1e9, 1)
-        if split and k == 3 and pack.supports_bf16x3(cout, cin, kd, k, k) and pack.bf16x3_launch_fits(odims[-2], odims[-1], ups):
+        fits = split and k == 3 and pack.bf16x3_launch_fits(odims[-2], odims[-1], ups)
+        if fits and pack.supports_bf16x3(cout, cin, kd, k, k):
             ls = pack.PackedConv("b3", w, None, DEV, precision="bf16x3")
             out = ops.conv_igemm(x, ls, scale, shift, relu_in=True, ups=ups)
             mss = timeit(lambda: ops.conv_igemm(x, ls, scale, shift, relu_in=True, ups=ups, out=out))
             rec["bf16x3_ms"] = round(mss, 3)
             rec["bf16x3_tflops"] = round(flops / mss / 1e9, 1)      # fp32-equivalent (algorithmic) FLOPs
-            if "--f16x2" in sys.argv:                                # opt-in two-term fp16 split (same kernel, SPLIT = 2)
-                l2 = pack.PackedConv("h2", w, None, DEV, precision="f16x2")
-                out = ops.conv_igemm(x, l2, scale, shift, relu_in=True, ups=ups)
-                ms2 = timeit(lambda: ops.conv_igemm(x, l2, scale, shift, relu_in=True, ups=ups, out=out))
-                rec["f16x2_ms"] = round(ms2, 3)
-                rec["f16x2_tflops"] = round(flops / ms2 / 1e9, 1)
+        if fits and "--f16x2" in sys.argv and pack.supports_bf16x3(cout, cin, kd, k, k, "f16x2"):   # two-term fp16 split (SPLIT = 2)
+            l2 = pack.PackedConv("h2", w, None, DEV, precision="f16x2")
+            out = ops.conv_igemm(x, l2, scale, shift, relu_in=True, ups=ups)
+            ms2 = timeit(lambda: ops.conv_igemm(x, l2, scale, shift, relu_in=True, ups=ups, out=out))
+            rec["f16x2_ms"] = round(ms2, 3)
+            rec["f16x2_tflops"] = round(flops / ms2 / 1e9, 1)
         if not f16_only:       # what the planner picks for this launch (block config + K split), as the networks run it
             la = pack.PackedConv("auto", w, None, DEV)
             Hl_, Wl_ = odims[-2], odims[-1]
