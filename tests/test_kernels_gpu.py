@@ -476,6 +476,27 @@ def test_upsample_trilinear(factors):
     assert rel_err(got, ref) < 1e-6
 
 
+@pytest.mark.parametrize("factors", [(2, 2, 2), (1, 2, 2), (2, 1, 2), (1, 1, 2)])
+@pytest.mark.parametrize("shape", [(2, 5, 4, 6, 8), (1, 3, 2, 4, 2), (1, 2, 3, 5, 4), (2, 4, 4, 16, 32), (1, 2, 1, 1, 64), (1, 1, 2, 2, 6)])
+def test_upsample_trilinear_even_widths_take_the_block_kernel(shape, factors):
+    """width factor 2 on an even width: one thread per block of up to 4 x 2 x 2 outputs that share their inputs
+    (csrc/resample.hip).  Bit for bit what the one-output-per-thread kernel computes (reached here through an output pointer
+    that is not 16-byte aligned), first / last pairs and quads of every axis included; both within 1e-6 of ATen's CPU kernel"""
+    from emoportraits_amd import hip
+    lib = hip.load()
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5))
+    ref = F.interpolate(x, scale_factor=tuple(float(f) for f in factors), mode="trilinear")
+    xd = x.to(DEV)
+    got = ops.upsample_trilinear(xd, factors)
+    assert got.shape == ref.shape and got.data_ptr() % 16 == 0
+    buf = torch.empty(ref.numel() + 4, device=DEV)
+    plain = buf[1:1 + ref.numel()]                              # 4 bytes off: the generic kernel
+    N, C, D, H, W = shape
+    hip.check(lib.emo_upsample_trilinear_f32(hip.ptr(xd), hip.ptr(plain), N * C, D, H, W, *factors, hip.current_stream()), "upsample")
+    assert torch.equal(got.flatten(), plain)
+    assert rel_err(got, ref) < 1e-6
+
+
 @pytest.mark.parametrize("kernel", [(2, 1, 1), (1, 2, 2), (2, 2, 2)])
 def test_avgpool3d(kernel):
     x = torch.randn(2, 3, 4, 6, 8, generator=torch.Generator().manual_seed(2))
