@@ -349,8 +349,9 @@ def supports_bf16x3(cout, cin, kd, kh, kw, precision="bf16x3"):
 
 
 def bf16x3_launch_fits(Hl, Wl, ups=False):
-    """output planes tiled by 4 x 64 positions, or (32-wide maps, no fused upsample) 8 x 32"""
-    return Hl is not None and ((Wl % 64 == 0 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0 and not ups))
+    """output planes tiled by 4 x 64 positions, or (32- / 16-wide maps, no fused upsample) 8 x 32 / 16 x 16"""
+    return Hl is not None and ((Wl % 64 == 0 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0 and not ups)
+                               or (Wl == 16 and Hl % 16 == 0 and not ups))
 
 
 F16_AFFINE_MAX_CIN = 1024   # ConvCfgH::SCT (conv_igemm_f16.h)

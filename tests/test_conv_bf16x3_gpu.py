@@ -28,6 +28,8 @@ CASES = [
     dict(N=2, Cin=128, Cout=64, dims=(16, 32, 32), k=3, cfg=3, affine=True, relu_in=True, res=True),   # 8 x 32 tiles, 3-D
     dict(N=1, Cin=24, Cout=120, dims=(8, 32), k=3, cfg=3, bias=False),                                 # 8 x 32, one tile per plane
     dict(N=6, Cin=64, Cout=320, dims=(64, 128), k=3, cfg=3, affine=True, relu_in=True),                # 960 tiles: persistent blocks
+    dict(N=2, Cin=64, Cout=128, dims=(6, 16, 16), k=3, cfg=3, affine=True, relu_in=True, res=True),    # 16 x 16 tiles, 3-D
+    dict(N=3, Cin=40, Cout=104, dims=(32, 16), k=3, cfg=3, affine=True, act="tanh"),                   # 16 x 16, two tiles per plane
 ]
 
 
@@ -78,13 +80,13 @@ def test_conv_bf16x3_is_as_close_to_fp64_as_the_fp32_kernel():
 
 
 def test_conv_bf16x3_layer_plan_and_tile_statistics():
-    """a layer built with precision='bf16x3' runs the split kernel where its 4 x 64 tile fits and the exact-fp32 kernel on
-    narrow maps; both write the GroupNorm tile statistics of what they stored"""
+    """a layer built with precision='bf16x3' runs the split kernel where one of its tiles (4 x 64, 8 x 32, 16 x 16) fits and the
+    exact-fp32 kernel on narrower maps; both write the GroupNorm tile statistics of what they stored"""
     g = torch.Generator().manual_seed(4)
     w = torch.randn(64, 32, 3, 3, generator=g) / 17
     layer = pack.PackedConv("l", w, None, DEV, precision="bf16x3")
-    assert layer.plan_for(64, 64, 64)[2] == "bf16x3" and layer.plan_for(2, 16, 16)[2] == "f32"
-    for hw in (64, 16):
+    assert layer.plan_for(64, 64, 64)[2] == "bf16x3" and layer.plan_for(2, 16, 16)[2] == "bf16x3" and layer.plan_for(1, 8, 8)[2] == "f32"
+    for hw in (64, 16, 8):
         x = torch.randn(2, 32, hw, hw, generator=g).to(DEV)
         out, st = ops.conv_igemm(x, layer, want_stats=True, ksplit=1)
         assert st is not None
