@@ -78,12 +78,6 @@ static __device__ unsigned long long emo_s_tlog[EMO_S_TLOG_N * EMO_S_TLOG_W];
 #ifndef EMO_S_CHAIN
 #define EMO_S_CHAIN 1   /* fp16 split: consecutive items of a persistent block run through one pipeline (0: A/B builds) */
 #endif
-#ifndef EMO_S_ACC_PLAIN
-#define EMO_S_ACC_PLAIN 0
-#endif
-#ifndef EMO_S_NOKILL
-#define EMO_S_NOKILL 0
-#endif
 #ifndef EMO_S_STAGGER
 #define EMO_S_STAGGER 0
 #endif
@@ -169,13 +163,9 @@ __device__ __forceinline__ float emo_row16_sum(float v) {
 // values and addresses are spilled to scratch, and every scratch reload (a vector-memory load as well) drags a vmcnt(0) in
 // front of the next store.  The caller is many instructions (a waitcnt, a barrier) behind the last MFMA.
 __device__ __forceinline__ float emo_acc_read(float acc_element) {
-#if EMO_S_ACC_PLAIN
-  return acc_element;
-#else
   float v;
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc_element));
   return v;
-#endif
 }
 
 // Tile statistics, second half (both epilogues below): the WGP waves' (mean, M2) of a channel combined with the equal-count update
@@ -842,7 +832,6 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   // (what no path below reads before writing it -- the fragment sets, the first raw patch buffer, the pixel under conversion --
   // is declared dead here: carried around the item loop as live values, the allocator kept second copies of ~100 registers in
   // accumulation registers, refreshed in every stage pair of the K loop)
-#if !EMO_S_NOKILL
 #pragma unroll
   for (int st_ = 0; st_ < 2; ++st_)
 #pragma unroll
@@ -857,7 +846,6 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
   asm volatile("" : "=v"(cv_h));
   asm volatile("" : "=v"(cv_m));
   if constexpr (SPLIT == 3) asm volatile("" : "=v"(cv_l));
-#endif
   if (CHAIN && chained_in) {
     // P[0] holds the converted patch of the first stage, W[0] its kernel rows, qv[1] the landed loads of the second stage, q_sc /
     // q_sh its first table entries (the state every stage leaves to the next); the tables are the sample's.  What is left:

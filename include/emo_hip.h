@@ -190,8 +190,8 @@ int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias
  * by v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-23 |x w| per product, below the fp32 accumulation error of either
  * kernel.  Same arguments, epilogue, K split and gn_stats as emo_conv_igemm_f32 (reference: torch.nn.Conv2d / Conv3d forward
  * of the decoder and WarpGenerator blocks, networks/volumetric_avatar/utils.py:854-1005, fp32).  3x3 (KD 1 or 3) kernels,
- * cfg 3 (64 x 256 tile = 4 x 64 pixels, or 8 x 32 on 32-wide maps without upsample; one block per CU); output
- * width % 64 == 0 and height % 4 == 0, or width 32 and height % 8 == 0; Cin % 8 == 0; x 16-byte
+ * cfg 3 (64 x 256 tile = 4 x 64 pixels, or 8 x 32 / 16 x 16 on 32- / 16-wide maps without upsample; one block per CU); output
+ * width % 64 == 0 and height % 4 == 0, or width 32 and height % 8 == 0, or width 16 and height % 16 == 0; Cin % 8 == 0; x 16-byte
  * aligned; Cin <= 1024 when scale / shift are given.  wpk3: bf16 weights packed
  * [co_tile][Cin chunk of 16][kd][kernel row][plane h|m|l][kernel column][half][BM = 64][8] (channel in chunk = 8*half + 0..7).
  * Operand range (tests/test_conv_bf16x3_gpu.py::test_conv_bf16x3_operand_contract): the split is exact for every finite staged

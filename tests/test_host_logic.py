@@ -357,3 +357,24 @@ def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect)
     convs = {k: v for k, v in stub.calls.items() if k.startswith("emo_conv_igemm")}
     assert convs == expect, convs
     assert sum(stub.calls.values()) == 95 + (30 if mode is None else 0), dict(stub.calls)
+
+
+def test_isa_audit_finds_a_scalar_operand_read_too_early_and_an_in_flight_destination():
+    """tools/kernel_resources.py --audit on synthetic listings: (1) a vector-ALU reload of a spilled scalar right in front of an
+    asm load that reads it (CDNA3: five wait states) is reported, the same with the wait states in between is not; (2) an
+    instruction that touches the destination of a pinned load before a vmcnt covers it is reported"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as K
+    bad = ["\tv_readlane_b32 s85, v253, 7", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]
+    good = ["\tv_readlane_b32 s85, v253, 7", "\t;;#ASMSTART", "\ts_nop 4", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]
+    other = ["\tv_readlane_b32 s80, v253, 7", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]
+    salu = ["\ts_mov_b32 s85, s3", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]   # SALU writes are interlocked
+    assert len(K.sgpr_hazards(bad)) == 1 and K.sgpr_hazards(bad)[0][2] == [85]
+    assert K.sgpr_hazards(good) == [] and K.sgpr_hazards(other) == [] and K.sgpr_hazards(salu) == []
+    rsrc = ["\tv_readfirstlane_b32 s73, v9", "\tv_add_u32_e32 v1, v2, v3", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]
+    assert len(K.sgpr_hazards(rsrc)) == 1                                  # (a register of the resource tuple, one wait state before)
+    loop = ["\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND",
+            "\tv_mov_b32_e32 v100, v47", "\ts_waitcnt vmcnt(0)", "\tv_mov_b32_e32 v101, v47",
+            "\tv_mfma_f32_32x32x16_f16 a[0:15], v[4:7], v[8:11], a[0:15]", "\ts_endpgm"]
+    hits = K.inflight_reads(loop)
+    assert len(hits) == 1 and "v100" in hits[0][1] and hits[0][2] == [47]
