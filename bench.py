@@ -615,10 +615,10 @@ def main():
                    "image_size": S, "frames_per_gpu_per_step": B,
                    "weights": ("seeded random, reference key layout" if a.raw_weights else
                                "seeded trained-like (spectral norms ~1, |uv delta| < ~1 voxel, unsaturated image), reference key layout"),
-                   "conv_arithmetic": {"bf16x3": "fp32 tensors and accumulation; 3x3 decoder convs: every fp32 operand split exactly "
+                   "conv_arithmetic": {"bf16x3": "fp32 tensors and accumulation; 3x3 / 3x3x3 convs of the decoder and the WarpGenerator that a 256-position tile of the split kernel fits: every fp32 operand split exactly "
                                                  "into 3 bf16 terms, 6 partial products on the bf16 matrix pipes (error vs fp64 <= "
                                                  "the fp32 MFMA kernel's, tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
-                                       "f16x2": "fp32 tensors and accumulation; 3x3 decoder convs: every scaled fp32 operand as two "
+                                       "f16x2": "fp32 tensors and accumulation; 3x3 / 3x3x3 convs of the decoder and the WarpGenerator that a 256-position tile of the split kernel fits: every scaled fp32 operand as two "
                                                 "fp16 terms (2^-24 relative), 3 partial products on the fp16 matrix pipes (error vs fp64 "
                                                 "1.1x the fp32 MFMA kernel's); the operand range is checked on the device by every "
                                                 "launch and a guarded bf16x3 launch recomputes a layer that left it "
