@@ -2,7 +2,9 @@
 a register the compiler spills while such a load is in flight would be silent corruption.  tools/kernel_resources.py --audit
 compiles every instantiation to ISA and checks that no scratch access lies between the first pinned load and the last MFMA,
 and that no instruction touches the destination of a pinned load which the listing's hand-counted vmcnt waits have not
-covered yet (the fp16-operand kernel keeps loads in flight across the stage boundary)."""
+covered yet (the fp16-operand kernel keeps loads in flight across the stage boundary); and that no vector-memory instruction
+of an asm statement reads a scalar register within five wait states of a vector-ALU write of it (the compiler reloads spilled
+scalars with v_readlane wherever it likes, and does not pad asm statements: round 4's A/B builds computed garbage that way)."""
 import os
 import subprocess
 import sys
@@ -16,6 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_no_scratch_access_while_pinned_loads_are_in_flight():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--audit"], capture_output=True,
                        text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 violations" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("EMO_SKIP_AUDIT") == "1", reason="needs hipcc")
+def test_the_measurement_build_of_the_split_kernel_passes_the_same_audit():
+    """an A/B / measurement build is a different register allocation of the same source (python -m emoportraits_amd.build
+    --variant x NAME=V  <->  --audit -DNAME=V): the unchained fp16 split is the one that exposed the scalar-register hazard"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--audit", "-DEMO_S_CHAIN=0"],
+                       capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 violations" in r.stdout
 
