@@ -14,3 +14,16 @@ static inline int emo_launch_status() {
 static inline bool emo_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 static inline int emo_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// compute units of the CURRENT device (the persistent grids of the split convolution are sized by it), cached per device id
+static inline int emo_cu_count() {
+  static int cached[64] = {0};     // (benign race: every writer stores the same value)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}

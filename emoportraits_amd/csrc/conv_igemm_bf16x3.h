@@ -1200,11 +1200,7 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   // persistent blocks (min(n_work, CUs)) by default: no workgroup launch between the items of a CU (kernel comment; measured
   // +2 % on the bench step, tools/session/r4_call12.sh); EMO_CONV_BF16X3_PERSISTENT=0 launches one block per item (A/B)
   static const int persistent = [] { const char* e = getenv("EMO_CONV_BF16X3_PERSISTENT"); return e ? atoi(e) : 1; }();
-  static const int ncu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int ncu = emo_cu_count();
   a.n_cotiles = cot;
   if (a.ksplit < 1 || (a.ksplit > 1 && !a.partial)) return EMO_ERR_BAD_ARG;
   if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }

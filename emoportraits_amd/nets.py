@@ -90,7 +90,8 @@ class ResBlock:
             out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, res_ups=True, want_stats=ws)
         elif self.skip is not None:
             r = ops.conv_igemm(x, self.skip, ups=ups)
-            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, out=r, want_stats=ws)
+            # (no out=r: the guarded recomputation of a range-checked layer reads the residual a second time)
+            out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=r, want_stats=ws)
         else:
             out = ops.conv_igemm(h, self.conv2, s2, h2, relu_in=True, res=x, res_ups=ups, want_stats=ws)
         ost = None

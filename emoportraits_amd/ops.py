@@ -253,6 +253,14 @@ class TileStats:
         self.stats, self.cnt = stats, cnt
 
 
+def _shares_storage(a, b):
+    """True when the two tensors overlap in memory (same allocation and intersecting byte ranges)"""
+    if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return False
+    a0, b0 = a.data_ptr(), b.data_ptr()
+    return a0 < b0 + b.numel() * b.element_size() and b0 < a0 + a.numel() * a.element_size()
+
+
 def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=None, res_ups=False, act="none",
                out=None, ksplit=None, want_stats=False):
     """layer: emoportraits_amd.pack.PackedConv.  x [N,Cin,H,W] or [N,Cin,D,H,W].
@@ -277,6 +285,8 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
     elif tuple(out.shape) != shape:
         raise ValueError("bad out shape")
+    elif _shares_storage(out, x):
+        raise ValueError("out overlaps x: tiles read their neighbours' input halo while others write")
     if res is not None:
         want = (N, layer.cout, D, Hl // 2, Wl // 2) if res_ups else (N, layer.cout, D, Hl, Wl)
         if res.numel() != want[0] * want[1] * want[2] * want[3] * want[4]:
@@ -302,6 +312,11 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         # the fp16 split checks its operand range on the device (overflow word of the layer); the guarded bf16x3 launch behind
         # it recomputes the layer with exact operands when the word is raised -- no host synchronisation, graph-capturable
         flag = pack_mod.overflow_flag_ptr(x.device, layer.flag_slot) if F16X2_GUARD else None
+        if F16X2_GUARD and res is not None and _shares_storage(out, res):
+            # the guarded launch re-reads res AFTER the first launch has written out: an output that aliases it (a residual
+            # updated in place) would feed the first launch's result into the recomputation -- conv + clipped conv + res
+            out = torch.empty(shape, device=x.device, dtype=torch.float32)
+            common = common[:4] + (hip.ptr(out),) + common[5:]
         rc = entry(hip.ptr(x), hip.ptr(wpk), *common, pack_mod.F16X2_IN_SCALE, layer.w_scale, flag)
         hip.check(rc, f"emo_conv_igemm_f16x2[{layer.name}]")
         if F16X2_GUARD:
@@ -315,7 +330,7 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
 
 
 # A/B switch (measurements only): 0 launches the fp16 split without its device-side range check and guarded recomputation
-F16X2_GUARD = __import__("os").environ.get("EMO_F16X2_GUARD", "1") != "0"
+F16X2_GUARD = pack_mod.F16X2_GUARD_DEFAULT
 clear_overflow_flags = pack_mod.clear_overflow_flags
 overflow_events = pack_mod.overflow_events
 

@@ -134,6 +134,7 @@ def pack_weight_bf16x3(w):
     return planes.view(-1)
 
 
+F16X2_GUARD_DEFAULT = __import__("os").environ.get("EMO_F16X2_GUARD", "1") != "0"   # ops.F16X2_GUARD starts from this
 F16X2_IN_SCALE = 32.0      # emo_conv_igemm_f16x2: the staged input is multiplied by this (inputs beyond +-2047 saturate)
 
 # Overflow flags of the fp16-split layers (include/emo_hip.h, emo_conv_igemm_f16x2): one int32 word per layer in a per-device
@@ -146,7 +147,10 @@ _flag_pools = {}     # device -> [int32 tensor, next free slot, {slot: layer nam
 
 def _flag_pool(device):
     import torch as _t
-    key = str(_t.device(device))
+    dev = _t.device(device)
+    if dev.type == "cuda" and dev.index is None:      # 'cuda' and 'cuda:<current>' are one pool (tensors report the indexed form)
+        dev = _t.device("cuda", _t.cuda.current_device())
+    key = str(dev)
     if key not in _flag_pools:
         _flag_pools[key] = [_t.zeros(_FLAG_POOL_WORDS, dtype=_t.int32, device=device), 0, {}]
     return _flag_pools[key]
@@ -400,7 +404,8 @@ class PackedConv:
         elif precision in ("bf16x3", "f16x2"):
             self.packed(CFG_D, precision)       # eager, like the fp32 layout: the first launch is not a host-side packing job
             if precision == "f16x2":            # the guarded exact recomputation behind a raised overflow flag (ops.conv_igemm)
-                self.packed(CFG_D, "bf16x3")
+                if F16X2_GUARD_DEFAULT:         # (EMO_F16X2_GUARD=0 builds never launch it: packed lazily if a caller turns
+                    self.packed(CFG_D, "bf16x3")    # the guard on later -- 1.5x the fp16 planes' memory otherwise)
                 self.flag_slot = overflow_flag_slot(device, name)
 
     def packed(self, cfg, precision="f32"):

@@ -74,7 +74,9 @@ def test_conv_bf16x3_is_as_close_to_fp64_as_the_fp32_kernel():
         outs[prec] = (err.mean().item() / scale, err.max().item() / scale)
     print("PARITY conv vs fp64 (rel mean, rel max): fp32 MFMA %.2e %.2e | bf16x3 %.2e %.2e | f16x2 %.2e %.2e"
           % (outs["f32"] + outs["bf16x3"] + outs["f16x2"]))
-    assert outs["f16x2"][0] <= 1.5 * outs["f32"][0] + 1e-8 and outs["f16x2"][1] <= 2.5 * outs["f32"][1] + 1e-7
+    # (the default mode: measured 1.09x the fp32 MFMA kernel's mean error; the bound is what the bench line advertises plus slack
+    # for the seed, not a factor a regression could hide in)
+    assert outs["f16x2"][0] <= 1.25 * outs["f32"][0] + 1e-8 and outs["f16x2"][1] <= 2.0 * outs["f32"][1] + 1e-7
     assert outs["bf16x3"][0] <= 1.1 * outs["f32"][0] + 1e-8        # mean error: no worse than the fp32 MFMA kernel
     assert outs["bf16x3"][1] <= 2.0 * outs["f32"][1] + 1e-7        # worst element of 1e6 (a tail statistic: factor 2)
 
@@ -188,6 +190,47 @@ def test_conv_f16x2_overflow_is_detected_and_recomputed(case):
     ops.clear_overflow_flags(DEV)
     again, _ = run(l2, x)
     assert torch.equal(again, in_range)
+
+
+@pytest.mark.parametrize("ksplit", [None, 3])
+def test_conv_f16x2_guarded_recomputation_with_the_residual_updated_in_place(ksplit):
+    """out aliases res (a residual updated in place, the form nets.ResBlock used for its convolved skip): the guarded bf16x3
+    launch reads the residual AFTER the fp16-split launch has written the output.  ops.conv_igemm must not hand the first
+    launch's result to the second as its residual (conv_exact + conv_clipped + res): bit-identical to a plain bf16x3 launch
+    with a separate output, whether the range check fires or not"""
+    g = torch.Generator().manual_seed(37)
+    N, Cin, Cout, H, W = 2, 48, 128, 16, 64
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    x = torch.randn(N, Cin, H, W, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    l2 = pack.PackedConv("alias", w, b, DEV, cfg=3, precision="f16x2")
+    l3 = pack.PackedConv("alias3", w, b, DEV, cfg=3, precision="bf16x3")
+    xa = x.clone()
+    xa[1, 7, 5, 33] = 5000.0
+    want = ops.conv_igemm(xa.to(DEV), l3, res=r.to(DEV), ksplit=ksplit).cpu()
+    ops.clear_overflow_flags(DEV)
+    rd = r.to(DEV)
+    got = ops.conv_igemm(xa.to(DEV), l2, res=rd, out=rd, ksplit=ksplit).cpu()
+    assert list(ops.overflow_events(DEV).values()) == ["alias"]
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):                               # (a convolution over its own input is never valid)
+        xd = xa.to(DEV)[:, :48].contiguous()
+        ops.conv_igemm(xd, pack.PackedConv("inplace", w[:48], None, DEV, cfg=3, precision="f16x2"), out=xd)
+    ops.clear_overflow_flags(DEV)
+
+
+def test_overflow_flag_pool_is_one_per_device_whatever_the_spelling():
+    """'cuda' and 'cuda:<current>' name the same pool (advisor, round 4: a HotPath built with device='cuda' cleared and
+    reported a pool the launches never wrote)"""
+    ops.clear_overflow_flags("cuda")
+    slot = pack.overflow_flag_slot("cuda", "spelling")
+    idx = torch.cuda.current_device()
+    assert pack._flag_pool("cuda") is pack._flag_pool(f"cuda:{idx}") is pack._flag_pool(torch.device("cuda", idx))
+    pack._flag_pool(f"cuda:{idx}")[0][slot] = 1
+    assert ops.overflow_events("cuda").get(slot) == "spelling"
+    ops.clear_overflow_flags("cuda")
+    assert ops.overflow_events(f"cuda:{idx}") == {}
 
 
 def test_conv_bf16x3_operand_contract():

@@ -373,6 +373,12 @@ def test_isa_audit_finds_a_scalar_operand_read_too_early_and_an_in_flight_destin
     assert K.sgpr_hazards(good) == [] and K.sgpr_hazards(other) == [] and K.sgpr_hazards(salu) == []
     rsrc = ["\tv_readfirstlane_b32 s73, v9", "\tv_add_u32_e32 v1, v2, v3", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]
     assert len(K.sgpr_hazards(rsrc)) == 1                                  # (a register of the resource tuple, one wait state before)
+    # any vector-ALU instruction with a scalar destination is a writer: the carry of v_add_co (second operand), a compare
+    carry = ["\tv_add_co_u32_e64 v4, s[84:85], v2, v3", "\t;;#ASMSTART", "\tglobal_load_lds_dwordx4 v9, s[84:85]", "\t;;#ASMEND"]
+    cmp_ = ["\tv_cmp_lt_u32_e64 s[72:73], v2, v3", "\ts_nop 1", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]
+    src_only = ["\tv_add_co_u32_e64 v4, s[10:11], s85, v3", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND"]
+    assert len(K.sgpr_hazards(carry)) == 1 and K.sgpr_hazards(carry)[0][2] == [84, 85]
+    assert len(K.sgpr_hazards(cmp_)) == 1 and K.sgpr_hazards(src_only) == []   # (a scalar SOURCE of a vector-ALU op is no write)
     loop = ["\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v2, s[72:75], s85 offen", "\t;;#ASMEND",
             "\tv_mov_b32_e32 v100, v47", "\ts_waitcnt vmcnt(0)", "\tv_mov_b32_e32 v101, v47",
             "\tv_mfma_f32_32x32x16_f16 a[0:15], v[4:7], v[8:11], a[0:15]", "\ts_endpgm"]

@@ -204,8 +204,19 @@ def sgpr_hazards(lines):
                 if used & regs and age < 5:
                     hits.append((i + 1, t, sorted(used & regs), age))
         recent = [(a + ws, r) for a, r in recent if a + ws < 8]
-        if re.match(r"v_readlane_b32|v_readfirstlane_b32|v_cmp", op):
-            recent.append((0, sregs(t.split()[1].rstrip(","))))
+        if op.startswith("v_"):
+            # ANY vector-ALU instruction with a scalar destination is a writer: lane reads and compares (first operand), and the
+            # carry / scale outputs of v_add_co / v_sub_co / v_addc_co / v_mad_u64 / v_div_scale (second operand; vcc has no number
+            # and is never the scalar operand of a pinned load)
+            ops_ = [o.strip() for o in t[len(op):].split(",")]
+            if re.match(r"v_readlane_b32|v_readfirstlane_b32|v_cmp", op):
+                w = sregs(ops_[0]) if ops_ else set()
+            elif re.search(r"_co_|v_mad_[ui]64_[ui]32|v_div_scale", op):
+                w = sregs(ops_[1]) if len(ops_) > 1 else set()
+            else:
+                w = set()
+            if w:
+                recent.append((0, w))
     return hits
 
 
@@ -241,7 +252,10 @@ def loop_scratch(src):
 if __name__ == "__main__":
     if sys.argv[1:2] == ["--audit"] and all(a.startswith("-D") for a in sys.argv[2:]):
         B.FLAGS = B.FLAGS + sys.argv[2:]          # (A/B builds: python -m emoportraits_amd.build --variant x NAME=V  <->  --audit -DNAME=V)
-        files = sorted(glob.glob(os.path.join(B.CSRC, "conv_inst_*.hip")))
+        # (the sampler's tile kernels fill LDS with global_load_lds off a scalar base as well: same hazard class, same scan;
+        # they have no MFMA, so only the scalar-operand rule applies to them)
+        files = sorted(glob.glob(os.path.join(B.CSRC, "conv_inst_*.hip")) + glob.glob(os.path.join(B.CSRC, "gs3d_tile_pad_*.hip"))
+                       + [os.path.join(B.CSRC, "grid_sample3d.hip")])
         with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
             res = list(ex.map(loop_scratch, files))
         bad = total = spilling = 0
