@@ -394,6 +394,115 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
     return out
 
 
+class StrongClip:
+    """BASELINE configs[3] / SURVEY.md section 8(e): ONE clip of `total` driver frames of one source identity, the unit a user
+    animates.  Per clip, in the timed region:
+        rank 0   source pass (LocalEncoder, VPN, xy WarpGenerator, 2 samplers, Unet3D) on the clip's source image
+        all      ONE flat broadcast of {canonical volume 25.2 MB, idt_embed, theta_src} (RCCL over xGMI; shapes known: no header)
+        rank r   its contiguous shard [lo, hi) of DISTINCT frames (parallel.shard_range) in batches of B: pose theta, driver pass,
+                 uint8 pack -- the full batches replayed from one hipGraph, a ragged tail batch from a second one -- and every
+                 batch's frames D2H into a ring of pinned buffers on a copy stream (the host waits only for a slot it reuses)
+    There is no data-path collective.  The frames' inputs (expression vectors, scale / rotation / translation) are resident in
+    HBM before the clock starts; the frames leave as uint8 in pinned host memory."""
+
+    def __init__(self, hp, cfg, dev, rank, world, total, B, S, seed, graph=True, ring=3):
+        self.hp, self.cfg, self.dev, self.rank, self.world, self.total, self.B, self.S = hp, cfg, dev, rank, world, total, B, S
+        c, d, s = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
+        self.shapes = dict(canonical=(1, c, d, s, s), idt_embed=(1, cfg["gen_max_channels"], 4, 4), theta_src=(1, 4, 4))
+        g = torch.Generator().manual_seed(seed + 7)
+        E = cfg["lpe_output_channels_expression"]
+        if rank == 0:
+            self.src = dict(img=torch.rand(1, 3, S, S, generator=g).to(dev), idt=torch.randn(1, cfg["gen_max_channels"], 4, 4, generator=g).to(dev),
+                            pose=torch.randn(1, E, generator=g).to(dev))
+            self.src["theta"] = ops.pose_theta(*[t.to(dev) for t in (1 + 0.05 * torch.randn(1, 3, generator=g),
+                                                                     0.3 * torch.randn(1, 3, generator=g), 0.05 * torch.randn(1, 3, generator=g))])
+        # every rank draws the WHOLE clip's inputs from the same seed and keeps its shard: distinct frames, no exchange
+        gf = torch.Generator().manual_seed(seed + 1000)
+        pose = torch.randn(total, E, generator=gf)
+        srt = (1 + 0.05 * torch.randn(total, 3, generator=gf), 0.3 * torch.randn(total, 3, generator=gf), 0.05 * torch.randn(total, 3, generator=gf))
+        self.lo, self.hi = parallel.shard_range(total, rank, world)
+        self.pose = pose[self.lo:self.hi].to(dev)
+        self.srt = [t[self.lo:self.hi].to(dev) for t in srt]
+        # static per-identity buffers the (graph-captured) step reads: overwritten by every clip's broadcast
+        self.ccl = torch.zeros((1, d, s, s, c), device=dev)
+        self.idt = torch.zeros(self.shapes["idt_embed"], device=dev)
+        self.ring = [torch.empty((B, S, S, 3), dtype=torch.uint8).pin_memory() for _ in range(ring)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.checksum = 0
+
+        def step_fn(pose_, s0, s1, s2):
+            return ops.pack_rgb8(hp.driver_pass(self.ccl, self.idt, pose_, ops.pose_theta(s0, s1, s2)))
+        self.step = graphs.Graphed(step_fn, warmup=1, clone_outputs=False) if graph else step_fn
+        # (the source pass is ~300 dependent launches for 13 ms of GPU time: replayed from a graph as well)
+        self.source = (graphs.Graphed(lambda *t: hp.source_pass(*t), warmup=1, clone_outputs=False) if graph else hp.source_pass) \
+            if rank == 0 else None
+
+    def run(self):
+        """one clip; returns the number of frames this rank delivered to the host"""
+        hp, dev = self.hp, self.dev
+        cache = {"canonical": None, "idt_embed": None, "theta_src": None}
+        if self.rank == 0:
+            canonical = self.source(self.src["img"], self.src["idt"], self.src["pose"], self.src["theta"])
+            cache = {"canonical": canonical, "idt_embed": self.src["idt"], "theta_src": self.src["theta"]}
+        cache = parallel.broadcast_source_cache(cache, self.shapes, src=0, device=dev, world=self.world, rank=self.rank,
+                                                names=list(self.shapes), exchange_shapes=False)
+        self.ccl.copy_(hp.prepare_canonical(cache["canonical"]))
+        self.idt.copy_(cache["idt_embed"])
+        events = [None] * len(self.ring)
+        done = 0
+        n = self.hi - self.lo
+        for k, b0 in enumerate(range(0, n, self.B)):
+            b1 = min(n, b0 + self.B)
+            u8 = self.step(self.pose[b0:b1], *[t[b0:b1] for t in self.srt]).clone()     # (the graph's static output is rewritten by the next replay)
+            ready = torch.cuda.Event()
+            ready.record()
+            slot = k % len(self.ring)
+            if events[slot] is not None:
+                events[slot].synchronize()               # the host has "consumed" the slot's previous batch
+                self.checksum += int(self.ring[slot][0, 0, 0, 0])
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(ready)
+                self.ring[slot][:b1 - b0].copy_(u8, non_blocking=True)
+                u8.record_stream(self.copy_stream)
+                ev = torch.cuda.Event()
+                ev.record()
+            events[slot] = ev
+            done += b1 - b0
+        for ev in events:
+            if ev is not None:
+                ev.synchronize()
+        return done
+
+
+def strong_scaling(hp, cfg, dev, rank, world, total, B, S, seed, clips, warm, graph):
+    """-> record of the strong-scaling measurement (rank 0) or None: `clips` timed clips behind `warm` untimed ones, barrier +
+    device synchronisation on both sides, MAX over ranks"""
+    if not hp.with_source and rank == 0:
+        raise SystemExit("the strong-scaling clip runs the source pass on rank 0: drop --no-source-pass")
+    clip = StrongClip(hp, cfg, dev, rank, world, total, B, S, seed, graph=graph)
+    for _ in range(warm):
+        clip.run()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    delivered = 0
+    for _ in range(clips):
+        delivered += clip.run()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    frames_all = parallel.sum_over_ranks(delivered, device=dev)
+    if frames_all != total * clips:
+        raise SystemExit(f"strong scaling: the ranks delivered {frames_all} frames, the clips hold {total * clips}")
+    if rank != 0:
+        return None
+    return {"scaling": "strong", "total_frames": total, "clips": clips, "warmup_clips": warm, "frames_per_s": round(total * clips / elapsed, 3),
+            "ms_per_clip": round(elapsed / clips * 1e3, 3), "n_gpus": world, "frames_per_rank": [parallel.shard_range(total, r, world)[1] -
+                                                                                               parallel.shard_range(total, r, world)[0] for r in range(world)],
+            "batch": B, "in_timed_region": "rank 0's source pass, one flat broadcast of its cache, every rank's contiguous shard of distinct "
+                                           "frames (pose theta, driver pass, uint8 pack; hipGraph replay per batch), uint8 D2H into a pinned ring"}
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` with N > 1 and no rendezvous environment: start N ranks ourselves (one process per GPU,
     RCCL backend) exactly as the driver would -- python -m torch.distributed.run on 127.0.0.1 -- and relay its output."""
@@ -425,6 +534,13 @@ def main():
     ap.add_argument("--raw-weights", action="store_true", help="plain seeded initialisation instead of the trained-like checkpoint")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (extras)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay of the step")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="STRONG scaling (BASELINE configs[3]): a step is one whole clip of this many driver frames of one identity, "
+                         "sharded contiguously over the ranks -- rank 0's source pass, the broadcast of its cache, every rank's shard "
+                         "in batches of --batch and the uint8 D2H ring all inside the timed region; the line says scaling: strong")
+    ap.add_argument("--strong-frames", type=int, default=512,
+                    help="weak-scaling runs also report one strong-scaling figure (strong_scaling in the line) on a clip of this "
+                         "many frames; 0 skips it")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -518,6 +634,11 @@ def main():
             sys.stderr.write(f"bench: hipGraph capture failed ({e!r}); timing eager launches\n")
             torch.cuda.synchronize()
 
+    strong = None
+    if a.total_frames:
+        # STRONG scaling is the headline of this invocation: a step = one clip (class StrongClip), K = --steps clips behind W =
+        # --warmup untimed ones; the weak-scaling step below is still run (briefly) for the per-kernel figures of the line
+        strong = strong_scaling(hp, cfg, dev, rank, world, a.total_frames, B, S, a.seed, a.steps, a.warmup, not a.no_graph)
     for _ in range(a.warmup):
         step()
     parallel.barrier()
@@ -528,6 +649,11 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    strong_extra = None
+    if not a.total_frames and a.strong_frames and not a.no_source_pass:
+        # one strong-scaling figure beside the weak headline (2 clips behind 1 untimed), so that a plain `--gpus N` sweep also
+        # yields the fixed-total-work curve of BASELINE configs[3]
+        strong_extra = strong_scaling(hp, cfg, dev, rank, world, a.strong_frames, B, S, a.seed, 2, 1, not a.no_graph)
 
     # the same K steps once more, launched eagerly with HIP events around every conv / sampler launch: the per-kernel figures.
     # An event interval is a kernel's duration only while the host is AHEAD of the GPU (otherwise it contains the wait for the
@@ -557,6 +683,11 @@ def main():
         return
     frames = world * B * a.steps
     fps = frames / elapsed
+    weak = {"scaling": "weak", "frames_per_s": round(fps, 3), "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "frames_per_gpu_per_step": B, "what": "the same step with the per-GPU batch fixed and the inputs replayed (source pass and "
+                                                  "broadcast outside the timed region)"}
+    if strong is not None:
+        fps, elapsed = strong["frames_per_s"], strong["ms_per_clip"] * 1e-3 * a.steps
     conv_ms = conv_meter.total_ms()
     samp_ms = samp_meter.total_ms()
     conv_tflops = conv_meter.flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -607,11 +738,15 @@ def main():
     rec = {
         "metric": "reenactment frames/sec @512x512, 1-src->N-driver" if S == 512 else f"reenactment frames/sec @{S}x{S}, 1-src->N-driver",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong is not None else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "dtype_note": f"tensors, norms, epilogue and accumulation fp32; conv operand form: {hp.precision} (config.conv_arithmetic)",
-        "config": {"workload": f"released stage-1 architecture R{S}, full HIP driver pass (pose theta, warp embed, uv WarpGenerator, "
-                               f"2x 3-D grid_sample, decoder, uint8 pack), 1 source identity, {B} driver frames per GPU per step",
+        "config": {"workload": (f"released stage-1 architecture R{S}, full HIP driver pass (pose theta, warp embed, uv WarpGenerator, "
+                                f"2x 3-D grid_sample, decoder, uint8 pack), 1 source identity, {B} driver frames per GPU per step"
+                                if strong is None else
+                                f"released stage-1 architecture R{S}: one clip of {a.total_frames} driver frames of one source identity per "
+                                f"step, sharded contiguously over {world} rank(s) -- source pass on rank 0, one broadcast of its cache, "
+                                f"full HIP driver pass in batches of {B}, uint8 frames D2H into a pinned ring, all inside the timed region"),
                    "image_size": S, "frames_per_gpu_per_step": B,
                    "weights": ("seeded random, reference key layout" if a.raw_weights else
                                "seeded trained-like (spectral norms ~1, |uv delta| < ~1 voxel, unsaturated image), reference key layout"),
@@ -636,6 +771,8 @@ def main():
                              "frac": round(samp_gbps / PEAK_HBM_GBPS, 4),
                              "avg_launch_ms": round(samp_ms / max(1, len(samp_meter.events)), 4)},
         "roofline_other_convs": {k: conv_roofline(k) for k in by_k if k != dom},
+        "strong_scaling": strong if strong is not None else strong_extra,
+        "weak_scaling": weak if strong is not None else None,
         "source_pass_ms": None if source_ms is None else round(source_ms, 2),
         "broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 3),   # one flat RCCL broadcast of the source cache, max over ranks
     }

@@ -144,6 +144,15 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def sum_over_ranks(value, device=None):
+    """SUM all-reduce of a python number (bench.py: frames delivered by all ranks)"""
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return type(value)(t.item())
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -1,4 +1,4 @@
-"""The PRODUCT path under world_size 2 (notebooks/infer.py:94-105 is how the reference initialises
+"""The PRODUCT path under world_size 2 and 8 (notebooks/infer.py:94-105 is how the reference initialises
 torch.distributed, it never shards frames): two freshly spawned processes -- on the one GPU of a test box through the gloo
 backend (EMO_FORCE_DEVICE=0, EMO_DIST_BACKEND=gloo; RCCL refuses two ranks per device), on two GPUs through RCCL -- each build
 an InferenceWrapper(num_gpus=2, use_graphs=True); rank 0 alone runs the source pass, both call share_source(), both run
@@ -143,3 +143,42 @@ def test_two_ranks_share_one_gpu_gloo(tmp_path, golden_dir):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_two_ranks_two_gpus_rccl(tmp_path, golden_dir):
     _check(2, tmp_path, golden_dir, share_gpu=False)
+
+
+def test_eight_ranks_share_one_gpu_gloo(tmp_path, golden_dir):
+    """world 8 with a frame count that 8 does not divide (33 = 5 + 7 x 4: ragged shards, a 1-frame tail batch on rank 0): eight
+    co-scheduled processes, each with its own packed weights, graphs and pinned ring"""
+    _check(8, tmp_path, golden_dir, share_gpu=True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 8, reason="needs eight GPUs")
+def test_eight_ranks_eight_gpus_rccl(tmp_path, golden_dir):
+    _check(8, tmp_path, golden_dir, share_gpu=False)
+
+
+def _bench_line(args, world, share_gpu=True):
+    import json
+    env = dict(os.environ)
+    for k in ("EMO_DIST_BACKEND", "EMO_FORCE_DEVICE", "EMO_DIST_FORCE_INIT", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if share_gpu and world > 1:
+        env.update(EMO_FORCE_DEVICE="0", EMO_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-cpu-baseline", "--no-extras"] + args,
+                       env=env, capture_output=True, text=True, timeout=1500)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_line_two_ranks():
+    """bench.py --total-frames (BASELINE configs[3]: a fixed clip, contiguous shards of DISTINCT frames, source pass + broadcast +
+    D2H inside the timed region) under 2 ranks on the one GPU of the box (gloo): a valid line that says scaling: strong; and the
+    weak-scaling form of the same launch carries the strong figure beside its headline.  R256 keeps the test short."""
+    rec = _bench_line(["--image-size", "256", "--batch", "4", "--steps", "2", "--warmup", "1", "--total-frames", "21"], 2)
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["unit"] == "frames/s"
+    st = rec["strong_scaling"]
+    assert st["total_frames"] == 21 and st["frames_per_rank"] == [11, 10] and st["clips"] == 2
+    assert abs(rec["value"] - st["frames_per_s"]) < 1e-6 and rec["value"] > 0
+    assert rec["weak_scaling"]["scaling"] == "weak" and rec["roofline"]["achieved"] > 0
+    rec = _bench_line(["--image-size", "256", "--batch", "4", "--steps", "2", "--warmup", "1", "--strong-frames", "13"], 2)
+    assert rec["scaling"] == "weak" and rec["strong_scaling"]["total_frames"] == 13 and rec["strong_scaling"]["frames_per_rank"] == [7, 6]
