@@ -146,7 +146,7 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   a.Dl = D; a.Hl = ups ? 2 * H : H; a.Wl = ups ? 2 * W : W;
   a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
   a.gn_stats = gn_stats;
-  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0;
+  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0; a.cot0 = 0;
   a.in_scale = in_scale; a.out_scale = 1.0f / (in_scale * w_scale);
   a.sat_flag = sat_flag; a.run_if = run_if;
   const int shape = shape_of_width(a.Wl);

@@ -349,7 +349,11 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, floatx16 (
 //                              statistics.
 // RES: 0 no residual, 1 residual of the output's size (16-byte aligned), 2 half-size residual, nearest x2 (8-byte aligned).
 // Arithmetic per element identical to conv_epilogue_rows (same operations in the same order): the two are bit-identical.
-template <int TW, int TP, int BM, int RES, int I>
+// LAUNDER (conv_igemm_f16x2_ct2.h): the volume sizes pass through an empty asm statement, so that the 32 per-lane offsets
+// (channel * volume + position) they enter are computed where they are used.  Left visible, the compiler hoists them out of the
+// item loop as loop invariants; a kernel whose accumulators fill all 256 accumulation registers has nowhere to keep them but
+// scratch, and reloaded each one in the epilogue behind a vmcnt(0) of its own (seen in the ISA: 44 serialised scratch loads per item).
+template <int TW, int TP, int BM, int RES, int I, bool LAUNDER = false>
 __device__ __forceinline__ void conv_epilogue_fast_issue(const ConvArgs& a, floatx4 (&rv)[8], int n, int cotile, int x0, int y0,
                                                          int z0, int wp, int lane) {
   if constexpr (RES != 0) {
@@ -357,7 +361,8 @@ __device__ __forceinline__ void conv_epilogue_fast_issue(const ConvArgs& a, floa
     const int p = wp * (TP * 32) + 4 * t;
     const int y = y0 + p / TW, x = x0 + p % TW;
     const unsigned Hr = RES == 2 ? a.Hl >> 1 : a.Hl, Wr = RES == 2 ? a.Wl >> 1 : a.Wl;
-    const unsigned rvol = (unsigned)a.Dl * Hr * Wr;
+    unsigned rvol = (unsigned)a.Dl * Hr * Wr;
+    if constexpr (LAUNDER) asm volatile("" : "+s"(rvol));
     const unsigned rsp = RES == 2 ? ((unsigned)z0 * Hr + (y >> 1)) * Wr + (x >> 1) : ((unsigned)z0 * Hr + y) * Wr + x;
     const float* rbase = a.res + ((long)n * a.Cout + (long)cotile * BM) * rvol;      // wave-uniform
     const unsigned roff = (unsigned)g * rvol + rsp;
@@ -370,7 +375,7 @@ __device__ __forceinline__ void conv_epilogue_fast_issue(const ConvArgs& a, floa
   }
 }
 
-template <int TW, int TM, int TP, int WGP, int BM, int SPLIT, int ROWF, int RES>
+template <int TW, int TM, int TP, int WGP, int BM, int SPLIT, int ROWF, int RES, bool LAUNDER = false>
 __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, floatx16 (&acc_lo)[TM][TP], floatx16 (&acc_hi)[TM][TP],
                                                           floatx4 (&rv0)[8], float* scratch, const float* sbias,
                                                           float* st_lds, int n, int cotile, int ptile, int x0, int y0, int z0, int wp,
@@ -379,7 +384,9 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
   constexpr int NIT = 8;
   const int g = lane >> 4, t = lane & 15;
   const bool want_stats = a.gn_stats != nullptr;
-  const unsigned plane = (unsigned)a.Hl * a.Wl, ovol = (unsigned)a.Dl * plane;
+  const unsigned plane = (unsigned)a.Hl * a.Wl;
+  unsigned ovol = (unsigned)a.Dl * plane;
+  if constexpr (LAUNDER) asm volatile("" : "+s"(ovol));
   const int p = wp * (TP * 32) + 4 * t;
   const int y = y0 + p / TW, x = x0 + p % TW;
   float* const obase = a.out + ((long)n * a.Cout + (long)cotile * BM) * ovol;          // wave-uniform
@@ -403,7 +410,7 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
       }
     // the second half's residual: issued now, into the registers the first half's accumulators have just left (with all 16
     // loads in flight from the start the compiler spills the landed values to scratch and waits vmcnt(0) before every store)
-    if (i == 0) conv_epilogue_fast_issue<TW, TP, BM, RES, 1>(a, rv1, n, cotile, x0, y0, z0, wp, lane);
+    if (i == 0) conv_epilogue_fast_issue<TW, TP, BM, RES, 1, LAUNDER>(a, rv1, n, cotile, x0, y0, z0, wp, lane);
     floatx4 (&rv)[8] = i == 0 ? rv0 : rv1;
     floatx4 v[NIT];
 #pragma unroll
@@ -556,7 +563,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
     P_##ptile = __builtin_amdgcn_readfirstlane(bx_);                                                  \
     const int tx_ = bx_ % a.tiles_x; bx_ /= a.tiles_x;                                                \
     const int ty_ = bx_ % a.tiles_y; bx_ /= a.tiles_y;                                                \
-    P_##cotile = __builtin_amdgcn_readfirstlane(cot_);                                                \
+    P_##cotile = __builtin_amdgcn_readfirstlane(cot_ + a.cot0);                                       \
     P_##ks = __builtin_amdgcn_readfirstlane(ks_);                                                     \
     P_##n = __builtin_amdgcn_readfirstlane(n_);                                                       \
     P_##x0 = __builtin_amdgcn_readfirstlane(tx_ * TW);                                                \
@@ -1201,12 +1208,13 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   // +2 % on the bench step, tools/session/r4_call12.sh); EMO_CONV_BF16X3_PERSISTENT=0 launches one block per item (A/B)
   static const int persistent = [] { const char* e = getenv("EMO_CONV_BF16X3_PERSISTENT"); return e ? atoi(e) : 1; }();
   const int ncu = emo_cu_count();
-  a.n_cotiles = cot;
+  if (a.cot0 < 0 || a.cot0 >= cot) return EMO_ERR_BAD_ARG;
+  a.n_cotiles = cot - a.cot0;                  // (cot0 > 0: the odd last tile behind conv_f16x2_ct2_launch's pairs)
   if (a.ksplit < 1 || (a.ksplit > 1 && !a.partial)) return EMO_ERR_BAD_ARG;
   if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }
   if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
-  if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  a.n_work = (int)(nt * cot * a.N * a.ksplit);
+  if (nt * a.n_cotiles * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  a.n_work = (int)(nt * a.n_cotiles * a.N * a.ksplit);
   // (a guarded fallback launch is normally skipped: min(n_work, CUs) blocks read the flag and leave instead of n_work)
   const int grid = (persistent || a.run_if != nullptr) && a.n_work > ncu ? ncu : a.n_work;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)Cfg::LDS_BYTES, s, a);

@@ -68,12 +68,11 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
   const int HW = a.H * a.W;
   const long DHW = (long)a.D * HW;
   const bool has_affine = a.scale != nullptr;
-  const int epi_mode = __builtin_amdgcn_readfirstlane(
-      (a.partial != nullptr || a.act != EMO_ACT_NONE || a.Cout % BM != 0 || (a.Wl & 3) != 0 ||
-       (long)a.Dl * a.Hl * a.Wl > (1l << 23) || (reinterpret_cast<unsigned long long>(a.out) & 15ull) != 0) ? -1
-      : a.res == nullptr ? 0
-      : !a.res_ups ? ((reinterpret_cast<unsigned long long>(a.res) & 15ull) == 0 ? 1 : -1)
-      : ((reinterpret_cast<unsigned long long>(a.res) & 7ull) == 0 ? 2 : -1));
+  // epilogue form: the straight-line one without / with a same-size / with a half-size residual (conv_ct2_epilogue_form() on the
+  // host: a launch whose output needs the general epilogue -- activation, ragged channel tile, unaligned tensors -- never gets here;
+  // with the general form inlined twice the register allocator, which has no free accumulation registers to park values in,
+  // spilled 250 values to scratch around every item)
+  const int epi_mode = __builtin_amdgcn_readfirstlane(a.res == nullptr ? 0 : (a.res_ups ? 2 : 1));
   const float in_scale = a.in_scale;
   const int padD = a.KD >> 1;
   constexpr float CLAMP_HI = 65504.0f;
@@ -476,8 +475,8 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
 #define EMO_T_EPI_FAST(RES_, h_)                                                                                                  \
     {                                                                                                                              \
       floatx4 rv_[8];                                                                                                              \
-      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0>(a, rv_, ep_n, ep_cotile + (h_), ep_x0, ep_y0, ep_z0, wp, lane);               \
-      conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_>(                                                  \
+      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0, true>(a, rv_, ep_n, ep_cotile + (h_), ep_x0, ep_y0, ep_z0, wp, lane);         \
+      conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_, true>(                                            \
           a, acc_lo[h_], acc_hi[h_], rv_, scratch, smem + ((h_) ? Cfg::OFF_BIAS2_F : Cfg::OFF_BIAS_F),                             \
           smem + ((h_) ? Cfg::OFF_STAT2_F : Cfg::OFF_STAT_F), ep_n, ep_cotile + (h_), ep_ptile, ep_x0, ep_y0, ep_z0, wp, half,     \
           l32, lane, tid);                                                                                                         \
@@ -486,12 +485,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     for (int h = 0; h < 2; ++h) {
       if (epi_mode == 1) EMO_T_EPI_FAST(1, h)
       else if (epi_mode == 2) EMO_T_EPI_FAST(2, h)
-      else if (epi_mode == 0) EMO_T_EPI_FAST(0, h)
-      else
-        conv_epilogue_rows<TR, TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF>(
-            a, acc_lo[h], acc_hi[h], scratch, smem + (h ? Cfg::OFF_BIAS2_F : Cfg::OFF_BIAS_F),
-            smem + (h ? Cfg::OFF_STAT2_F : Cfg::OFF_STAT_F), ep_n, ep_cotile + h, ep_ptile, 0, ep_x0, ep_y0, ep_z0, wp, half, l32,
-            lane, tid);
+      else EMO_T_EPI_FAST(0, h)
     }
 #undef EMO_T_EPI_FAST
   }
@@ -523,8 +517,15 @@ template <int TR, int TW, bool UPS>
 int conv_f16x2_ct2_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   using Cfg = ConvCfgS2<TR, TW, UPS>;
   *rest_cot0 = 0;
-  static const int enabled = [] { const char* e = getenv("EMO_CONV_CT2"); return e ? atoi(e) : 1; }();
-  if (!enabled || a.ksplit != 1 || a.run_if != nullptr) return EMO_OK;
+  // (read at every launch: tests and A/B runs toggle them inside one process; a launch is microseconds)
+  const char* const e_on = getenv("EMO_CONV_CT2");
+  const char* const e_min = getenv("EMO_CONV_CT2_MIN_ITEMS");
+  if ((e_on && atoi(e_on) == 0) || a.ksplit != 1 || a.run_if != nullptr) return EMO_OK;
+  // the straight-line epilogue forms only (conv_igemm_bf16x3.h, epi_mode): final output, no activation, whole 64-channel tiles,
+  // 16-byte aligned output, 16- / 8-byte aligned same-size / half-size residual, offsets inside 2^31 bytes per sample
+  if (a.act != EMO_ACT_NONE || a.Cout % Cfg::BM != 0 || (a.Wl & 3) != 0 || (long)a.Dl * a.Hl * a.Wl > (1l << 23) ||
+      (reinterpret_cast<unsigned long long>(a.out) & 15ull) != 0 ||
+      (a.res != nullptr && (reinterpret_cast<unsigned long long>(a.res) & (a.res_ups ? 7ull : 15ull)) != 0)) return EMO_OK;
   if (a.Wl % TW || a.Hl % TR || a.Cin % 8) return EMO_OK;                 // (the single-tile launcher reports what is unsupported)
   if (a.scale && a.Cin > Cfg::SCT) return EMO_OK;
   if ((unsigned long long)a.Cin * a.D * a.H * a.W * 4ull >= (1ull << 32)) return EMO_OK;
@@ -534,7 +535,8 @@ int conv_f16x2_ct2_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   const long nt = (long)(a.Wl / TW) * (a.Hl / TR) * a.Dl;
   const int ncu = emo_cu_count();
   // enough pair items for two per CU: below that the single-tile kernel's twice as many, half as long items balance better
-  if (pairs < 1 || nt > 0x7fffffffL || a.N > 65535 || nt * pairs * a.N > 0x7fffffffL || nt * pairs * a.N < 2l * ncu) return EMO_OK;
+  const long min_items = e_min ? atol(e_min) : 2l * ncu;
+  if (pairs < 1 || nt > 0x7fffffffL || a.N > 65535 || nt * pairs * a.N > 0x7fffffffL || nt * pairs * a.N < min_items) return EMO_OK;
   auto kern = conv_igemm_bf16x3_ct2_kernel<TR, TW, UPS>;
   const int rc = emo_raise_dynamic_lds(kern);
   if (rc != EMO_OK) return rc;

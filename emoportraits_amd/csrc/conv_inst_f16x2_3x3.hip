@@ -2,8 +2,20 @@
 // accumulation: opt-in, emo_conv_igemm_f16x2): 3x3 taps, 64 x 256 tiles of 4 x 64, 8 x 32 or 16 x 16 pixels
 #include "conv_dispatch.h"
 #include "conv_igemm_bf16x3.h"
+int conv_f16x2_ct2_4x64(ConvArgs, hipStream_t, int ups, int* rest_cot0);    // conv_inst_f16x2_ct2.hip
+// 4 x 64 tiles: the layer's channel-tile pairs on the two-tile kernel where that fills the chip, the rest (an odd last tile, or
+// everything) on the single-tile one
+template <bool UPS>
+static int conv_f16x2_4x64(ConvArgs a, hipStream_t s) {
+  int rest = 0;
+  const int rc = conv_f16x2_ct2_4x64(a, s, UPS, &rest);
+  if (rc != EMO_OK) return rc;
+  if (rest * ConvCfgS<4, 64, UPS, 2>::BM >= a.Cout) return EMO_OK;
+  a.cot0 = rest;
+  return conv_igemm_bf16x3_launch<4, 64, UPS, 2>(a, s);
+}
 conv_launch_fn conv_lookup_f16x2_3x3(int Wl, int ups) {
-  if (Wl % 64 == 0) return ups ? &conv_igemm_bf16x3_launch<4, 64, true, 2> : &conv_igemm_bf16x3_launch<4, 64, false, 2>;
+  if (Wl % 64 == 0) return ups ? &conv_f16x2_4x64<true> : &conv_f16x2_4x64<false>;
   if (Wl == 32 && !ups) return &conv_igemm_bf16x3_launch<8, 32, false, 2>;
   if (Wl == 16 && !ups) return &conv_igemm_bf16x3_launch<16, 16, false, 2>;     // (the 16-wide 3-D maps of the WarpGenerator)
   return nullptr;

@@ -192,6 +192,75 @@ def test_conv_f16x2_overflow_is_detected_and_recomputed(case):
     assert torch.equal(again, in_range)
 
 
+# the two-tile kernel (csrc/conv_igemm_f16x2_ct2.h: two 64-channel output tiles per work item on one converted patch).  It takes a
+# layer's channel-tile PAIRS when there are two items per CU; EMO_CONV_CT2_MIN_ITEMS=1 makes every eligible launch take it, so
+# that small shapes exercise it too.  Cases: one pair; pairs + an odd last tile (192, 320 channels: the single-tile kernel runs
+# that tile with cot0 set); one-stage and two-stage items; many items per block on a few samples (chained items, chains broken
+# at sample boundaries); every residual form; the fused upsample; depth taps as stages
+CT2_CASES = [
+    dict(N=1, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=3, affine=True, relu_in=True, res=True),
+    dict(N=2, Cin=48, Cout=192, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True),
+    dict(N=3, Cin=64, Cout=320, dims=(32, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),
+    dict(N=2, Cin=16, Cout=128, dims=(16, 64), k=3, cfg=3, bias=False),                                # one stage per item
+    dict(N=2, Cin=32, Cout=256, dims=(8, 64), k=3, cfg=3, affine=True, relu_in=True),                 # two stages
+    dict(N=2, Cin=40, Cout=128, dims=(64, 128), k=3, cfg=3, affine=True, relu_in=True, res=True),     # ragged channel group
+    dict(N=2, Cin=64, Cout=192, dims=(32, 32), k=3, cfg=3, ups=True, affine=True, relu_in=True, res=True, res_ups=True),
+    dict(N=1, Cin=96, Cout=128, dims=(64, 64), k=3, cfg=3, ups=True, affine=True, relu_in=True),
+    dict(N=1, Cin=24, Cout=128, dims=(6, 64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),   # 3-D: depth taps as stages
+    dict(N=5, Cin=64, Cout=128, dims=(128, 128), k=3, cfg=3, affine=True, relu_in=True),              # 1280 items: chains
+]
+
+
+@pytest.mark.parametrize("case", CT2_CASES)
+def test_conv_f16x2_two_tile_kernel_is_bit_identical_to_the_single_tile_kernel(case, monkeypatch):
+    """same products in the same order into the same accumulator sets: the pair kernel and the single-tile kernel must agree bit
+    for bit, output and GroupNorm tile statistics; and the fp32 bound against torch CPU holds"""
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    monkeypatch.setenv("EMO_CONV_CT2", "1")
+    e, got, ref = run_conv(seed=27, precision="f16x2", **case)
+    print("PARITY conv f16x2 two-tile kernel:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    assert e < 2e-5, e
+    e2, got2, _ = run_conv(seed=27, precision="f16x2", **case)
+    assert torch.equal(got, got2), "two launches on the same input differ: a race in the pipeline"
+    monkeypatch.setenv("EMO_CONV_CT2", "0")
+    e1, single, _ = run_conv(seed=27, precision="f16x2", **case)
+    assert torch.equal(got, single), (got - single).abs().max().item()
+
+
+def test_conv_f16x2_two_tile_kernel_statistics_and_range_check(monkeypatch):
+    """tile statistics written by the pair kernel equal the single-tile kernel's bit for bit; an out-of-range input raises the
+    layer's overflow word from the pair kernel as well, and the guarded bf16x3 launch rewrites the whole layer"""
+    g = torch.Generator().manual_seed(33)
+    N, Cin, Cout, H, W = 2, 48, 192, 32, 64
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(N, Cin, generator=g) * 0.2).to(DEV)
+    l2 = pack.PackedConv("ct2", w, b, DEV, cfg=3, precision="f16x2")
+    l3 = pack.PackedConv("ct2_3", w, b, DEV, cfg=3, precision="bf16x3")
+
+    def run(layer, xin):
+        out, st = ops.conv_igemm(xin.to(DEV), layer, sc, sh, relu_in=True, want_stats=True)
+        return out.cpu(), st.stats.cpu()
+
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    ops.clear_overflow_flags(DEV)
+    monkeypatch.setenv("EMO_CONV_CT2", "0")
+    o1, s1 = run(l2, x)
+    monkeypatch.setenv("EMO_CONV_CT2", "1")
+    o2, s2 = run(l2, x)
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+    assert ops.overflow_events(DEV) == {}
+    xa = x.clone()
+    xa[1, 7, 5, 33] = 5000.0
+    got, sg = run(l2, xa)
+    assert list(ops.overflow_events(DEV).values()) == ["ct2"]
+    want, sw = run(l3, xa)
+    assert torch.equal(got, want) and torch.equal(sg, sw)
+    ops.clear_overflow_flags(DEV)
+
+
 @pytest.mark.parametrize("ksplit", [None, 3])
 def test_conv_f16x2_guarded_recomputation_with_the_residual_updated_in_place(ksplit):
     """out aliases res (a residual updated in place, the form nets.ResBlock used for its convolved skip): the guarded bf16x3
