@@ -52,6 +52,7 @@
 #include "conv_igemm_f16.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 #ifndef EMO_S_PIN
 #define EMO_S_PIN 1   /* 0: A/B switch -- the compiler schedules the inside of a step on its own */
@@ -400,13 +401,19 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
     for (int j = 0; j < TP; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        floatx4 c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sum = emo_acc_read(acc_lo[i][j][4 * q + e]) + emo_acc_read(acc_hi[i][j][4 * q + e]);
-          c[e] = SPLIT == 3 ? sum : sum * a.out_scale;
+        // (two values per instruction -- v_pk_add_f32 / v_pk_mul_f32: behind the K loop there is no MFMA stream to disturb, and
+        // the epilogue is bound by its instruction count; per element the operations and their order are those of
+        // conv_epilogue_rows)
+        floatx2 c01 = floatx2{emo_acc_read(acc_lo[i][j][4 * q + 0]), emo_acc_read(acc_lo[i][j][4 * q + 1])} +
+                      floatx2{emo_acc_read(acc_hi[i][j][4 * q + 0]), emo_acc_read(acc_hi[i][j][4 * q + 1])};
+        floatx2 c23 = floatx2{emo_acc_read(acc_lo[i][j][4 * q + 2]), emo_acc_read(acc_lo[i][j][4 * q + 3])} +
+                      floatx2{emo_acc_read(acc_hi[i][j][4 * q + 2]), emo_acc_read(acc_hi[i][j][4 * q + 3])};
+        if constexpr (SPLIT != 3) {
+          const floatx2 sc2 = floatx2{a.out_scale, a.out_scale};
+          c01 = c01 * sc2;
+          c23 = c23 * sc2;
         }
-        *reinterpret_cast<floatx4*>(scratch + l32 * ROWF + j * 32 + 8 * q + 4 * half) = c;
+        *reinterpret_cast<floatx4*>(scratch + l32 * ROWF + j * 32 + 8 * q + 4 * half) = floatx4{c01[0], c01[1], c23[0], c23[1]};
       }
     // the second half's residual: issued now, into the registers the first half's accumulators have just left (with all 16
     // loads in flight from the start the compiler spills the landed values to scratch and waits vmcnt(0) before every store)
@@ -420,13 +427,11 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const float bs = it < 4 ? b0[it & 3] : b1[it & 3];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float u = v[it][e] + bs;
-        if constexpr (RES == 1) u += rv[it][e];
-        if constexpr (RES == 2) u += rv[it][e >> 1];
-        v[it][e] = u;
-      }
+      const floatx2 bs2 = floatx2{bs, bs};
+      floatx2 u01 = floatx2{v[it][0], v[it][1]} + bs2, u23 = floatx2{v[it][2], v[it][3]} + bs2;
+      if constexpr (RES == 1) { u01 = u01 + floatx2{rv[it][0], rv[it][1]}; u23 = u23 + floatx2{rv[it][2], rv[it][3]}; }
+      if constexpr (RES == 2) { u01 = u01 + floatx2{rv[it][0], rv[it][0]}; u23 = u23 + floatx2{rv[it][1], rv[it][1]}; }
+      v[it] = floatx4{u01[0], u01[1], u23[0], u23[1]};
       float* const op = obase + (off + (unsigned)(i * 32 + 4 * it) * ovol);
       if (EMO_CONV_NT_STORE) __builtin_nontemporal_store(v[it], reinterpret_cast<floatx4*>(op));
       else *reinterpret_cast<floatx4*>(op) = v[it];
@@ -435,11 +440,16 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
       constexpr float inv_cnt = 1.0f / (float)(TP * 32);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const float s4 = (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+        const floatx2 p2 = floatx2{v[it][0], v[it][2]} + floatx2{v[it][1], v[it][3]};      // (v0 + v1, v2 + v3)
+        const float s4 = p2[0] + p2[1];
         const float mean = emo_row16_sum(s4) * inv_cnt;
+        const floatx2 mean2 = floatx2{mean, mean};
+        const floatx2 d01 = floatx2{v[it][0], v[it][1]} - mean2, d23 = floatx2{v[it][2], v[it][3]} - mean2;
         float m2 = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = v[it][e] - mean; m2 = __fmaf_rn(d, d, m2); }
+        m2 = __fmaf_rn(d01[0], d01[0], m2);
+        m2 = __fmaf_rn(d01[1], d01[1], m2);
+        m2 = __fmaf_rn(d23[0], d23[0], m2);
+        m2 = __fmaf_rn(d23[1], d23[1], m2);
         m2 = emo_row16_sum(m2);
         if (t == 0) *reinterpret_cast<float2*>(st_lds + (wp * BM + i * 32 + 4 * it + g) * 2) = make_float2(mean, m2);
       }

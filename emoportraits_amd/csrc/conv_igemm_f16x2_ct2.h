@@ -253,6 +253,11 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
   bool chained_in = false;                 // this item's first stage (and its second patch) were staged by the previous item
   int pp = 0;                              // patch buffer of the item's current stage
   for (int idx8 = blockIdx.x >> 3; idx8 < n_mine; idx8 += l_stride) {
+#if EMO_S_TIMING
+  unsigned long long tstamp[12];     // measurement builds (tools/conv_phase_timing.py): s_memtime of wave 0 at the phase boundaries
+  for (int k = 0; k < 12; ++k) tstamp[k] = 0;
+#endif
+  EMO_S_STAMP(0)
   EMO_T_DECODE(it_, l_base + idx8)
   int nx_cotile = 0, nx_n = 0, nx_ptile = 0, nx_x0 = 0, nx_y0 = 0, nx_z0 = 0;
   bool chain_out = false, nxq_ok = false;
@@ -355,6 +360,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
   }
 
   // ---- K loop: one stage = two half-stages (header comment) ----
+  EMO_S_STAMP(1)
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -462,12 +468,16 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     }
     pp ^= 1;
   }
+  EMO_S_STAMP(2)
   {
     // ---- epilogue, once per channel tile of the pair; the transposition scratch is W[1] ----
     float* const scratch = smem + (Cfg::OFF_W + Cfg::WSTAGE) * 4 + wave * Cfg::EPI_WAVE;
     const int ep_n = it_n, ep_cotile = it_cotile, ep_ptile = it_ptile, ep_x0 = it_x0, ep_y0 = it_y0, ep_z0 = it_z0;
     EMO_T_WAIT(0);
+    EMO_S_STAMP(5)
     __syncthreads();
+    EMO_S_STAMP(6)
+    EMO_S_STAMP(7)
     if (EMO_S_CHAIN && chain_out && tid < 2 * BM && a.bias != nullptr) {   // the next item's bias entries
       const int co_ = nx_cotile * BM + tid;
       te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];
@@ -479,17 +489,34 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
       conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_, true>(                                            \
           a, acc_lo[h_], acc_hi[h_], rv_, scratch, smem + ((h_) ? Cfg::OFF_BIAS2_F : Cfg::OFF_BIAS_F),                             \
           smem + ((h_) ? Cfg::OFF_STAT2_F : Cfg::OFF_STAT_F), ep_n, ep_cotile + (h_), ep_ptile, ep_x0, ep_y0, ep_z0, wp, half,     \
-          l32, lane, tid);                                                                                                         \
+          l32, lane, tid EMO_S_TSTAMP_ARG);                                                                                        \
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (epi_mode == 1) EMO_T_EPI_FAST(1, h)
       else if (epi_mode == 2) EMO_T_EPI_FAST(2, h)
       else EMO_T_EPI_FAST(0, h)
+      if (h == 0) { EMO_S_STAMP(8) } else { EMO_S_STAMP(9) }       // (measurement builds: first / second channel tile written)
     }
 #undef EMO_T_EPI_FAST
   }
   if (a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
+#if EMO_S_TIMING
+  EMO_S_STAMP(3)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  EMO_S_STAMP(4)
+  {
+    const int ep_L_ = l_base + idx8;
+    if (tid == 0 && ep_L_ < EMO_S_TLOG_N) {
+      unsigned long long* t_ = emo_s_tlog + (long)ep_L_ * EMO_S_TLOG_W;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) t_[k] = tstamp[k];
+      t_[12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+      t_[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+      t_[14] = (unsigned long long)blockIdx.x;
+    }
+  }
+#endif
   // the next prologue overwrites the tables, the statistics exchange and W[1]: every wave must be out of the epilogue first
   __syncthreads();
   chained_in = chain_out;
