@@ -305,30 +305,52 @@ def extras(cfg, sd, hp, ccl, idt, pose, srt, dev, S):
         out["stage1_f16_operands_fps"] = round(B / t, 2)
         del hp16
     del s2
-    # BASELINE configs[1]: "256x256 1-src -> 64-driver batch, HIP 3-D grid_sample only": the two sampler calls of the driver pass
-    # (uv warp of the shared canonical volume, then the head-pose rotation; latent volume [96, 16, 64, 64] at R256 as at R512)
-    # on 64 frames, algorithmic bytes of SURVEY.md section 8(d) / time
+    # BASELINE configs[1] / SURVEY.md section 8(d) "Config 2": 64 drivers sharing one canonical volume randn(1,96,16,64,64) (seed 1);
+    # uv call: identity lattice + 0.05 * tanh(randn) (seed 2); rotation call: analytic theta, yaw / pitch / roll ~ U(-0.3, 0.3),
+    # scale ~ U(0.9, 1.1), translation ~ U(-0.05, 0.05) (seed 3); BOTH padding modes.  Algorithmic bytes of section 8(d) / time.
+    # And the reference-layout operator seam (va.py:264-265: Model.grid_sample(NCDHW volume, explicit grid) -> NCDHW) on the same
+    # 64 samples, each with a volume of its own, as a drop-in user who only swaps that attribute gets it
     try:
         c_, d_, s_ = cfg["latent_volume_channels"], cfg["latent_volume_depth"], cfg["latent_volume_size"]
-        gs_ = torch.Generator().manual_seed(15)
         N64 = 64
-        delta64 = (torch.tanh(torch.randn(N64, 3, d_, s_, s_, generator=gs_)) * 0.02).to(dev)
-        th64 = ops.pose_theta(*[x.to(dev) for x in (1 + 0.05 * torch.randn(N64, 3, generator=gs_), 0.3 * torch.randn(N64, 3, generator=gs_),
-                                                    0.05 * torch.randn(N64, 3, generator=gs_))])[:, :3].contiguous()
+        vol1 = torch.randn(1, c_, d_, s_, s_, generator=torch.Generator().manual_seed(1)).to(dev)
+        ccl64 = hp.prepare_canonical(vol1)
+        delta64 = (torch.tanh(torch.randn(N64, 3, d_, s_, s_, generator=torch.Generator().manual_seed(2))) * 0.05).to(dev)
+        g3 = torch.Generator().manual_seed(3)
+        uni = lambda lo, hi: lo + (hi - lo) * torch.rand(N64, 3, generator=g3)
+        rot64, sc64, tr64 = uni(-0.3, 0.3), uni(0.9, 1.1), uni(-0.05, 0.05)
+        th64 = ops.pose_theta(sc64.to(dev), rot64.to(dev), tr64.to(dev))[:, :3].contiguous()
         al64 = torch.empty((N64, c_, d_, s_, s_), device=dev)
-
-        def sampler_pair():
-            for a0 in range(0, N64, hp.sampler_chunk):
-                w_ = ops.grid_sample3d(ccl, delta=delta64[a0:a0 + hp.sampler_chunk], padding_mode=hp.pad, in_layout="ndhwc", out_layout="ndhwc")
-                ops.grid_sample3d(w_, theta=th64[a0:a0 + hp.sampler_chunk], padding_mode=hp.pad, in_layout="ndhwc", out_layout="ncdhw",
-                                  out=al64[a0:a0 + hp.sampler_chunk])
-            return al64
-        t = _time_loop(sampler_pair)
         vol_b = c_ * d_ * s_ * s_ * 4
         # per frame: uv call = shared volume / N + delta (3 planes) + warped out; rotation call = warped in + aligned out
         byts = N64 * (vol_b / N64 + 3 * d_ * s_ * s_ * 4 + vol_b) + N64 * 2 * vol_b
-        out["sampler_only_n64"] = {"frames": N64, "us_per_frame": round(t / N64 * 1e6, 2), "frames_per_s": round(N64 / t, 1),
-                                   "GBps_algorithmic": round(byts / t / 1e9, 1), "frac_of_8TBps": round(byts / t / 1e9 / PEAK_HBM_GBPS, 4)}
+        res64 = {"frames": N64, "warp": "identity + 0.05 * tanh(randn), seed 2", "theta": "yaw/pitch/roll U(-0.3,0.3), scale U(0.9,1.1), "
+                 "translation U(-0.05,0.05), seed 3", "algorithmic_bytes_per_frame": byts / N64}
+        for pad in ("zeros", "reflection"):
+            def sampler_pair():
+                for a0 in range(0, N64, hp.sampler_chunk):
+                    w_ = ops.grid_sample3d(ccl64, delta=delta64[a0:a0 + hp.sampler_chunk], padding_mode=pad, in_layout="ndhwc", out_layout="ndhwc")
+                    ops.grid_sample3d(w_, theta=th64[a0:a0 + hp.sampler_chunk], padding_mode=pad, in_layout="ndhwc", out_layout="ncdhw",
+                                      out=al64[a0:a0 + hp.sampler_chunk])
+                return al64
+            t = _time_loop(sampler_pair)
+            res64[pad] = {"us_per_frame": round(t / N64 * 1e6, 2), "GBps_algorithmic": round(byts / t / 1e9, 1),
+                          "frac_of_8TBps": round(byts / t / 1e9 / PEAK_HBM_GBPS, 4)}
+        res64.update(res64["zeros"])          # (round-4 key layout: the zeros-padding figures at the top level)
+        # the seam: explicit grids [N,16,64,64,3], per-sample NCDHW volumes, NCDHW out, 16 samples per call
+        NS = 16
+        lin = lambda n: torch.linspace(-1, 1, n)
+        wz, vy, ux = torch.meshgrid(lin(d_), lin(s_), lin(s_), indexing="ij")
+        gridS = (torch.stack([ux, vy, wz], -1)[None] + delta64[:NS].permute(0, 2, 3, 4, 1).cpu()).contiguous().to(dev)
+        volS = torch.randn(NS, c_, d_, s_, s_, generator=torch.Generator().manual_seed(4)).to(dev)
+        outS = torch.empty_like(volS)
+        t = _time_loop(lambda: ops.grid_sample3d(volS, gridS, padding_mode="zeros", out=outS))
+        seam_b = NS * (2 * vol_b + d_ * s_ * s_ * 3 * 4)
+        res64["reference_layout_seam_ncdhw_in_out"] = {"samples": NS, "us_per_sample": round(t / NS * 1e6, 2),
+                                                       "GBps_algorithmic": round(seam_b / t / 1e9, 1),
+                                                       "frac_of_8TBps": round(seam_b / t / 1e9 / PEAK_HBM_GBPS, 4)}
+        out["sampler_only_n64"] = res64
+        del vol1, ccl64, delta64, al64, gridS, volS, outS
     except Exception as e:
         out["sampler_only_n64"] = {"error": repr(e)}
     # R256 (BASELINE configs[0]/[1] size): same hot path, 32 frames per step
@@ -698,12 +720,21 @@ def main():
     def conv_roofline(k):
         ms, fl, n = by_k[k]
         tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        pmc, pmc_path = None, ""
+        # HBM traffic per launch: a PMC figure of this command from separate rocprofv3 --pmc passes (it cannot be measured inside
+        # the run).  Only a profile taken on THESE kernel sources is quoted: the file records the hash of the conv kernel headers
+        # (tools/kernel_source_hash.py); with another hash -- or none: profiles of earlier rounds -- the field is null
+        pmc, pmc_path, stale = None, "", None
         pat = {"bf16x3": "r*_pmc_conv_bf16x3_traffic.json", "f16x2": "r*_pmc_conv_f16x2_traffic.json"}.get(k, "r*_pmc_conv_traffic.json")
         found = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", pat)))[-1:]
         if found:
             try:
-                pmc, pmc_path = json.load(open(found[0])).get("hbm_bytes_per_launch"), found[0]
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from kernel_source_hash import kernel_source_hash
+                pj = json.load(open(found[0]))
+                if pj.get("kernel_source_sha16") == kernel_source_hash():
+                    pmc, pmc_path = pj.get("hbm_bytes_per_launch"), found[0]
+                else:
+                    stale = os.path.relpath(found[0], ROOT)
             except Exception:
                 pmc = None
         if k == "f16x2":
@@ -719,7 +750,7 @@ def main():
                     "v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation)")
             note = ("achieved = algorithmic fp32 FLOPs / event time; peak = 2500 TF dense bf16 / 6 products.  A bare stream of this "
                     "MFMA sustains 1.49-1.72 PF on this chip (clocks fall to 1.4-1.7 GHz under it: tools/microbench/mfma_stream.hip, "
-                    "profiles/r3_mfma_stream.jsonl) = 249-287 TF fp32-equivalent")
+                    "archive/profiles/r3_mfma_stream.jsonl) = 249-287 TF fp32-equivalent")
         else:
             peak = PEAK_FP32_MFMA_TFLOPS if k == "f32" else PEAK_BF16_MFMA_TFLOPS
             name = ("conv_igemm_kernel (fp32 32x32x2 MFMA implicit-GEMM conv, all instantiations)" if k == "f32" else
@@ -728,7 +759,8 @@ def main():
         r = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
              "frac": round(tf / peak, 4), "traffic": pmc,
              "traffic_source": (f"{os.path.relpath(pmc_path, ROOT)}: rocprofv3 --pmc passes of this command (guide-corrected "
-                                "HBM bytes per launch), NOT measured in this run" if pmc is not None else None),
+                                "HBM bytes per launch) on these kernel sources, NOT measured in this run" if pmc is not None else
+                                (f"{stale} was taken on other kernel sources: not quoted" if stale else None)),
              "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
              "share_of_step": round(ms / (elapsed_metered * 1e3), 3)}
         if note:

@@ -315,7 +315,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, floatx16 (&acc_
 #endif
 #ifndef EMO_CONV_LDS_PREFETCH
 #define EMO_CONV_LDS_PREFETCH 0   /* 1: the LDS operands of MFMA step k+1 are read before the MFMAs of step k are issued.
-                                     Measured neutral (bench 132.0 vs 131.9 frames/s, profiles/r2_conv_mfma_stream_variants.jsonl):
+                                     Measured neutral (bench 132.0 vs 131.9 frames/s, archive/profiles/r2_conv_mfma_stream_variants.jsonl):
                                      with 4-5 waves per SIMD the operand latency is already covered by the other waves */
 #endif
 #ifndef EMO_CONV_SETPRIO

@@ -4,7 +4,7 @@
 //     x * w  ~=  xh*wh + xh*wm + xm*wh + xm*wm + xh*wl + xl*wh          (dropped: xm*wl + xl*wm + xl*wl  <=  2^-23 |x w|)
 // Each partial product of two bf16 values is exact in fp32, so the only rounding is the fp32 accumulation inside
 // v_mfma_f32_32x32x16_bf16.  That accumulation is coarser than an fp32 fma chain (measured: with all six products in one
-// accumulator the error against an fp64 convolution is 2.4x the fp32 MFMA kernel's, profiles/r3_bf16x3_first_run.txt), so the
+// accumulator the error against an fp64 convolution is 2.4x the fp32 MFMA kernel's, archive/profiles/r3_bf16x3_first_run.txt), so the
 // five small products (<= 2^-8 of the leading one) go to a SECOND accumulator set whose rounding is 2^-8 smaller, and the
 // leading product's accumulator sees one MFMA per 16 channels and tap -- 8x fewer accumulation steps than the fp32 kernel's
 // K = 2 instructions; the two sets are added once in the epilogue.  The dropped terms are 30x below the accumulation error
@@ -39,7 +39,7 @@
 // operand -- x * in_scale = x1 + x2 (+ <= 2^-24 relative; in_scale a power of two folded into the producer's affine, weights
 // scaled per layer on the host) -- and the THREE products x1 w1 + x1 w2 + x2 w1 (dropped: x2 w2 <= 2^-24), result multiplied
 // by 1 / (in_scale * w_scale) when the accumulator sets are combined.  Half the matrix work and two thirds of the LDS planes;
-// measured 279-359 TF fp32-equivalent against 189-226 (profiles/r3_conv_microbench.jsonl), error against an fp64 convolution
+// measured 279-359 TF fp32-equivalent against 189-226 (archive/profiles/r3_conv_microbench.jsonl), error against an fp64 convolution
 // 1.09x the fp32 MFMA kernel's, end-to-end parity figures those of SPLIT = 3.  Its contract is narrower -- |x * in_scale|
 // saturates at 65504 (inputs beyond +-2047 after norm + ReLU), terms below 2^-14 / scale lose relative (not absolute)
 // precision -- which is why the exact SPLIT = 3 is the default.
@@ -157,6 +157,19 @@ __device__ __forceinline__ float emo_row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
   return v;
+}
+
+// the same for N independent values, stage by stage (N butterflies in step: the DPP latency of one hides behind the others)
+template <int N>
+__device__ __forceinline__ void emo_row16_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0xB1, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0x4E, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0x141, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0x140, 0xf, 0xf, true));
 }
 
 // One accumulator element, read where it is used.  The MFMA results live in accumulation registers; left to itself the compiler
@@ -376,7 +389,9 @@ __device__ __forceinline__ void conv_epilogue_fast_issue(const ConvArgs& a, floa
   }
 }
 
-template <int TW, int TM, int TP, int WGP, int BM, int SPLIT, int ROWF, int RES, bool LAUNDER = false>
+// DEFER_STATS (conv_igemm_f16x2_ct2.h): the waves' (mean, M2) entries are left in st_lds; the caller combines them behind a
+// barrier of its own (the one that ends its item anyway) instead of a second one per channel tile.
+template <int TW, int TM, int TP, int WGP, int BM, int SPLIT, int ROWF, int RES, bool LAUNDER = false, bool DEFER_STATS = false>
 __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, floatx16 (&acc_lo)[TM][TP], floatx16 (&acc_hi)[TM][TP],
                                                           floatx4 (&rv0)[8], float* scratch, const float* sbias,
                                                           float* st_lds, int n, int cotile, int ptile, int x0, int y0, int z0, int wp,
@@ -437,26 +452,43 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
       else *reinterpret_cast<floatx4*>(op) = v[it];
     }
     if (want_stats) {
+      // The eight channels of the lane are reduced IN STEP -- stage by stage of the butterfly, all eight before the next stage --
+      // and stored behind one test.  Written channel by channel (reduce, store under `if (t == 0)`, next channel) the exec-mask
+      // region of every store fenced the scheduler: sixteen fully serialised chains of 8 dependent DPP adds per tile, each add
+      // behind its two wait states -- 2.8 k of the epilogue's 9.2 k cycles (profiles/r5_conv_phase_epilogue_parts.jsonl).  Same
+      // operations in the same order per channel: the statistics are bit-identical to conv_epilogue_rows'
       constexpr float inv_cnt = 1.0f / (float)(TP * 32);
+      float mean[NIT], m2[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const floatx2 p2 = floatx2{v[it][0], v[it][2]} + floatx2{v[it][1], v[it][3]};      // (v0 + v1, v2 + v3)
-        const float s4 = p2[0] + p2[1];
-        const float mean = emo_row16_sum(s4) * inv_cnt;
-        const floatx2 mean2 = floatx2{mean, mean};
+        mean[it] = p2[0] + p2[1];
+      }
+      emo_row16_sum_n<NIT>(mean);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        mean[it] *= inv_cnt;
+        const floatx2 mean2 = floatx2{mean[it], mean[it]};
         const floatx2 d01 = floatx2{v[it][0], v[it][1]} - mean2, d23 = floatx2{v[it][2], v[it][3]} - mean2;
-        float m2 = 0.0f;
-        m2 = __fmaf_rn(d01[0], d01[0], m2);
-        m2 = __fmaf_rn(d01[1], d01[1], m2);
-        m2 = __fmaf_rn(d23[0], d23[0], m2);
-        m2 = __fmaf_rn(d23[1], d23[1], m2);
-        m2 = emo_row16_sum(m2);
-        if (t == 0) *reinterpret_cast<float2*>(st_lds + (wp * BM + i * 32 + 4 * it + g) * 2) = make_float2(mean, m2);
+        float q = 0.0f;
+        q = __fmaf_rn(d01[0], d01[0], q);
+        q = __fmaf_rn(d01[1], d01[1], q);
+        q = __fmaf_rn(d23[0], d23[0], q);
+        q = __fmaf_rn(d23[1], d23[1], q);
+        m2[it] = q;
+      }
+      emo_row16_sum_n<NIT>(m2);
+      if (t == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          *reinterpret_cast<float2*>(st_lds + (wp * BM + i * 32 + 4 * it + g) * 2) = make_float2(mean[it], m2[it]);
       }
     }
   }
   EMO_S_STAMP(9)
-  if (want_stats) conv_epilogue_rows_stats<TP, WGP, BM>(a, st_lds, n, cotile, ptile, tid);
+  if constexpr (!DEFER_STATS) {
+    if (want_stats) conv_epilogue_rows_stats<TP, WGP, BM>(a, st_lds, n, cotile, ptile, tid);
+  }
 }
 
 template <int TR, int TW, bool UPS, int SPLIT>

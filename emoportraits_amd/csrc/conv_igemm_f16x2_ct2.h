@@ -482,22 +482,28 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
       const int co_ = nx_cotile * BM + tid;
       te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];
     }
-#define EMO_T_EPI_FAST(RES_, h_)                                                                                                  \
+// both tiles of the pair: the second tile's first residual loads are issued in front of the first tile's epilogue (they have landed
+// when their turn comes: the residual is a tensor another kernel wrote long ago -- an HBM round trip that the single-tile kernel
+// waits out in every item)
+#define EMO_T_EPI_FAST(RES_)                                                                                                      \
     {                                                                                                                              \
-      floatx4 rv_[8];                                                                                                              \
-      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0, true>(a, rv_, ep_n, ep_cotile + (h_), ep_x0, ep_y0, ep_z0, wp, lane);         \
-      conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_, true>(                                            \
-          a, acc_lo[h_], acc_hi[h_], rv_, scratch, smem + ((h_) ? Cfg::OFF_BIAS2_F : Cfg::OFF_BIAS_F),                             \
-          smem + ((h_) ? Cfg::OFF_STAT2_F : Cfg::OFF_STAT_F), ep_n, ep_cotile + (h_), ep_ptile, ep_x0, ep_y0, ep_z0, wp, half,     \
-          l32, lane, tid EMO_S_TSTAMP_ARG);                                                                                        \
+      floatx4 rv_[8], rvn_[8];                                                                                                     \
+      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0, true>(a, rv_, ep_n, ep_cotile, ep_x0, ep_y0, ep_z0, wp, lane);                 \
+      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0, true>(a, rvn_, ep_n, ep_cotile + 1, ep_x0, ep_y0, ep_z0, wp, lane);            \
+      conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_, true, true>(                                      \
+          a, acc_lo[0], acc_hi[0], rv_, scratch, smem + Cfg::OFF_BIAS_F, smem + Cfg::OFF_STAT_F, ep_n, ep_cotile, ep_ptile, ep_x0,  \
+          ep_y0, ep_z0, wp, half, l32, lane, tid EMO_S_TSTAMP_ARG);                                                                \
+      EMO_S_STAMP(10)                                                                                                              \
+      conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_, true, true>(                                      \
+          a, acc_lo[1], acc_hi[1], rvn_, scratch, smem + Cfg::OFF_BIAS2_F, smem + Cfg::OFF_STAT2_F, ep_n, ep_cotile + 1, ep_ptile,  \
+          ep_x0, ep_y0, ep_z0, wp, half, l32, lane, tid EMO_S_TSTAMP_ARG);                                                         \
     }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (epi_mode == 1) EMO_T_EPI_FAST(1, h)
-      else if (epi_mode == 2) EMO_T_EPI_FAST(2, h)
-      else EMO_T_EPI_FAST(0, h)
-      if (h == 0) { EMO_S_STAMP(8) } else { EMO_S_STAMP(9) }       // (measurement builds: first / second channel tile written)
-    }
+    if (epi_mode == 1) EMO_T_EPI_FAST(1)
+    else if (epi_mode == 2) EMO_T_EPI_FAST(2)
+    else EMO_T_EPI_FAST(0)
+#if EMO_S_TIMING
+    tstamp[8] = tstamp[10];          // (measurement builds: stamp 8 = first tile written, 9 = second tile written)
+#endif
 #undef EMO_T_EPI_FAST
   }
   if (a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
@@ -517,8 +523,26 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     }
   }
 #endif
-  // the next prologue overwrites the tables, the statistics exchange and W[1]: every wave must be out of the epilogue first
+  // the next prologue overwrites the tables and W[1]: every wave must be out of the epilogue first
   __syncthreads();
+  // tile statistics, second half (conv_epilogue_rows_stats, for both tiles at once and behind the barrier above instead of one of
+  // their own each): thread c of the first 128 combines the four waves' (mean, M2) of channel c with the equal-count update.
+  // The exchange areas are next written by the NEXT item's epilogue, a K loop away
+  if (a.gn_stats != nullptr && tid < 2 * BM) {
+    const int c_ = tid & (BM - 1);
+    const float* const st_ = smem + (tid < BM ? Cfg::OFF_STAT_F : Cfg::OFF_STAT2_F);
+    float mean = 0.0f, m2 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WGP; ++w) mean += st_[(w * BM + c_) * 2 + 0];
+    mean *= 1.0f / (float)WGP;
+#pragma unroll
+    for (int w = 0; w < WGP; ++w) {
+      const float d = st_[(w * BM + c_) * 2 + 0] - mean;
+      m2 += st_[(w * BM + c_) * 2 + 1] + (float)(TP * 32) * d * d;
+    }
+    float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)it_n * nptiles + it_ptile) * a.Cout + it_cotile * BM + tid;
+    *dst = make_float2(mean, m2);
+  }
   chained_in = chain_out;
   }
 #undef EMO_T_DECODE

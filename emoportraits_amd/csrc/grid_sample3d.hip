@@ -30,7 +30,7 @@
 typedef float emo_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef EMO_GS3D_ABLATE
 #define EMO_GS3D_ABLATE 0      /* timing experiments only (results are WRONG for any value != 0): 1 no corner gathers, 2 no output
-                                  stores of the channels-last kernels, 4 no NCDHW stores of the rotation kernel (profiles/r3_sampler_ablation.jsonl) */
+                                  stores of the channels-last kernels, 4 no NCDHW stores of the rotation kernel (archive/profiles/r3_sampler_ablation.jsonl) */
 #endif
 #if EMO_GS3D_ABLATE & 2
 #define EMO_GS3D_STORE(ptr, val)                                                                                       \
@@ -274,7 +274,7 @@ __device__ __forceinline__ float4 gather_quad(const char* __restrict__ vbytes, c
 
 // (voxel, quad) of item = threadIdx.x + 256 * k without a division per item: the runtime divisor LPV = C / 4 costs ~25 VALU
 // instructions per division, a third of an item's instruction count (the kernels' arithmetic skeleton is 40 % of their time,
-// profiles/r3_sampler_ablation.jsonl); one division per thread, then (v, q) advance by (256 / LPV, 256 % LPV) with a carry
+// archive/profiles/r3_sampler_ablation.jsonl); one division per thread, then (v, q) advance by (256 / LPV, 256 % LPV) with a carry
 struct ItemWalk {
   int v, q, dv, dq, lpv;
   __device__ __forceinline__ ItemWalk(int tid, int LPV) : lpv(LPV) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void gs3d_cl_v2_kernel(
 // NDHWC -> NDHWC with 4x4x4 output bricks per block: the 8 corners of a brick's 64 voxels fall into ~5x5x5 source voxels
 // (48 KB at C = 96) instead of the 2x2x65 of an x-row (100 KB): half the L1 fills per output voxel.  The samplers are
 // bound by the per-CU L1 path (64-byte granules per clock + outstanding-miss capacity), not by L2 or HBM
-// (profiles/r2_pmc_sampler_*.json), so fewer fills per voxel is the lever.  Needs Do, Ho, Wo multiples of 4.
+// (archive/profiles/r2_pmc_sampler_*.json), so fewer fills per voxel is the lever.  Needs Do, Ho, Wo multiples of 4.
 template <int PAD, int MODE, int ORDER>
 __global__ __launch_bounds__(256) void gs3d_cl_brick_kernel(
     const float* __restrict__ vol, const float* __restrict__ grid, const float* __restrict__ theta,
@@ -417,7 +417,7 @@ int launch_cl_v2(const float* vol, const float* grid, const float* theta, const 
 // is 1.3 us per frame slower: opt-in.  2 = non-temporal stores of an NCDHW output (the driver pass's rotation call).
 // 4 = fused multiply-add accumulation (gather_quad<true>: taps bit-identical, values within 8 * 2^-24 * max|v w| of ATen).
 // Default: 64-voxel rows, XCD-contiguous, and for a volume shared by N % 8 == 0 samples also row-group-major over the XCD's
-// samples.  (profiles/r3_sampler_nt_stores_ab.jsonl, r3_sampler_nt_out_ab.jsonl)
+// samples.  (archive/profiles/r3_sampler_nt_stores_ab.jsonl, r3_sampler_nt_out_ab.jsonl)
 template <int PAD, int MODE>
 int dispatch_cl_v2(const float* vol, const float* grid, const float* theta, const float* lin_x, const float* lin_y,
                    const float* lin_z, float* out, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,

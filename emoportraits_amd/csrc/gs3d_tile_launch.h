@@ -86,7 +86,7 @@ int launch_tile(const float* vol, const float* grid, const float* theta, const f
   int threads = (variant >> 25) & 1 ? 512 : 256;
   if (txs + tys + tzs == 0) {
     // default tile: 4 x 8 x 8 output voxels, one per thread -- the best of the sweeps for both calls at 16 frames per launch
-    // (profiles/r3_sampler_tile_sweep_n16.jsonl: rotation 15.6 us P4 -> P4, uv 11.6 us); larger tiles stage smaller boxes per
+    // (archive/profiles/r3_sampler_tile_sweep_n16.jsonl: rotation 15.6 us P4 -> P4, uv 11.6 us); larger tiles stage smaller boxes per
     // voxel but leave too few blocks
     txs = 3; tys = 3; tzs = 2; threads = 256;
     while (tzs > 0 && (1 << tzs) >= 2 * Do) { --tzs; ++tys; }

@@ -317,8 +317,8 @@ class HotPath:
         self.sampler_chunk = int(os.environ.get("EMO_SAMPLER_CHUNK", "4"))
         self.sampler_uv_variant = int(os.environ.get("EMO_SAMPLER_UV_VARIANT", "0"))   # 1: 4x4x4 output bricks instead of rows (A/B)
         # 2: the aligned volume goes past the caches (non-temporal stores).  Measured inconclusive: - 5 % on the pair when every
-        # launch is bracketed by events (profiles/r3_sampler_nt_out_ab.jsonl), nothing back to back or in the bench
-        # (profiles/r3_sampler_microbench.jsonl): off
+        # launch is bracketed by events (archive/profiles/r3_sampler_nt_out_ab.jsonl), nothing back to back or in the bench
+        # (archive/profiles/r3_sampler_microbench.jsonl): off
         self.sampler_rot_variant = int(os.environ.get("EMO_SAMPLER_ROT_VARIANT", "0"))
         from .pack import conv_precision
         # fp16 mode: the WarpGenerators stay exact fp32 (EMO_WARP_PRECISION=f16 overrides) -- their output is GEOMETRY (where

@@ -84,7 +84,7 @@ def grid_sample3d(vol, grid=None, theta=None, padding_mode="zeros", in_layout="n
             and C * 260 + 5120 <= 65536 and C * D * H * W * 4 < 2 ** 32):
         # the reference's call shape (model.grid_sample(NCDHW, grid) -> NCDHW, va.py:264-265) on a large volume: one repack
         # to channels-last + the channels-last gather (NCDHW out) moves 51 MB in 23 us, the NCDHW gather needs 35 us
-        # (its 4-byte corner loads are bound by the vector-memory instruction rate; profiles/r3_sampler_seam.jsonl)
+        # (its 4-byte corner loads are bound by the vector-memory instruction rate; archive/profiles/r3_sampler_seam.jsonl)
         return grid_sample3d(volume_to_channels_last(vol), grid if delta is None else None, theta, padding_mode, "ndhwc",
                              "ncdhw", 0, out, delta)
     shape = {"ndhwc": (N, Do, Ho, Wo, C), "ncdhw": (N, C, Do, Ho, Wo), "p4": (N, C // 4, Do, Ho, Wo, 4)}[out_layout]

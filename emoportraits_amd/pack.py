@@ -219,12 +219,12 @@ def pack_weight(w, cfg):
     return wp.view(-1)
 
 
-# relative MFMA efficiency of the block configs measured on MI355X at 16 frames (profiles/r2_conv_microbench.jsonl):
+# relative MFMA efficiency of the block configs measured on MI355X at 16 frames (archive/profiles/r2_conv_microbench.jsonl):
 # the 64-row tile (15 KB stage buffers -> 5 blocks per CU) beats the 128-row one (25 KB -> 3 blocks) on the 64^2 .. 256^2
 # layers (133 vs 124 TF on 512->512 @64^2) and ties it at 512^2 (132-135); the 32-row tile re-stages the same input patch
 # for a quarter of the work
 # the 64 x 256 tile (D) halves the weight-tile traffic per MFMA and stages 25-33 % less patch per position: 131-141 TF on
-# every 2-D 3x3 decoder layer (B: 126-135), bench 127.3 -> 132.0 frames/s (profiles/r2_conv_microbench.jsonl)
+# every 2-D 3x3 decoder layer (B: 126-135), bench 127.3 -> 132.0 frames/s (archive/profiles/r2_conv_microbench.jsonl)
 _CFG_EFF = {CFG_A: 0.97, CFG_B: 1.0, CFG_C: 0.88, CFG_D: 1.03, CFG_E: 0.0, CFG_F: 0.92, CFG_G: 0.0}
 if __import__("os").environ.get("EMO_F16_CFG_G") == "1":   # opt-in: plan fp16-operand 3x3 layers with the 128 x 256 tile
     _CFG_EFF[CFG_G] = 1.15                                  # (one block per CU; built and parity-tested, not yet the default)
@@ -284,7 +284,7 @@ def ksplit_for(blocks, nstages):
 
 def _quantisation(nblocks, cus=256):
     """a launch of a few blocks per CU finishes when the most loaded CU does: 640 blocks put 3 on half of the CUs and 2 on
-    the rest -- 2.5 / 3 of the machine.  Measured at batch 2 (profiles/r3_conv_microbench_b2.jsonl): 320 -> 320 @128^2 runs at
+    the rest -- 2.5 / 3 of the machine.  Measured at batch 2 (archive/profiles/r3_conv_microbench_b2.jsonl): 320 -> 320 @128^2 runs at
     113 TF on the 64 x 256 tile (640 blocks) and at 130 TF on the 64 x 128 tile (1280 blocks)."""
     if nblocks < cus or EMO_PLAN_QUANTISATION == 0:
         return 1.0

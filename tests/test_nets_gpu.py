@@ -127,7 +127,7 @@ def test_driver_pass_released_architecture_vs_oracle(S, B):
     print(f"PARITY R{S} B={B} driver end-to-end:", {k: f"{v:.2e}" for k, v in errs.items()})
     print(f"PARITY R{S} B={B} driver stage-wise:", {k: f"{v:.2e}" for k, v in st.items()})
     assert errs["warp_embed"] <= 1e-5 and errs["delta_abs"] <= 1e-4, errs
-    # measured on MI355X (profiles/r1_parity.txt): samplers 8.5e-6, deep_f 2.9e-6, img_f 7.7e-6, img 1.0e-4 abs;
+    # measured on MI355X (archive/profiles/r1_parity.txt): samplers 8.5e-6, deep_f 2.9e-6, img_f 7.7e-6, img 1.0e-4 abs;
     # end-to-end: aligned 1.5e-4, deep_f 6.1e-5, img_f 1.2e-4, img 1.6e-3 abs (sigmoid of a WS-normalised 128-ch head:
     # the head's pre-activation gain turns 1e-4 relative feature error into 1e-3 of the [0,1] range)
     assert st["samplers"] <= 5e-5, st     # explicit grids are bit-exact; analytic theta differs by <= 1 ulp in coords

@@ -86,6 +86,8 @@ def main():
     lib = hip.load()
     shapes = [(128, 128, (512, 512), False), (192, 128, (256, 256), True), (192, 192, (256, 256), False),
               (320, 320, (128, 128), False), (512, 512, (64, 64), False)]
+    if "--shapes" in sys.argv:                                   # e.g. --shapes 0,4
+        shapes = [shapes[int(i)] for i in sys.argv[sys.argv.index("--shapes") + 1].split(",")]
     for cin, cout, dims, ups in shapes:
         x = torch.randn(B, cin, *dims, device=DEV)
         w = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
@@ -108,10 +110,12 @@ def main():
             layer = pack.PackedConv("t", w, None, DEV, precision=prec)
             gn = None
             real = "--real" in sys.argv          # as the decoder launches it: residual + GroupNorm tile statistics
-            res = torch.randn(B, cout, *odims, device=DEV) if real else None
-            kw = dict(relu_in=True, ups=ups, res=res, want_stats=real)
+            with_res = real or "--res" in sys.argv          # (--res / --stats: one of the two alone, to tell their costs apart)
+            with_stats = real or "--stats" in sys.argv
+            res = torch.randn(B, cout, *odims, device=DEV) if with_res else None
+            kw = dict(relu_in=True, ups=ups, res=res, want_stats=with_stats)
             out = ops.conv_igemm(x, layer, scale, shift, **kw)
-            out = out[0] if real else out
+            out = out[0] if with_stats else out
             for _ in range(2):
                 ops.conv_igemm(x, layer, scale, shift, out=out, **kw)
             torch.cuda.synchronize()
@@ -121,7 +125,7 @@ def main():
             b.record()
             torch.cuda.synchronize()
             ms = a.elapsed_time(b)
-            rec = dict(B=B, cin=cin, cout=cout, dims=dims, ups=ups, mode=mode, real=real, stagger=os.environ.get("EMO_CONV_STAGGER", "0"),
+            rec = dict(B=B, cin=cin, cout=cout, dims=dims, ups=ups, mode=mode, real=real, residual=with_res, statistics=with_stats, stagger=os.environ.get("EMO_CONV_STAGGER", "0"),
                        ms=round(ms, 3), tflops=round(flops / ms / 1e9, 1), tiles_per_item=2 if mode == "ct2" else 1,
                        stages=(-(-cin // 16)))
             full = stamps(lib, mode, 65536)
