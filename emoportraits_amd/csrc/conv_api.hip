@@ -17,6 +17,7 @@ conv_launch_fn conv_lookup_f16_1x1_D(int, int);
 conv_launch_fn conv_lookup_f16_3x3_G(int, int);
 conv_launch_fn conv_lookup_bf16x3_3x3(int, int);
 conv_launch_fn conv_lookup_f16x2_3x3(int, int);
+conv_launch_fn conv_lookup_f16x2_1x1(int, int);
 
 // MFMA operand format (accumulation and all tensors in HBM are fp32 either way).  PREC_S: every fp32 operand as the exact sum
 // of three bf16 terms, six partial products (conv_igemm_bf16x3.h) -- fp32 results on the bf16 pipes
@@ -33,6 +34,7 @@ static int shape_of_width(int Wl) {
 }
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
+  if (prec == PREC_S2 && cfg == CFG_D && KH == 1 && KW == 1) return 32;   // conv_igemm_f16x2_p1.h: pointwise, 32 channels per stage
   if (prec == PREC_S || prec == PREC_S2) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
   if (prec == PREC_F16) {
     if (cfg == CFG_G) return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : 0;   // 128 x 256 tile: 3x3 only
@@ -152,7 +154,12 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;
-  if (prec == PREC_S || prec == PREC_S2) {
+  if (prec == PREC_S2 && KH == 1 && KW == 1) {
+    // pointwise layers on the fp16 split (conv_igemm_f16x2_p1.h): one launch form, no K split
+    if (KD != 1 || cfg != CFG_D || Cin % 8 || ksplit != 1 || run_if != nullptr) return EMO_ERR_UNSUPPORTED;
+    if (!(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;
+    fn = conv_lookup_f16x2_1x1(a.Wl, ups);
+  } else if (prec == PREC_S || prec == PREC_S2) {
     if (!(KH == 3 && KW == 3 && (KD == 1 || KD == 3)) || cfg != CFG_D || Cin % 8) return EMO_ERR_UNSUPPORTED;
     if (prec == PREC_S2 && !(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;
     fn = prec == PREC_S ? conv_lookup_bf16x3_3x3(a.Wl, ups) : conv_lookup_f16x2_3x3(a.Wl, ups);
@@ -202,6 +209,15 @@ extern "C" int emo_conv_igemm_f32(const float* x, const float* wpk, const float*
                                   int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
   return conv_igemm_dispatch(PREC_F32, x, wpk, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
                              relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
+}
+
+extern "C" int emo_conv_igemm_f32_guarded(const float* x, const float* wpk, const float* bias, const float* scale,
+                                          const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
+                                          int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
+                                          int cfg, int ksplit, float* workspace, float* gn_stats, void* stream,
+                                          const int* run_if) {
+  return conv_igemm_dispatch(PREC_F32, x, wpk, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream, 1.0f, 1.0f, nullptr, run_if);
 }
 
 extern "C" int emo_conv_igemm_bf16x3(const float* x, const void* wpk3, const float* bias, const float* scale,

@@ -85,7 +85,7 @@ struct ConvArgs {
   float* gn_stats;     // or null (needs ksplit == 1): [N][position tiles][Cout][2] = (mean, centred sum of squares) of
                        // the 128 final output values of every (sample, position tile, channel)
   int* sat_flag;       // conv_igemm_bf16x3.h, fp16 two-term split only, or null: set to 1 when a staged value left the fp16 range
-  const int* run_if;   // conv_igemm_bf16x3.h, or null: the launch does nothing unless *run_if != 0 (guarded fallback of a layer
+  const int* run_if;   // conv_igemm_bf16x3.h / conv_igemm.h, or null: the launch does nothing unless *run_if != 0 (guarded fallback of a layer
                        // whose fp16-split launch raised its sat_flag)
 };
 
@@ -354,6 +354,7 @@ void conv_igemm_kernel(const ConvArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
+  if (a.run_if != nullptr && *a.run_if == 0) return;   // guarded exact recomputation of a fp16-split pointwise layer (emo_conv_igemm_f32_guarded)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   // wave id as a scalar (SGPR): everything derived from it (staged channel, base pointers, GN scale/shift) is then

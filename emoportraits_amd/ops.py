@@ -293,12 +293,17 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
             raise ValueError("bad residual shape")
     positions = N * D * Hl * Wl
     cfg, ks, prec = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl, ups, affine=scale is not None,
-                                   aligned16=x.data_ptr() % 16 == 0, in_elems_per_sample=x.numel() // max(1, N))
+                                   aligned16=x.data_ptr() % 16 == 0 and (res is None or res.data_ptr() % 16 == 0)
+                                   and (out is None or out.data_ptr() % 16 == 0),
+                                   in_elems_per_sample=x.numel() // max(1, N), act=act)
+    pointwise_split = prec == "f16x2" and getattr(layer, "pointwise_split", False)
     if ksplit is not None:
         ks = int(ksplit)
     ws = torch.empty((ks, out.numel()), device=x.device, dtype=torch.float32) if ks > 1 else None
     stats = None
-    bp = pack_mod._BP[cfg]
+    # (a pointwise layer on the fp16 split keeps its tile statistics in the 128-position layout of the fp32 MFMA kernel that
+    # recomputes it behind a raised overflow word: csrc/conv_igemm_f16x2_p1.h writes two half entries per 256-position tile)
+    bp = 128 if pointwise_split else pack_mod._BP[cfg]
     if want_stats and ks == 1 and (D * Hl * Wl) % bp == 0:
         stats = TileStats(torch.empty((N, D * Hl * Wl // bp, layer.cout, 2), device=x.device, dtype=torch.float32), bp)
     layer.last_plan = (cfg, ks, prec)        # which kernel ran (bench.py meters the kernels separately)
@@ -319,7 +324,17 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
             common = common[:4] + (hip.ptr(out),) + common[5:]
         rc = entry(hip.ptr(x), hip.ptr(wpk), *common, pack_mod.F16X2_IN_SCALE, layer.w_scale, flag)
         hip.check(rc, f"emo_conv_igemm_f16x2[{layer.name}]")
-        if F16X2_GUARD:
+        if F16X2_GUARD and pointwise_split:
+            # (pointwise layer: the exact recomputation is the fp32 MFMA kernel at its own launch plan)
+            gcfg, gks = pack_mod.plan_launch(layer.cout, layer.cin, layer.kd, layer.kh, layer.kw, max(1, -(-positions // 128)),
+                                             layer.allowed, "f32")
+            if gks > 1 and stats is not None:
+                raise RuntimeError("pointwise fp16-split launch with tile statistics: the guarded fp32 launch may not split K")
+            gws = torch.empty((gks, out.numel()), device=x.device, dtype=torch.float32) if gks > 1 else None
+            gcommon = common[:18] + (gcfg, gks, hip.ptr(gws), None if gks > 1 else common[21], common[22])
+            rc = lib.emo_conv_igemm_f32_guarded(hip.ptr(x), hip.ptr(layer.packed(gcfg)), *gcommon, flag)
+            hip.check(rc, f"emo_conv_igemm_f32_guarded[{layer.name}]")
+        elif F16X2_GUARD:
             rc = lib.emo_conv_igemm_bf16x3(hip.ptr(x), hip.ptr(layer.packed(cfg, "bf16x3")), *common, flag)
             hip.check(rc, f"emo_conv_igemm_bf16x3[{layer.name}, guarded]")
     else:

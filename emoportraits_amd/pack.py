@@ -135,6 +135,7 @@ def pack_weight_bf16x3(w):
 
 
 F16X2_GUARD_DEFAULT = __import__("os").environ.get("EMO_F16X2_GUARD", "1") != "0"   # ops.F16X2_GUARD starts from this
+F16X2_POINTWISE = __import__("os").environ.get("EMO_F16X2_POINTWISE", "1") != "0"   # A/B switch: 1x1 layers of an f16x2 model on the fp32 MFMA kernel
 F16X2_IN_SCALE = 32.0      # emo_conv_igemm_f16x2: the staged input is multiplied by this (inputs beyond +-2047 saturate)
 
 # Overflow flags of the fp16-split layers (include/emo_hip.h, emo_conv_igemm_f16x2): one int32 word per layer in a per-device
@@ -200,6 +201,31 @@ def pack_weight_f16x2(w):
     w2 = (wp - w1.float()).to(torch.float16)
     planes = torch.stack((w1, w2), 0)
     planes = planes.view(2, n_cot, bm, n_cc, 2, 8, kd, kh, kw).permute(1, 3, 6, 7, 0, 8, 4, 2, 5).contiguous()
+    return planes.view(-1), w_scale
+
+
+F16X2_P1_KC = 32     # conv_igemm_f16x2_p1.h: input channels per stage of the pointwise kernel
+
+
+def pack_weight_f16x2_1x1(w):
+    """operand layout of emo_conv_igemm_f16x2 for KH = KW = 1 (csrc/conv_igemm_f16x2_p1.h):
+    [channel tile, padded to an EVEN count][Cin chunk of 32][plane 1|2][k-step of 16][half][BM = 64][8] fp16 of w * w_scale
+    -> (flat fp16 tensor, w_scale).  One (tile, chunk) block is 8 KB, copied into LDS as it lies."""
+    w = w.reshape(w.shape[0], w.shape[1])
+    cout, cin = w.shape
+    bm, kc = BF16X3_BM, F16X2_P1_KC
+    n_cot = -(-cout // bm)
+    n_cot += n_cot & 1                          # (an odd last tile runs in a pair whose second half is zero weights)
+    n_cc = -(-cin // kc)
+    wmax = float(w.abs().max())
+    w_scale = 2.0 ** math.floor(math.log2(1023.0 / wmax)) if wmax > 0 else 1.0
+    wp = torch.zeros((n_cot * bm, n_cc * kc), dtype=torch.float32)
+    wp[:cout, :cin] = w.float() * w_scale
+    w1 = wp.to(torch.float16)
+    w2 = (wp - w1.float()).to(torch.float16)
+    planes = torch.stack((w1, w2), 0)           # [plane, co, ci]
+    # [plane, cot, BM, cc, ks, half, k8] -> [cot, cc, plane, ks, half, BM, k8]
+    planes = planes.view(2, n_cot, bm, n_cc, 2, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).contiguous()
     return planes.view(-1), w_scale
 
 
@@ -352,6 +378,22 @@ def supports_bf16x3(cout, cin, kd, kh, kw, precision="bf16x3"):
     return (kh, kw) == (3, 3) and kd in (1, 3) and cin % 8 == 0 and fill >= (0.5 if precision == "f16x2" else 0.75)
 
 
+def supports_f16x2_pointwise(cout, cin, kd, kh, kw):
+    """pointwise layers the fp16 split takes (csrc/conv_igemm_f16x2_p1.h): whole 64-channel tiles, at least one PAIR of them,
+    whole 8-channel input groups, an even number of 32-channel stages"""
+    return (kd, kh, kw) == (1, 1, 1) and cout % BF16X3_BM == 0 and cout >= 2 * BF16X3_BM and cin % 8 == 0 \
+        and (-(-cin // F16X2_P1_KC)) % 2 == 0          # (its K loop runs two 32-channel stages per iteration)
+
+
+def f16x2_pointwise_launch_fits(Hl, Wl, ups, n_pos_tiles, cout, act="none"):
+    """the launch form of the pointwise kernel: 4 x 64 position tiles on the source grid, no activation, and enough pair items
+    for two per CU (below that the fp32 MFMA kernel's K split fills the chip better)"""
+    if Hl is None or ups or act != "none" or Wl % 64 or Hl % 4:
+        return False
+    min_items = int(__import__("os").environ.get("EMO_F16X2_P1_MIN_ITEMS", 2 * 256))      # (tests lower it to reach small shapes)
+    return (n_pos_tiles // 2) * (-(-(cout // BF16X3_BM) // 2)) >= min_items
+
+
 def bf16x3_launch_fits(Hl, Wl, ups=False):
     """output planes tiled by 4 x 64 positions, or (32- / 16-wide maps, no fused upsample) 8 x 32 / 16 x 16"""
     return Hl is not None and ((Wl % 64 == 0 and Hl % 4 == 0) or (Wl == 32 and Hl % 8 == 0 and not ups)
@@ -389,8 +431,10 @@ class PackedConv:
         self.pinned_cfg = cfg
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
-        if precision in ("bf16x3", "f16x2") and not supports_bf16x3(cout, cin, kd, kh, kw, precision):
-            raise ValueError(f"{name}: the split-operand kernel covers 3x3 / 3x3x3 convolutions with a multiple of 8 input channels")
+        self.pointwise_split = precision == "f16x2" and supports_f16x2_pointwise(cout, cin, kd, kh, kw)
+        if precision in ("bf16x3", "f16x2") and not self.pointwise_split and not supports_bf16x3(cout, cin, kd, kh, kw, precision):
+            raise ValueError(f"{name}: the split-operand kernel covers 3x3 / 3x3x3 convolutions with a multiple of 8 input channels "
+                             f"(fp16 split: also 1x1 layers with at least 128 output channels)")
         if precision == "f16" and not supports_f16(cout, cin, kd, kh, kw):
             raise ValueError(f"{name}: the fp16-operand kernel covers 3x3 / 3x3x3 / 1x1 convolutions with >= 32 output "
                              f"channels and a multiple of 8 input channels")
@@ -401,6 +445,13 @@ class PackedConv:
         if precision == "f32":
             first = choose_cfg(cout) if cfg is None else cfg
             self.packed(first if first in self.allowed else CFG_B)
+        elif self.pointwise_split:
+            # pointwise layer on the fp16 split: its own operand layout; the fp32 layout as well -- launches the pointwise kernel
+            # does not take (small batches, activations), and the guarded exact recomputation, run the fp32 MFMA kernel
+            self.packed(CFG_D, "f16x2")
+            first = choose_cfg(cout) if cfg in (None, CFG_D) else cfg
+            self.packed(first if first in self.allowed else CFG_B)
+            self.flag_slot = overflow_flag_slot(device, name)
         elif precision in ("bf16x3", "f16x2"):
             self.packed(CFG_D, precision)       # eager, like the fp32 layout: the first launch is not a host-side packing job
             if precision == "f16x2":            # the guarded exact recomputation behind a raised overflow flag (ops.conv_igemm)
@@ -421,7 +472,7 @@ class PackedConv:
             return self._packed["bf16x3"]
         if precision == "f16x2":
             if "f16x2" not in self._packed:
-                flat, self.w_scale = pack_weight_f16x2(self._weight)
+                flat, self.w_scale = (pack_weight_f16x2_1x1 if self.pointwise_split else pack_weight_f16x2)(self._weight)
                 self._packed["f16x2"] = flat.to(self.device)
             return self._packed["f16x2"]
         cfg = _PACK_AS.get(cfg, cfg)
@@ -434,7 +485,7 @@ class PackedConv:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
-    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False, aligned16=True, in_elems_per_sample=0):
+    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False, aligned16=True, in_elems_per_sample=0, act="none"):
         """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output; `affine`: the
         launch carries a per-sample input scale / shift (the fp16-operand kernel keeps those in a 1024-entry LDS table);
         `aligned16`: the input pointer is 16-byte aligned (that kernel loads 16-byte quads); `in_elems_per_sample`:
@@ -447,7 +498,11 @@ class PackedConv:
                 (CFG_D, CFG_G) if (_CFG_EFF[CFG_G] > 0 and self.kh == 3) else (CFG_D,)
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, tiles, "f16")
             return cfg, ks, "f16"
-        if self.precision in ("bf16x3", "f16x2") and bf16x3_launch_fits(Hl, Wl, ups) and self.pinned_cfg in (None, CFG_D) \
+        if self.pointwise_split:
+            if f16x2_pointwise_launch_fits(Hl, Wl, ups, n_pos_tiles, self.cout, act) and self.pinned_cfg in (None, CFG_D) \
+                    and aligned16 and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
+                return CFG_D, 1, "f16x2"
+        elif self.precision in ("bf16x3", "f16x2") and bf16x3_launch_fits(Hl, Wl, ups) and self.pinned_cfg in (None, CFG_D) \
                 and aligned16 and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), self.precision)
             return cfg, ks, self.precision
@@ -471,5 +526,7 @@ class PackedConv:
             split = _build_precision in ("bf16x3", "f16x2")
             ok = supports_bf16x3(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1], _build_precision) if split \
                 else supports_f16(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1])
+            if _build_precision == "f16x2" and F16X2_POINTWISE and supports_f16x2_pointwise(w.shape[0], w.shape[1], kd, w.shape[-2], w.shape[-1]):
+                ok = True
             precision = _build_precision if ok else "f32"
         return cls(prefix, w, b, device, cfg, precision)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 6
+#define EMO_ABI_VERSION 7
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
@@ -230,6 +230,21 @@ int emo_conv_igemm_f16x2(const float* x, const void* wpk2, const float* bias,
                          int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
                          int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
                          float* gn_stats, void* stream, float in_scale, float w_scale, int* overflow_flag);
+
+/* ABI 7.  POINTWISE layers on the fp16 split: emo_conv_igemm_f16x2 also takes KH = KW = 1 (KD = 1; 2-D, or 3-D with D as a
+ * batch of planes) -- nn.Conv2d(Cin, Cout, 1) of decoder.py:66-70 (1536 -> 512) and the 1x1 skips of utils.py:764-781 -- on a
+ * kernel of its own (csrc/conv_igemm_f16x2_p1.h: two 64-channel output tiles per work item on one converted patch).  wpk2 then is
+ * [channel tile, padded to an even count][Cin chunk of 32][plane 1|2][k-step of 16][half][BM = 64][8] fp16 of w * w_scale
+ * (emoportraits_amd.pack.pack_weight_f16x2_1x1).  Launch form: ksplit 1, ups 0, act EMO_ACT_NONE, Cout % 64 == 0, W % 64 == 0,
+ * H % 4 == 0, 16-byte aligned x / out / res; EMO_ERR_UNSUPPORTED otherwise (such a launch runs emo_conv_igemm_f32).  Contract
+ * and overflow_flag as above; the guarded exact recomputation behind it is
+ * emo_conv_igemm_f32_guarded: emo_conv_igemm_f32 with run_if (NULL, or a device word: the launch does nothing unless
+ * *run_if != 0 when it starts executing), same stream, launched right after the fp16-split launch. */
+int emo_conv_igemm_f32_guarded(const float* x, const float* wpk, const float* bias,
+                               const float* scale, const float* shift, const float* res, float* out,
+                               int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
+                               int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
+                               float* gn_stats, void* stream, const int* run_if);
 
 /* ---------------------------------------------------------------------------------------------
  * resampling / pointwise helpers (HBM-bound, one pass)

@@ -261,6 +261,66 @@ def test_conv_f16x2_two_tile_kernel_statistics_and_range_check(monkeypatch):
     ops.clear_overflow_flags(DEV)
 
 
+# pointwise layers on the fp16 split (csrc/conv_igemm_f16x2_p1.h): 32-channel stages, two channel tiles per item, an odd last tile
+# in a half-empty pair, chained items; every residual form; affine + ReLU inputs; 3-D tensors as batches of planes
+P1_CASES = [
+    dict(N=1, Cin=64, Cout=128, dims=(64, 64), k=1, cfg=None),
+    dict(N=2, Cin=192, Cout=320, dims=(32, 64), k=1, cfg=None, bias=False, res=True),                 # 5 channel tiles: half-empty pair
+    dict(N=2, Cin=128, Cout=192, dims=(64, 128), k=1, cfg=None, affine=True, relu_in=True),
+    dict(N=3, Cin=320, Cout=128, dims=(16, 64), k=1, cfg=None, res=True),
+    dict(N=1, Cin=64, Cout=256, dims=(4, 64, 64), k=1, cfg=None, affine=True, relu_in=True, res=True), # 3-D
+    dict(N=4, Cin=1536, Cout=512, dims=(64, 64), k=1, cfg=None, bias=False),                          # the decoder's entry convolution
+]
+
+
+@pytest.mark.parametrize("case", P1_CASES)
+def test_conv_f16x2_pointwise_kernel(case, monkeypatch):
+    monkeypatch.setenv("EMO_F16X2_P1_MIN_ITEMS", "1")
+    e, got, ref = run_conv(seed=29, precision="f16x2", **case)
+    print("PARITY conv f16x2 pointwise kernel:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    assert e < 2e-5, e
+    e2, got2, _ = run_conv(seed=29, precision="f16x2", **case)
+    assert torch.equal(got, got2), "two launches on the same input differ: a race in the pipeline"
+    e32, got32, _ = run_conv(seed=29, precision="f32", **case)
+    assert not torch.equal(got, got32), "the fp32 MFMA kernel ran: the pointwise launch was not planned onto the split kernel"
+
+
+def test_conv_f16x2_pointwise_plan_statistics_and_range_check(monkeypatch):
+    """the planner routes a pointwise layer of an f16x2 model onto the split kernel only in its launch form (enough pair items, no
+    activation, no fused upsample); its tile statistics (two half entries per 256-position tile, the fp32 MFMA kernel's
+    128-position layout) give the GroupNorm affine of a direct reduction; an out-of-range input raises the layer's overflow word
+    and the guarded fp32 MFMA launch rewrites output and statistics: bit-identical to a plain fp32 launch"""
+    monkeypatch.setenv("EMO_F16X2_P1_MIN_ITEMS", "1")
+    g = torch.Generator().manual_seed(35)
+    N, Cin, Cout, H, W = 2, 64, 192, 32, 64
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g) * 0.1
+    x = torch.randn(N, Cin, H, W, generator=g)
+    l2 = pack.PackedConv("pw", w, b, DEV, precision="f16x2")
+    l1 = pack.PackedConv("pw32", w, b, DEV, precision="f32")
+    assert l2.pointwise_split and l2.plan_for(N * H * W // 128, H, W)[2] == "f16x2"
+    assert l2.plan_for(N * H * W // 128, H, W, act="tanh")[2] == "f32" and l2.plan_for(N * H * W // 128, 2 * H, 2 * W, ups=True)[2] == "f32"
+    monkeypatch.setenv("EMO_F16X2_P1_MIN_ITEMS", "512")
+    assert l2.plan_for(N * H * W // 128, H, W)[2] == "f32"            # (too few items: the fp32 MFMA kernel, K split)
+    monkeypatch.setenv("EMO_F16X2_P1_MIN_ITEMS", "1")
+    with pytest.raises(ValueError):
+        pack.PackedConv("bad", torch.zeros(64, 64, 1, 1), None, DEV, precision="f16x2")     # one channel tile: no pair
+    ops.clear_overflow_flags(DEV)
+    out, st = ops.conv_igemm(x.to(DEV), l2, want_stats=True)
+    assert l2.last_plan[2] == "f16x2" and st is not None and ops.overflow_events(DEV) == {}
+    assert rel_err(out, F.conv2d(x, w, b)) < 2e-5
+    s1, h1 = ops.groupnorm_affine(out, stats=st)
+    s0, h0 = ops.groupnorm_affine(out)
+    assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item() and (h1 - h0).abs().max().item() <= 2e-6
+    xa = x.clone()
+    xa[1, 7, 5, 33] = 5000.0
+    got, sg = ops.conv_igemm(xa.to(DEV), l2, want_stats=True)
+    assert list(ops.overflow_events(DEV).values()) == ["pw"]
+    want, sw = ops.conv_igemm(xa.to(DEV), l1, want_stats=True)
+    assert torch.equal(got.cpu(), want.cpu()) and torch.equal(sg.stats.cpu(), sw.stats.cpu())
+    ops.clear_overflow_flags(DEV)
+
+
 @pytest.mark.parametrize("ksplit", [None, 3])
 def test_conv_f16x2_guarded_recomputation_with_the_residual_updated_in_place(ksplit):
     """out aliases res (a residual updated in place, the form nets.ResBlock used for its convolved skip): the guarded bf16x3

@@ -112,6 +112,36 @@ def test_pack_weight_layout(cfg_id, shape):
         assert flat[idx].item() == w5[co, ci, t, tap // kw, tap % kw].item()
 
 
+def test_pack_weight_layout_of_the_pointwise_fp16_split():
+    """pack.pack_weight_f16x2_1x1 (csrc/conv_igemm_f16x2_p1.h): [channel tile, even count][Cin chunk of 32][plane][k-step of 16]
+    [half][BM][8]; the two planes are the fp16 pair of w * w_scale; padding (channels, the tile that fills an odd count) is zero"""
+    g = torch.Generator().manual_seed(7)
+    cout, cin = 320, 96
+    w = torch.randn(cout, cin, 1, 1, generator=g)
+    flat, ws = pack.pack_weight_f16x2_1x1(w)
+    ncot, ncc = 6, 3
+    assert flat.dtype == torch.float16 and flat.numel() == ncot * ncc * 2 * 2 * 2 * 64 * 8 and 512 <= w.abs().max().item() * ws < 1024
+    v = flat.view(ncot, ncc, 2, 2, 2, 64, 8)
+    wp = torch.zeros(ncot * 64, ncc * 32)
+    wp[:cout, :cin] = w.view(cout, cin) * ws
+    w1 = wp.to(torch.float16)
+    planes = (w1, (wp - w1.float()).to(torch.float16))
+    assert torch.equal((planes[0].float() + planes[1].float())[:cout, :cin], (w.view(cout, cin) * ws)) or \
+        ((planes[0].float() + planes[1].float())[:cout, :cin] - w.view(cout, cin) * ws).abs().max().item() <= 2.0 ** -13
+    for _ in range(500):
+        co, ci, pl = (int(torch.randint(n, (1,), generator=g)) for n in (ncot * 64, ncc * 32, 2))
+        cot, m = divmod(co, 64)
+        cc, r = divmod(ci, 32)
+        ks, r2 = divmod(r, 16)
+        half, k8 = divmod(r2, 8)
+        assert v[cot, cc, pl, ks, half, m, k8] == planes[pl][co, ci]
+    assert v[5].abs().sum() == 0                                         # the padding tile of the odd count
+    # which layers: whole channel tiles, at least one pair, an even number of 32-channel stages
+    ok = pack.supports_f16x2_pointwise
+    assert ok(512, 1536, 1, 1, 1) and ok(320, 512, 1, 1, 1) and ok(192, 320, 1, 1, 1) and ok(128, 192, 1, 1, 1)
+    assert not ok(64, 128, 1, 1, 1) and not ok(128, 96, 1, 1, 1) and not ok(128, 128, 1, 3, 3) and not ok(130, 128, 1, 1, 1)
+
+
 def test_launch_config_heuristic():
     assert pack.choose_cfg(512) == pack.CFG_B and pack.choose_cfg(320) == pack.CFG_B and pack.choose_cfg(3) == pack.CFG_C
     # few position tiles: prefer more (smaller) blocks; many: least padding wins
@@ -334,12 +364,16 @@ def test_split_convolution_arithmetic_on_the_cpu():
                                           ("f32", {"emo_conv_igemm_f32": 42}),
                                           # (every fp16-split launch is followed by its guarded bf16x3 recomputation launch)
                                           # (... and the fp16 split also takes the two 32-channel 3-D layers of the WarpGenerator)
-                                          (None, {"emo_conv_igemm_f16x2": 30, "emo_conv_igemm_bf16x3": 30, "emo_conv_igemm_f32": 12})])
+                                          # (... and, since round 5, the decoder's four 1x1 layers -- 1536 -> 512 and the skips of its
+                                          # up-blocks -- on the pointwise kernel, each followed by its guarded fp32 MFMA launch)
+                                          (None, {"emo_conv_igemm_f16x2": 34, "emo_conv_igemm_bf16x3": 30, "emo_conv_igemm_f32": 8,
+                                                  "emo_conv_igemm_f32_guarded": 4})])
 def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect):
     """the host side of the released R512 driver pass without a GPU (tools/host_overhead.py: every kernel entry point of the
     library returns at once): the launch plan sends the 28 3x3 / 3x3x3 layers the split kernel covers to it (30 in the fp16 split) (default mode: as the
     fp16 split, each launch followed by its guarded bf16x3 launch), the 1x1 / narrow 3-D / head convolutions to the fp32 MFMA
-    kernel, and the whole pass is 95 C-ABI calls (+ 30 guards)"""
+    kernel (default mode: the decoder's four 1x1 layers on the pointwise split kernel), and the whole pass is 95 C-ABI calls
+    (+ 34 guards)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import host_overhead
     from emoportraits_amd import nets
@@ -356,7 +390,7 @@ def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect)
     assert tuple(img.shape) == (B, 3, 512, 512)
     convs = {k: v for k, v in stub.calls.items() if k.startswith("emo_conv_igemm")}
     assert convs == expect, convs
-    assert sum(stub.calls.values()) == 95 + (30 if mode is None else 0), dict(stub.calls)
+    assert sum(stub.calls.values()) == 95 + (34 if mode is None else 0), dict(stub.calls)
 
 
 def test_isa_audit_finds_a_scalar_operand_read_too_early_and_an_in_flight_destination():

@@ -95,6 +95,23 @@ def main():
             ms2 = timeit(lambda: ops.conv_igemm(x, l2, scale, shift, relu_in=True, ups=ups, out=out))
             rec["f16x2_ms"] = round(ms2, 3)
             rec["f16x2_tflops"] = round(flops / ms2 / 1e9, 1)
+        if "--f16x2" in sys.argv and k == 1 and not three_d and pack.supports_f16x2_pointwise(cout, cin, 1, 1, 1):
+            # pointwise layers of the default mode (csrc/conv_igemm_f16x2_p1.h).  A 1x1 skip commutes with the nearest upsample, so
+            # the network runs it on the PRE-upsample tensor (nets.ResBlock): a quarter of the positions -- timed that way, with
+            # stock torch on the same tensor beside it; no input affine (these layers have none: decoder.py:66-70, utils.py:764-781)
+            lp = pack.PackedConv("p1", w, None, DEV, precision="f16x2")
+            pos_src = B * math.prod(dims)
+            if lp.plan_for(max(1, -(-pos_src // 128)), dims[-2], dims[-1])[2] == "f16x2":
+                fl_src = 2.0 * B * cout * cin * math.prod(dims)
+                out = ops.conv_igemm(x, lp)
+                msp = timeit(lambda: ops.conv_igemm(x, lp, out=out))
+                ms_ts = timeit(lambda: conv(x, wd))
+                l32 = pack.PackedConv("p32", w, None, DEV)
+                out32 = ops.conv_igemm(x, l32)
+                ms32 = timeit(lambda: ops.conv_igemm(x, l32, out=out32))
+                rec["pointwise_on_the_source_grid"] = dict(f16x2_ms=round(msp, 3), f16x2_tflops=round(fl_src / msp / 1e9, 1),
+                                                          fp32_mfma_ms=round(ms32, 3), fp32_mfma_tflops=round(fl_src / ms32 / 1e9, 1),
+                                                          torch_ms=round(ms_ts, 3), torch_tflops=round(fl_src / ms_ts / 1e9, 1))
         if not f16_only:       # what the planner picks for this launch (block config + K split), as the networks run it
             la = pack.PackedConv("auto", w, None, DEV)
             Hl_, Wl_ = odims[-2], odims[-1]
