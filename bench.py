@@ -64,7 +64,10 @@ class ConvMeter:
             out = ret[0] if isinstance(ret, tuple) else ret         # (out, tile statistics) with want_stats=True
             positions = out.numel() // layer.cout
             fl = 2.0 * positions * layer.macs_per_position
-            meter.events.append((e0, e1, layer.last_plan[2], fl))
+            kern = layer.last_plan[2]
+            if kern == "f16x2" and getattr(layer, "pointwise_split", False):
+                kern = "f16x2_pointwise"                 # (csrc/conv_igemm_f16x2_p1.h: a kernel of its own, metered separately)
+            meter.events.append((e0, e1, kern, fl))
             meter.flops += fl
             meter.launches += 1
             return ret
@@ -725,7 +728,7 @@ def main():
         # (tools/kernel_source_hash.py); with another hash -- or none: profiles of earlier rounds -- the field is null
         pmc, pmc_path, stale = None, "", None
         pat = {"bf16x3": "r*_pmc_conv_bf16x3_traffic.json", "f16x2": "r*_pmc_conv_f16x2_traffic.json"}.get(k, "r*_pmc_conv_traffic.json")
-        found = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", pat)))[-1:]
+        found = [] if k == "f16x2_pointwise" else sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", pat)))[-1:]
         if found:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -739,11 +742,17 @@ def main():
                 pmc = None
         if k == "f16x2":
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
-            name = ("conv_igemm_bf16x3_kernel<SPLIT = 2> (fp32 3x3 conv on the fp16 matrix pipes: scaled operands as two fp16 terms, 3 "
-                    "v_mfma_f32_32x32x16_f16 products per fp32 product, fp32 accumulation; operand range checked on the device, "
-                    "guarded bf16x3 recomputation launch behind every layer)")
-            note = ("achieved = algorithmic fp32 FLOPs / event time of the launch PAIR (fp16-split launch + its guarded, normally "
-                    "skipped, bf16x3 launch); peak = 2500 TF dense fp16 / 3 products")
+            name = ("conv_igemm_bf16x3_ct2_kernel + conv_igemm_bf16x3_kernel<SPLIT = 2> (fp32 3x3 conv on the fp16 matrix pipes: scaled "
+                    "operands as two fp16 terms, 3 v_mfma_f32_32x32x16_f16 products per fp32 product, fp32 accumulation; two 64-channel "
+                    "output tiles per work item on one converted patch where a layer has pairs of them, the single-tile kernel on an "
+                    "odd last tile; operand range checked on the device, guarded bf16x3 recomputation launch behind every layer)")
+            note = ("achieved = algorithmic fp32 FLOPs / event time of a LAYER's launches (two-tile launch, single-tile launch of an odd "
+                    "last tile, the guarded, normally skipped, bf16x3 launch); peak = 2500 TF dense fp16 / 3 products")
+        elif k == "f16x2_pointwise":
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+            name = ("conv_igemm_bf16x3_p1_kernel (1x1 convolutions on the fp16 matrix pipes: the two-term split, 32-channel stages, two "
+                    "channel tiles per work item; guarded fp32 MFMA recomputation launch behind every layer)")
+            note = "achieved = algorithmic fp32 FLOPs / event time of the launch pair; peak = 2500 TF dense fp16 / 3 products"
         elif k == "bf16x3":
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0
             name = ("conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes: exact 3-way operand split, 6 "
@@ -789,7 +798,8 @@ def main():
                                                 "fp16 terms (2^-24 relative), 3 partial products on the fp16 matrix pipes (error vs fp64 "
                                                 "1.1x the fp32 MFMA kernel's); the operand range is checked on the device by every "
                                                 "launch and a guarded bf16x3 launch recomputes a layer that left it "
-                                                "(tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
+                                                "(tests/test_conv_bf16x3_gpu.py); the decoder's four 1x1 layers: the same split on "
+                                                "the pointwise kernel (guarded fp32 MFMA recomputation); other convs: fp32 MFMA",
                                        "f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in every convolution"}[hp.precision],
                    "step_launch": step_launch,
                    "f16x2_layers_recomputed_after_range_check": recomputed,

@@ -32,6 +32,12 @@
 #pragma once
 #include "conv_igemm_bf16x3.h"
 
+#ifndef EMO_CT2_RES_EARLY
+#define EMO_CT2_RES_EARLY 0   /* 1: the first tile's residual loads go out in front of the K loop instead of at the top of the epilogue.
+                                 Measured (tools/session/r5_call9.sh): epilogue 13.1 k -> 12.6 k cycles per pair, but the K loop's first
+                                 barrier (vmcnt(0): loads complete in order) then waits for them -- K loop + 3.8 k, prologue + 2.2 k: off */
+#endif
+
 template <int TR, int TW, bool UPS>
 struct ConvCfgS2 : ConvCfgS<TR, TW, UPS, 2> {
   using Base = ConvCfgS<TR, TW, UPS, 2>;
@@ -359,6 +365,14 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     pp = 0;
   }
 
+  // (EMO_CT2_RES_EARLY: the first residual loads of the item's first channel tile issued here, a K loop ahead of their use --
+  // measured slower, see the macro.  Ordinary loads: the compiler waits for them itself; its count of younger loads misses the
+  // pinned ones, which only makes the wait stricter)
+  floatx4 rv_first[8];
+#if EMO_CT2_RES_EARLY
+  if (epi_mode == 1) conv_epilogue_fast_issue<TW, TP, BM, 1, 0, true>(a, rv_first, it_n, it_cotile, it_x0, it_y0, it_z0, wp, lane);
+  else if (epi_mode == 2) conv_epilogue_fast_issue<TW, TP, BM, 2, 0, true>(a, rv_first, it_n, it_cotile, it_x0, it_y0, it_z0, wp, lane);
+#endif
   // ---- K loop: one stage = two half-stages (header comment) ----
   EMO_S_STAMP(1)
 #pragma unroll
@@ -487,8 +501,9 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
 // waits out in every item)
 #define EMO_T_EPI_FAST(RES_)                                                                                                      \
     {                                                                                                                              \
-      floatx4 rv_[8], rvn_[8];                                                                                                     \
-      conv_epilogue_fast_issue<TW, TP, BM, RES_, 0, true>(a, rv_, ep_n, ep_cotile, ep_x0, ep_y0, ep_z0, wp, lane);                 \
+      floatx4 (&rv_)[8] = rv_first;                                                                                                \
+      floatx4 rvn_[8];                                                                                                             \
+      if (!EMO_CT2_RES_EARLY) conv_epilogue_fast_issue<TW, TP, BM, RES_, 0, true>(a, rv_, ep_n, ep_cotile, ep_x0, ep_y0, ep_z0, wp, lane); \
       conv_epilogue_fast_issue<TW, TP, BM, RES_, 0, true>(a, rvn_, ep_n, ep_cotile + 1, ep_x0, ep_y0, ep_z0, wp, lane);            \
       conv_epilogue_fast_finish<TW, TM, TP, WGP, BM, SPLIT, Cfg::EPI_ROWF, RES_, true, true>(                                      \
           a, acc_lo[0], acc_hi[0], rv_, scratch, smem + Cfg::OFF_BIAS_F, smem + Cfg::OFF_STAT_F, ep_n, ep_cotile, ep_ptile, ep_x0,  \
