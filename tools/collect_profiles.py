@@ -89,8 +89,9 @@ traffic("conv_igemm_kernel", "conv_igemm_kernel (fp32 MFMA, all instantiations)"
 # the split kernel's two operand modes are instantiations of one template: <TR, TW, UPS, SPLIT>.  A default (f16x2) run also holds
 # the guarded bf16x3 launches, which leave at once: they would dilute a per-launch figure, so only a bf16x3 run's trace is used
 if any(k.startswith("conv_igemm_bf16x3_kernel") and ", 2>" in k for k in f):
-    traffic("conv_igemm_bf16x3_kernel", "conv_igemm_bf16x3_kernel<SPLIT = 2> (fp32 3x3 conv on the fp16 matrix pipes: two-term split, device-checked range)",
-            f"{tag}_pmc_conv_f16x2_traffic.json", suffix=", 2>")
+    # (default mode, round 5: a layer is up to two kernels + its guarded launch -- tools/collect_traffic.py sums them per LAYER
+    # launch and records the hash of the kernel sources, which bench.py checks before quoting the file)
+    os.system(f"{sys.executable} tools/collect_traffic.py {tag}")
 else:
     traffic("conv_igemm_bf16x3_kernel", "conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes, all instantiations)",
             f"{tag}_pmc_conv_bf16x3_traffic.json", suffix=", 3>")
