@@ -502,8 +502,6 @@ class StrongClip:
 def strong_scaling(hp, cfg, dev, rank, world, total, B, S, seed, clips, warm, graph):
     """-> record of the strong-scaling measurement (rank 0) or None: `clips` timed clips behind `warm` untimed ones, barrier +
     device synchronisation on both sides, MAX over ranks"""
-    if not hp.with_source and rank == 0:
-        raise SystemExit("the strong-scaling clip runs the source pass on rank 0: drop --no-source-pass")
     clip = StrongClip(hp, cfg, dev, rank, world, total, B, S, seed, graph=graph)
     for _ in range(warm):
         clip.run()
@@ -568,6 +566,8 @@ def main():
                          "many frames; 0 skips it")
     a = ap.parse_args()
 
+    if a.total_frames and a.no_source_pass:          # (every rank sees the same flags: no rank is left waiting in a collective)
+        raise SystemExit("--total-frames times the source pass of every clip: it cannot be combined with --no-source-pass")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         visible = torch.cuda.device_count()
         if visible < a.gpus and os.environ.get("EMO_FORCE_DEVICE") is None:

@@ -293,8 +293,9 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
             raise ValueError("bad residual shape")
     positions = N * D * Hl * Wl
     cfg, ks, prec = layer.plan_for(max(1, -(-positions // 128)), Hl, Wl, ups, affine=scale is not None,
-                                   aligned16=x.data_ptr() % 16 == 0 and (res is None or res.data_ptr() % 16 == 0)
-                                   and (out is None or out.data_ptr() % 16 == 0),
+                                   # (the pointwise split kernel has the straight-line epilogue only: 16-byte aligned out / res)
+                                   aligned16=x.data_ptr() % 16 == 0 and (not getattr(layer, "pointwise_split", False) or (
+                                       (res is None or res.data_ptr() % 16 == 0) and (out is None or out.data_ptr() % 16 == 0))),
                                    in_elems_per_sample=x.numel() // max(1, N), act=act)
     pointwise_split = prec == "f16x2" and getattr(layer, "pointwise_split", False)
     if ksplit is not None:
