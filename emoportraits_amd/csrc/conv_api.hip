@@ -18,6 +18,7 @@ conv_launch_fn conv_lookup_f16_3x3_G(int, int);
 conv_launch_fn conv_lookup_bf16x3_3x3(int, int);
 conv_launch_fn conv_lookup_f16x2_3x3(int, int);
 conv_launch_fn conv_lookup_f16x2_1x1(int, int);
+conv_launch_fn conv_lookup_f16x2_3x3_bm32(int, int);
 
 // MFMA operand format (accumulation and all tensors in HBM are fp32 either way).  PREC_S: every fp32 operand as the exact sum
 // of three bf16 terms, six partial products (conv_igemm_bf16x3.h) -- fp32 results on the bf16 pipes
@@ -35,6 +36,7 @@ static int shape_of_width(int Wl) {
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
   if (prec == PREC_S2 && cfg == CFG_D && KH == 1 && KW == 1) return 32;   // conv_igemm_f16x2_p1.h: pointwise, 32 channels per stage
+  if (prec == PREC_S2 && cfg == CFG_F && KH == 3 && KW == 3) return 16;   // fp16 split on 32-row channel tiles (conv_igemm_bf16x3.h, BMT = 32)
   if (prec == PREC_S || prec == PREC_S2) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
   if (prec == PREC_F16) {
     if (cfg == CFG_G) return (KH == 3 && KW == 3) ? EMO_CONV_KC_F16_3X3 : 0;   // 128 x 256 tile: 3x3 only
@@ -159,6 +161,11 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
     if (KD != 1 || cfg != CFG_D || Cin % 8 || ksplit != 1 || run_if != nullptr) return EMO_ERR_UNSUPPORTED;
     if (!(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;
     fn = conv_lookup_f16x2_1x1(a.Wl, ups);
+  } else if (prec == PREC_S2 && cfg == CFG_F) {
+    // the fp16 split on 32-row channel tiles (weights packed for BM = 32: emoportraits_amd.pack.pack_weight_f16x2(w, bm=32))
+    if (!(KH == 3 && KW == 3 && (KD == 1 || KD == 3)) || Cin % 8) return EMO_ERR_UNSUPPORTED;
+    if (!(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;
+    fn = conv_lookup_f16x2_3x3_bm32(a.Wl, ups);
   } else if (prec == PREC_S || prec == PREC_S2) {
     if (!(KH == 3 && KW == 3 && (KD == 1 || KD == 3)) || cfg != CFG_D || Cin % 8) return EMO_ERR_UNSUPPORTED;
     if (prec == PREC_S2 && !(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;

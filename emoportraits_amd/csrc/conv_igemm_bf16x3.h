@@ -88,9 +88,13 @@ static __device__ unsigned long long emo_s_tlog[EMO_S_TLOG_N * EMO_S_TLOG_W];
 
 // SPLIT = 3: bf16 x 3 terms, 6 products (exact operands).  SPLIT = 2: fp16 x 2 terms of the SCALED operand, 3 products (header
 // comment at the end of this file's introduction): half the matrix work, operands to 2^-24 relative inside +-65504 / in_scale.
-template <int TR, int TW, bool UPS, int SPLIT = 3>
+// BMT: output channels per tile, 64 -- or 32 (fp16 split only, round 5): a layer with 32 output channels ran the 64-row tile half
+// empty (the two 32-channel 3-D layers of the WarpGenerator: 160-186 TF); with a 32-row tile a wave's tile is 32 x 64 -- half the
+// MFMAs, half the weight stage (18 DMA pieces: five per wave, the last two re-copied by waves 2, 3)
+template <int TR, int TW, bool UPS, int SPLIT = 3, int BMT = 64>
 struct ConvCfgS {
-  static constexpr int BM = 64, BP = 256, TM = 2, TP = 2, WGP = 4, KC = 16;
+  static constexpr int BM = BMT, BP = 256, TM = BMT / 32, TP = 2, WGP = 4, KC = 16;
+  static_assert(BMT == 64 || (BMT == 32 && SPLIT == 2), "32-row channel tiles: the one-barrier (fp16-split) schedule only");
   static constexpr int NPL = SPLIT;                      // operand planes
   static constexpr int NPROD = SPLIT == 3 ? 6 : 3;       // partial products per fp32 product
   static constexpr int TRS = UPS ? TR / 2 : TR;          // tile extent in SOURCE pixels
@@ -135,12 +139,16 @@ struct ConvCfgS {
   // idle stage buffer, which holds the dead re-staged rows
   static constexpr bool CHAIN = EMO_S_CHAIN && NWB == 2;
   static constexpr bool EPI_IN_W = !EPI_IN_PATCH && NWB == 2 && WSTAGE * 4 >= WGP * EPI_WAVE;
-  static_assert(!CHAIN || EPI_IN_W, "a chained epilogue needs the free weight stage buffer");
+  // (a chained epilogue needs scratch that the next item's first stage does not occupy: the free weight stage buffer, or -- the
+  // 32-row tile, whose weight stage is too small for it -- a region of its own)
   static constexpr int LDS_BYTES = (OFF_EPI_F + ((EPI_IN_PATCH || EPI_IN_W) ? 0 : WGP * EPI_WAVE)) * 4;
   // LDS-DMA instructions EVERY wave issues per kernel row (1 KiB each).  3 planes: 18 pieces, waves 2, 3 re-copy pieces 16,
   // 17 (uniform vmcnt counts); 2 planes: 12 pieces, 3 per wave
   static constexpr int NDMA = SPLIT == 3 ? 5 : 3;
-  static_assert(WROW_BYTES == (SPLIT == 3 ? 18 : 12) * 1024, "DMA pieces per kernel row");
+  // one-barrier schedule: 1 KiB pieces of a whole stage (three kernel rows, contiguous) per wave -- piece k of wave w is piece
+  // w + 4 k of the stage; 36 pieces: nine per wave; 18 pieces (32-row tile): five, the fifth = piece 16 + (w & 1)
+  static constexpr int NSTP = SPLIT == 3 ? 0 : (BMT == 64 ? 9 : 5);
+  static_assert(WROW_BYTES == (SPLIT == 3 ? 18 : 12) * 1024 * BMT / 64, "DMA pieces per kernel row");
   static_assert(TR * TW == BP, "planar position tile of BP pixels");
   static_assert(TWS % 4 == 0 && (!UPS || (TR % 2 == 0 && TW % 2 == 0)), "whole quads");
   static_assert(PR * NQ + NHQ <= QPG, "one interior quad or one halo pixel per thread and stage");
@@ -396,7 +404,7 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
                                                           floatx4 (&rv0)[8], float* scratch, const float* sbias,
                                                           float* st_lds, int n, int cotile, int ptile, int x0, int y0, int z0, int wp,
                                                           int half, int l32, int lane, int tid, unsigned long long* tstamp = nullptr) {
-  static_assert(TP == 2 && TM == 2 && BM == 64, "wave tile of 64 channels x 64 positions");
+  static_assert(TP == 2 && (TM == 1 || TM == 2) && BM == 32 * TM, "wave tile of 64 (32) channels x 64 positions");
   constexpr int NIT = 8;
   const int g = lane >> 4, t = lane & 15;
   const bool want_stats = a.gn_stats != nullptr;
@@ -432,7 +440,7 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
       }
     // the second half's residual: issued now, into the registers the first half's accumulators have just left (with all 16
     // loads in flight from the start the compiler spills the landed values to scratch and waits vmcnt(0) before every store)
-    if (i == 0) conv_epilogue_fast_issue<TW, TP, BM, RES, 1, LAUNDER>(a, rv1, n, cotile, x0, y0, z0, wp, lane);
+    if (i == 0 && TM == 2) conv_epilogue_fast_issue<TW, TP, BM, RES, 1, LAUNDER>(a, rv1, n, cotile, x0, y0, z0, wp, lane);
     floatx4 (&rv)[8] = i == 0 ? rv0 : rv1;
     floatx4 v[NIT];
 #pragma unroll
@@ -491,10 +499,10 @@ __device__ __forceinline__ void conv_epilogue_fast_finish(const ConvArgs& a, flo
   }
 }
 
-template <int TR, int TW, bool UPS, int SPLIT>
+template <int TR, int TW, bool UPS, int SPLIT, int BMT = 64>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void conv_igemm_bf16x3_kernel(const ConvArgs a) {
-  using Cfg = ConvCfgS<TR, TW, UPS, SPLIT>;
+  using Cfg = ConvCfgS<TR, TW, UPS, SPLIT, BMT>;
   using opx8 = typename std::conditional<SPLIT == 3, bf16x8, halfx8>::type;      // one LDS slot: 8 channels of one plane
   constexpr int NPL = Cfg::NPL;
   constexpr int BM = Cfg::BM, TM = Cfg::TM, TP = Cfg::TP, WGP = Cfg::WGP, KC = Cfg::KC;
@@ -775,8 +783,14 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #define EMO_S_DMA_PIECE(ptr_, row_, i_) EMO_S_DMA_PIECE_TO(ptr_, 0, row_, i_)
 #define EMO_S_DMA_ROW(ptr_, row_)                                                                     \
   { _Pragma("unroll") for (int i = 0; i < Cfg::NDMA; ++i) EMO_S_DMA_PIECE(ptr_, row_, i) }
-// piece k = 0 .. 3 * NDMA - 1 of a whole stage (one-barrier schedule): row k / NDMA, piece k % NDMA of that row
-#define EMO_S_DMA_STAGE_PIECE(ptr_, wb_, k_) EMO_S_DMA_PIECE_TO(ptr_, wb_, (k_) / Cfg::NDMA, (k_) % Cfg::NDMA)
+// piece k = 0 .. NSTP - 1 of a whole stage (one-barrier schedule; the three kernel rows of a stage are contiguous on both sides):
+// piece wave + 4 k of the stage -- for the 64-row tile that is row k / 3, piece wave + 4 (k % 3) of the row; the 18-piece stage of
+// the 32-row tile ends with pieces 16, 17, copied twice (waves 0 / 2 and 1 / 3: the same bytes to the same place)
+#define EMO_S_DMA_STAGE_PIECE(ptr_, wb_, k_)                                                          \
+  {                                                                                                   \
+    const int j = (BMT == 64 || (k_) < 4) ? wave + 4 * (k_) : 16 + (wave & 1);                        \
+    emo_dma16_pinned_s((ptr_) + j * 1024, lane16, smem_lds + (unsigned)((Cfg::OFF_W + (wb_) * Cfg::WSTAGE) * 16 + j * 1024)); \
+  }
 #define EMO_S_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #if EMO_S_TIMING == 2
 // measurement build: how long every wave sits in the waitcnt of a K-loop barrier (memory / LDS latency it did not hide) and in
@@ -827,9 +841,13 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
         const int co_ = P_##cotile * BM + tid;                                                        \
         te_b = a.bias[co_ < a.Cout ? co_ : a.Cout - 1];                                               \
       }                                                                                               \
-      EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 0);                  \
-      EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 1);                  \
-      if constexpr (ONEBAR) EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 2); \
+      if constexpr (ONEBAR) {                                                                         \
+        _Pragma("unroll") for (int k = 0; k < Cfg::NSTP; ++k)                                         \
+          EMO_S_DMA_STAGE_PIECE(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 0, k)    \
+      } else {                                                                                        \
+        EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 0);                \
+        EMO_S_DMA_ROW(EMO_S_WSRC(P_) + (long)P_##st_begin * (3 * Cfg::WROW_BYTES), 1);                \
+      }                                                                                               \
     }                                                                                                 \
     EMO_S_SET_STAGE_INIT(P_##st_begin);                                                               \
     EMO_S_ISSUE_BEGIN(0)                                                                              \
@@ -1054,7 +1072,7 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
             if (ONEBAR) {
               // weights of stage cg + 1 into W[par ^ 1]: pieces 2 .. 8 in steps 0 .. 4; the first two pieces of stage cg + 2 into
               // W[par] behind the barrier of step 8; the quad loads two per step in steps 0 .. 3
-              static_assert(!ONEBAR || (NPL == 2 && Cfg::NDMA == 3), "piece schedule of the one-barrier stage");
+              static_assert(!ONEBAR || (NPL == 2 && (Cfg::NSTP == 9 || Cfg::NSTP == 5)), "piece schedule of the one-barrier stage");
               if (gs == 8 && pl < 2) {
                 // (chained item, last stage: the two pieces go to the patch buffer this stage has finished with, a dump)
                 const int j_ = wave + 4 * pl;
@@ -1062,9 +1080,9 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
                                                            : (unsigned)((Cfg::OFF_W + par * Cfg::WSTAGE) * 16 + j_ * 1024));
                 emo_dma16_pinned_s(dma_ptr2 + j_ * 1024, lane16, dst_);
               }
-              if (gs < 4 && pl == 0) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 2 + gs)
+              if (gs < 4 && pl == 0 && 2 + gs < Cfg::NSTP) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 2 + gs)
               if (gs < 4 && pl == 1) EMO_S_ISSUE_LOADS(par, 2 * gs, 2 * gs + 2)
-              if (gs == 4) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 6 + pl)
+              if (gs == 4 && 6 + pl < Cfg::NSTP) EMO_S_DMA_STAGE_PIECE(dma_ptr, par ^ 1, 6 + pl)
             } else if (!(EMO_S_ABLATE & 1)) {
               static_assert(ONEBAR || (NPL == 3 && Cfg::NDMA == 5), "piece schedule of the three-row stage");
               if (gs == 8 && pl < 2) EMO_S_DMA_PIECE(dma_ptr, 2, pl)                      // row 2 of stage cg + 1
@@ -1102,7 +1120,21 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
               else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[fcur][pb][j], fa_[fcur][pa][i], acc_, 0, 0, 0);
             }
         }
-        if (EMO_S_PIN) {
+        if (EMO_S_PIN && TM == 1) {
+          // 32-row tile: 6 MFMAs and 6 fragment reads per step -- { MFMA, two reads, VALU } x 3, then { MFMA, VALU, LDS store } x 3
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          }
+#pragma unroll
+          for (int k = 3; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        } else if (EMO_S_PIN) {
           // { MFMA, fragment read, <= 5 VALU } for the 4 * NPL reads of the step, then { MFMA, <= 6 VALU, LDS store }
 #pragma unroll
           for (int k = 0; k < 4 * NPL; ++k) {
@@ -1228,9 +1260,9 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
 #undef EMO_S_CURSOR_OF
 }
 
-template <int TR, int TW, bool UPS, int SPLIT = 3>
+template <int TR, int TW, bool UPS, int SPLIT = 3, int BMT = 64>
 int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
-  using Cfg = ConvCfgS<TR, TW, UPS, SPLIT>;
+  using Cfg = ConvCfgS<TR, TW, UPS, SPLIT, BMT>;
   if (a.Wl % TW || a.Hl % TR) return EMO_ERR_UNSUPPORTED;
   if (a.Cin % 8) return EMO_ERR_UNSUPPORTED;   // whole 8-channel groups
   if (a.scale && a.Cin > Cfg::SCT) return EMO_ERR_UNSUPPORTED;   // scale / shift tables in LDS
@@ -1243,7 +1275,7 @@ int conv_igemm_bf16x3_launch(ConvArgs a, hipStream_t s) {
   const long nt = (long)a.tiles_x * a.tiles_y * a.tiles_z;
   if (nt > 0x7fffffffL || a.N > 65535) return EMO_ERR_UNSUPPORTED;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
-  auto kern = conv_igemm_bf16x3_kernel<TR, TW, UPS, SPLIT>;
+  auto kern = conv_igemm_bf16x3_kernel<TR, TW, UPS, SPLIT, BMT>;
   const int rc = emo_raise_dynamic_lds(kern);
   if (rc != EMO_OK) return rc;
   // persistent blocks (min(n_work, CUs)) by default: no workgroup launch between the items of a CU (kernel comment; measured

@@ -14,6 +14,12 @@ static int conv_f16x2_4x64(ConvArgs a, hipStream_t s) {
   a.cot0 = rest;
   return conv_igemm_bf16x3_launch<4, 64, UPS, 2>(a, s);
 }
+// 32-row channel tiles (block config F as the tile id: 32 channels x 256 positions; weights packed for BM = 32): layers with at
+// most 32 output channels per tile row -- the WarpGenerator's last 3-D block, stage 2's 32-channel ResBlocks
+conv_launch_fn conv_lookup_f16x2_3x3_bm32(int Wl, int ups) {
+  if (Wl % 64 == 0 && !ups) return &conv_igemm_bf16x3_launch<4, 64, false, 2, 32>;
+  return nullptr;
+}
 conv_launch_fn conv_lookup_f16x2_3x3(int Wl, int ups) {
   if (Wl % 64 == 0) return ups ? &conv_f16x2_4x64<true> : &conv_f16x2_4x64<false>;
   if (Wl == 32 && !ups) return &conv_igemm_bf16x3_launch<8, 32, false, 2>;

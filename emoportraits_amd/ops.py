@@ -336,7 +336,9 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
             rc = lib.emo_conv_igemm_f32_guarded(hip.ptr(x), hip.ptr(layer.packed(gcfg)), *gcommon, flag)
             hip.check(rc, f"emo_conv_igemm_f32_guarded[{layer.name}]")
         elif F16X2_GUARD:
-            rc = lib.emo_conv_igemm_bf16x3(hip.ptr(x), hip.ptr(layer.packed(cfg, "bf16x3")), *common, flag)
+            # (the exact recomputation runs the 64-row tile of the bf16 split whatever tile the fp16-split launch used)
+            gcommon = common[:18] + (pack_mod.CFG_D,) + common[19:]
+            rc = lib.emo_conv_igemm_bf16x3(hip.ptr(x), hip.ptr(layer.packed(pack_mod.CFG_D, "bf16x3")), *gcommon, flag)
             hip.check(rc, f"emo_conv_igemm_bf16x3[{layer.name}, guarded]")
     else:
         extra = (None,) if prec == "bf16x3" else ()

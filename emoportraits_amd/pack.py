@@ -135,6 +135,7 @@ def pack_weight_bf16x3(w):
 
 
 F16X2_GUARD_DEFAULT = __import__("os").environ.get("EMO_F16X2_GUARD", "1") != "0"   # ops.F16X2_GUARD starts from this
+F16X2_BM32 = __import__("os").environ.get("EMO_F16X2_BM32", "1") != "0"   # A/B switch: 32-channel layers on the half-empty 64-row tile
 F16X2_POINTWISE = __import__("os").environ.get("EMO_F16X2_POINTWISE", "1") != "0"   # A/B switch: 1x1 layers of an f16x2 model on the fp32 MFMA kernel
 F16X2_IN_SCALE = 32.0      # emo_conv_igemm_f16x2: the staged input is multiplied by this (inputs beyond +-2047 saturate)
 
@@ -182,15 +183,18 @@ def overflow_events(device):
     return {s: pool[2].get(s) for s in raised}
 
 
-def pack_weight_f16x2(w):
+def pack_weight_f16x2(w, bm=None):
     """operand layout of emo_conv_igemm_f16x2: the bf16x3 layout with two fp16 planes of w * w_scale, w_scale = the power of
-    two that puts max|w| into [512, 1024) -> (flat fp16 tensor, w_scale)"""
+    two that puts max|w| into [512, 1024) -> (flat fp16 tensor, w_scale).  bm: channel tile height, 64 (block config D) or 32
+    (block config F: layers with at most 32 output channels per tile)"""
     if w.dim() == 4:
         w = w.unsqueeze(2)
     cout, cin, kd, kh, kw = w.shape
     if (kh, kw) != (3, 3):
         raise ValueError("3x3 kernels only")
-    bm, kc = BF16X3_BM, BF16X3_KC
+    bm, kc = (BF16X3_BM if bm is None else bm), BF16X3_KC
+    if bm not in (32, 64):
+        raise ValueError("channel tiles of 64 or 32 rows")
     n_cot = -(-cout // bm)
     n_cc = -(-cin // kc)
     wmax = float(w.abs().max())
@@ -375,7 +379,15 @@ def supports_bf16x3(cout, cin, kd, kh, kw, precision="bf16x3"):
     tile are twelve per useful one), at least half real in the fp16 split (three products: the 32-channel 3-D layers of the
     WarpGenerator run 1.6x the fp32 MFMA kernel's speed on a half-empty tile)"""
     fill = cout / (-(-cout // BF16X3_BM) * BF16X3_BM)
+    if precision == "f16x2" and F16X2_BM32 and cout <= 32:      # (a 32-row tile; also the 3-channel warp head: a tenth of the tile is
+        fill = 1.0                                              # real, and it is still 3x the fp32 MFMA kernel's 32-row tile)
     return (kh, kw) == (3, 3) and kd in (1, 3) and cin % 8 == 0 and fill >= (0.5 if precision == "f16x2" else 0.75)
+
+
+def f16x2_tile_cfg(cout):
+    """block config of an fp16-split 3x3 layer: F (32 channels x 256 positions, csrc/conv_igemm_bf16x3.h BMT = 32) for layers
+    with at most 32 output channels -- they ran the 64-row tile half empty --, D (64 x 256) otherwise"""
+    return CFG_F if (F16X2_BM32 and cout <= 32) else CFG_D
 
 
 def supports_f16x2_pointwise(cout, cin, kd, kh, kw):
@@ -472,7 +484,10 @@ class PackedConv:
             return self._packed["bf16x3"]
         if precision == "f16x2":
             if "f16x2" not in self._packed:
-                flat, self.w_scale = (pack_weight_f16x2_1x1 if self.pointwise_split else pack_weight_f16x2)(self._weight)
+                if self.pointwise_split:
+                    flat, self.w_scale = pack_weight_f16x2_1x1(self._weight)
+                else:
+                    flat, self.w_scale = pack_weight_f16x2(self._weight, bm=_BM[f16x2_tile_cfg(self.cout)])
                 self._packed["f16x2"] = flat.to(self.device)
             return self._packed["f16x2"]
         cfg = _PACK_AS.get(cfg, cfg)
@@ -504,8 +519,14 @@ class PackedConv:
                 return CFG_D, 1, "f16x2"
         elif self.precision in ("bf16x3", "f16x2") and bf16x3_launch_fits(Hl, Wl, ups) and self.pinned_cfg in (None, CFG_D) \
                 and aligned16 and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
-            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (CFG_D,), self.precision)
-            return cfg, ks, self.precision
+            tile = CFG_D
+            if self.precision == "f16x2" and f16x2_tile_cfg(self.cout) == CFG_F:
+                # (the weights are packed for the 32-row tile, which exists for 4 x 64 position tiles without fused upsample:
+                # other maps of such a layer run the fp32 MFMA kernel)
+                tile = CFG_F if (Wl % 64 == 0 and not ups) else None
+            if tile is not None:
+                cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (tile,), self.precision)
+                return cfg, ks, self.precision
         pinned = None if self.pinned_cfg == CFG_G else self.pinned_cfg   # (G exists for fp16 operands only)
         allowed = (pinned,) if pinned is not None else self.allowed
         if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl):

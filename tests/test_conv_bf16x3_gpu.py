@@ -33,9 +33,64 @@ CASES = [
 ]
 
 
+BM32_CASES = [
+    dict(N=2, Cin=64, Cout=32, dims=(8, 64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),      # the WarpGenerator's layers
+    dict(N=1, Cin=32, Cout=32, dims=(128, 128), k=3, cfg=3, affine=True, relu_in=True),
+    dict(N=3, Cin=16, Cout=32, dims=(16, 64), k=3, cfg=3, bias=False, res=True),                        # one stage per item
+    dict(N=2, Cin=48, Cout=24, dims=(32, 64), k=3, cfg=3, affine=True, relu_in=True),                   # ragged channel tile
+    dict(N=6, Cin=32, Cout=32, dims=(64, 128), k=3, cfg=3, affine=True, relu_in=True, res=True),        # 768 items: chains
+    dict(N=2, Cin=32, Cout=3, dims=(4, 64, 64), k=3, cfg=3, affine=True, relu_in=True, act="tanh"),     # the warp head
+]
+
+
+@pytest.mark.parametrize("case", BM32_CASES)
+def test_fp16_split_on_32_row_channel_tiles(case):
+    """layers with at most 32 output channels run a 32-row channel tile (csrc/conv_igemm_bf16x3.h, BMT = 32; block config F as
+    the tile id) instead of a half-empty 64-row one: same bound, deterministic, and the launch plan says so"""
+    e, got, ref = run_conv(seed=31, precision="f16x2", **case)
+    print("PARITY conv f16x2, 32-row channel tiles:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    assert e < 2e-5, e
+    e2, got2, _ = run_conv(seed=31, precision="f16x2", **case)
+    assert torch.equal(got, got2), "two launches on the same input differ: a race in the pipeline"
+    layer = pack.PackedConv("t", torch.randn(case["Cout"], case["Cin"], *([3] * len(case["dims"]))), None, DEV, precision="f16x2")
+    assert layer.plan_for(64, case["dims"][-2], case["dims"][-1])[0] == (pack.CFG_F if pack.F16X2_BM32 else pack.CFG_D)
+
+
+def test_fp16_split_32_row_tiles_statistics_and_range_check():
+    """tile statistics from the 32-row tile give the GroupNorm affine of a direct reduction; an out-of-range input raises the
+    overflow word and the guarded bf16x3 launch (64-row tile) rewrites output and statistics: bit-identical to a plain bf16x3 launch"""
+    g = torch.Generator().manual_seed(39)
+    N, Cin, Cout, H, W = 2, 64, 32, 16, 64
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    x = torch.randn(N, Cin, H, W, generator=g)
+    l2 = pack.PackedConv("bm32", w, b, DEV, precision="f16x2")
+    ops.clear_overflow_flags(DEV)
+    out, st = ops.conv_igemm(x.to(DEV), l2, relu_in=True, want_stats=True)
+    assert ops.overflow_events(DEV) == {} and rel_err(out, F.conv2d(F.relu(x), w, b, padding=1)) < 2e-5
+    s1, h1 = ops.groupnorm_affine(out, stats=st)
+    s0, h0 = ops.groupnorm_affine(out)
+    assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item() and (h1 - h0).abs().max().item() <= 2e-6
+    xa = x.clone()
+    xa[1, 7, 5, 33] = 5000.0
+    got, sg = ops.conv_igemm(xa.to(DEV), l2, relu_in=True, want_stats=True)
+    assert list(ops.overflow_events(DEV).values()) == ["bm32"]
+    # the exact launch the guard issued, on its own: the bf16 split on the (half-empty) 64-row tile
+    want = torch.empty_like(got)
+    stw = torch.empty_like(sg.stats)
+    from emoportraits_amd import hip
+    lib = hip.load()
+    rc = lib.emo_conv_igemm_bf16x3(hip.ptr(xa.to(DEV)), hip.ptr(l2.packed(pack.CFG_D, "bf16x3")), hip.ptr(l2.bias), None, None, None,
+                                   hip.ptr(want), N, Cin, Cout, 1, H, W, 1, 3, 3, 0, 1, 0, 0, pack.CFG_D, 1, None, hip.ptr(stw),
+                                   hip.current_stream(), None)
+    hip.check(rc, "emo_conv_igemm_bf16x3")
+    assert torch.equal(got.cpu(), want.cpu()) and torch.equal(sg.stats.cpu(), stw.cpu())
+    ops.clear_overflow_flags(DEV)
+
+
 def test_fp16_split_on_a_half_empty_channel_tile():
-    """32 output channels on the 64-row tile (the WarpGenerator's last 3-D block: pack.supports_bf16x3(..., "f16x2")); the bf16
-    split declines such a layer"""
+    """32 output channels (the WarpGenerator's last 3-D block: pack.supports_bf16x3(..., "f16x2")) in the general epilogue's forms
+    (activation); the bf16 split declines such a layer"""
     for case in (dict(N=2, Cin=64, Cout=32, dims=(4, 64, 64), k=3, cfg=3, affine=True, relu_in=True, res=True),
                  dict(N=1, Cin=32, Cout=32, dims=(64, 64), k=3, cfg=3, affine=True, relu_in=True, act="tanh")):
         e, got, ref = run_conv(seed=23, precision="f16x2", **case)
