@@ -15,6 +15,12 @@
 //                                   from qv[par ^ 1] into P[par ^ 1] (3 + 3 + 2 units)
 //                          step 1  the weight pieces of stage cg + 1 into W[par ^ 1]
 //                          step 3  ONE barrier (everything in flight is drained: vmcnt(0)); the first fragments of stage cg + 1
+// (A stage is 1.5 k cycles of MFMA work -- shorter than a memory round trip: the kernel is latency-bound at ~ 4.4 k per stage.
+// Running the loads three stages ahead (issued behind the barrier into the buffer whose conversion just ended) was built and
+// measured, tools/session/r5_call14.sh: the loads then cross the loop's exit in flight, the compiler copies their destination
+// registers on the exit edge -- the audit's epilogue walk flags it -- and a first version declared the buffer dead at the top of
+// the item loop: every chained item converted garbage, raised its overflow word, and was silently recomputed by the guarded
+// fp32 launch (correct results at a third of the speed).  Reverted; the fix is a peeled last stage.)
 // Items of a persistent block are chained (even stage counts), the epilogue is conv_igemm_bf16x3.h's straight-line form, run
 // per channel tile; it transposes through the patch buffer the last stage read.  A layer with an odd number of channel tiles
 // (320 = 5 x 64) runs its last tile in a pair whose second half computes on zero weights and is not written.

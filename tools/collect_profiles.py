@@ -88,10 +88,10 @@ def traffic(prefix, label, dst, suffix=None):
 traffic("conv_igemm_kernel", "conv_igemm_kernel (fp32 MFMA, all instantiations)", f"{tag}_pmc_conv_traffic.json")
 # the split kernel's two operand modes are instantiations of one template: <TR, TW, UPS, SPLIT>.  A default (f16x2) run also holds
 # the guarded bf16x3 launches, which leave at once: they would dilute a per-launch figure, so only a bf16x3 run's trace is used
-if any(k.startswith("conv_igemm_bf16x3_kernel") and ", 2>" in k for k in f):
+if any(k.startswith("conv_igemm_bf16x3_ct2_kernel") or __import__("re").match(r"conv_igemm_bf16x3_kernel<\d+, \d+, (?:true|false), 2", k) for k in f):
     # (default mode, round 5: a layer is up to two kernels + its guarded launch -- tools/collect_traffic.py sums them per LAYER
     # launch and records the hash of the kernel sources, which bench.py checks before quoting the file)
     os.system(f"{sys.executable} tools/collect_traffic.py {tag}")
 else:
     traffic("conv_igemm_bf16x3_kernel", "conv_igemm_bf16x3_kernel (fp32 3x3 conv on the bf16 matrix pipes, all instantiations)",
-            f"{tag}_pmc_conv_bf16x3_traffic.json", suffix=", 3>")
+            f"{tag}_pmc_conv_bf16x3_traffic.json", suffix=", 3")

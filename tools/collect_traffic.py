@@ -22,8 +22,10 @@ for n, d in (("fetch", f), ("write", w), ("mfma", m)):
     json.dump(d, open(p + f"{tag}_pmc_{n}.json", "w"), indent=1, sort_keys=True)
 shutil.copy(g + f"{tag}_kernel_stats.csv", p + f"{tag}_bench_kernel_stats.csv")
 rows = list(csv.DictReader(open(p + f"{tag}_bench_kernel_stats.csv")))
-split = lambda k: k.startswith("conv_igemm_bf16x3_ct2_kernel") or (k.startswith("conv_igemm_bf16x3_kernel") and ", 2>" in k)
-guard = lambda k: k.startswith("conv_igemm_bf16x3_kernel") and ", 3>" in k
+import re
+_mode = lambda k: (re.match(r"conv_igemm_bf16x3_kernel<\d+, \d+, (?:true|false), (\d)", k) or [None, None])[1]   # <TR, TW, UPS, SPLIT[, BMT]>
+split = lambda k: k.startswith("conv_igemm_bf16x3_ct2_kernel") or _mode(k) == "2"
+guard = lambda k: _mode(k) == "3"
 ks = [k for k in f if split(k)]
 layers = sum(f[k]["FETCH_SIZE"]["launches"] for k in f if guard(k))
 tf = sum(f[k]["FETCH_SIZE"]["sum"] for k in ks)

@@ -238,7 +238,7 @@ def loop_scratch(src):
                 # vmcnt model, and flags a copy or spill of any register whose pinned load may not have landed
                 lo = mf[0] if mf else 10 ** 9
                 inside = [i for i in sc if mf and lo < i < mf[-1]]
-                out.append((name, len(inside), len(sc), inflight_reads(lines, walk_epilogue="conv_igemm_bf16x3_kernel" in name)
+                out.append((name, len(inside), len(sc), inflight_reads(lines, walk_epilogue="conv_igemm_bf16x3" in name)
                             + [(ln, t + "   [scalar operand %s written by the vector ALU %d wait states before]" % (r, a), [])
                                for ln, t, r, a in sgpr_hazards(lines)]))
             m = re.search(r"Begin function (\S+)", line)
