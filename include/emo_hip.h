@@ -240,6 +240,12 @@ int emo_conv_igemm_f16x2(const float* x, const void* wpk2, const float* bias,
  * and overflow_flag as above; the guarded exact recomputation behind it is
  * emo_conv_igemm_f32_guarded: emo_conv_igemm_f32 with run_if (NULL, or a device word: the launch does nothing unless
  * *run_if != 0 when it starts executing), same stream, launched right after the fp16-split launch. */
+/* ABI 7, also: emo_conv_igemm_f16x2 takes cfg 5 (block config F: 32 channels x 256 positions) for 3x3 / 3x3x3 layers -- a 32-row
+ * channel tile for layers with at most 32 output channels (the WarpGenerator's last 3-D block and its 3-channel head,
+ * warp_generator_resnet.py:95-123; stage 2's 32-channel ResBlocks), which ran the 64-row tile half empty.  wpk2 is then packed
+ * with BM = 32 (emoportraits_amd.pack.pack_weight_f16x2(w, bm=32)); 4 x 64 position tiles (W % 64 == 0, H % 4 == 0), no fused
+ * upsample.  The guarded recomputation of such a layer is emo_conv_igemm_bf16x3 with cfg 3 and the BM = 64 weights, as for
+ * every 3x3 layer. */
 int emo_conv_igemm_f32_guarded(const float* x, const float* wpk, const float* bias,
                                const float* scale, const float* shift, const float* res, float* out,
                                int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
