@@ -195,6 +195,25 @@ extern "C" int emo_groupnorm_affine_f32(const float* x, int N, int C, int64_t S,
   return emo_launch_status();
 }
 
+// The second half of emo_groupnorm_affine_f32 alone: `partial` holds `split` (sum, sum of squares) slices per (sample, group)
+// in the workspace layout ([N * G][64][2] doubles), left there by a producer that had the tensor in its registers anyway
+// (emo_upsample_trilinear_gn_sums_f32, resample.hip).  S = elements per (sample, channel) of the tensor the sums are of.
+extern "C" int emo_groupnorm_affine_from_sums_f32(const void* partial, int split, int N, int C, int64_t S, int G, float eps,
+                                                  const float* gamma, const float* beta, const float* ada_gamma,
+                                                  const float* ada_beta, int64_t ada_stride, float* scale, float* shift,
+                                                  float* mean_out, float* rstd_out, void* stream) {
+  if (!partial || !scale || !shift) return EMO_ERR_BAD_ARG;
+  if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G || split < 1 || split > GN_MAX_SPLIT) return EMO_ERR_BAD_ARG;
+  if ((ada_gamma == nullptr) != (ada_beta == nullptr)) return EMO_ERR_BAD_ARG;
+  if ((mean_out == nullptr) != (rstd_out == nullptr)) return EMO_ERR_BAD_ARG;
+  if ((long)N * G > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  const long L = (long)(C / G) * S;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(emo_cdiv((long)N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const double*>(partial), split, N, C, G, L, eps, gamma, beta, ada_gamma, ada_beta,
+                     (long)ada_stride, scale, shift, mean_out, rstd_out);
+  return emo_launch_status();
+}
+
 extern "C" int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_t T, int cnt, int G, float eps,
                                                    const float* gamma, const float* beta, const float* ada_gamma,
                                                    const float* ada_beta, int64_t ada_stride, float* scale, float* shift,

@@ -55,40 +55,46 @@ __global__ __launch_bounds__(256) void upsample_trilinear_kernel(const float* __
 
 // The same for a width factor of 2 and an even input width (every call of the driver pass).  The generic kernel spends three
 // 64-bit divisions, eight 4-byte loads and a 4-byte store on every output and is bound by the CU's vector-memory instruction
-// rate at a fifth of the HBM rate of its bytes (4 launches of ~0.3 ms per step: 2.3 % of the driver pass).  Here one thread
-// produces a BLOCK of outputs that share their inputs: four consecutive columns 4m .. 4m + 3 (input columns 2m - 1 .. 2m + 2)
-// x the output rows 2k - 1, 2k (both interpolate the input rows k - 1, k; a factor-1 axis: one row) x the same pairing in
-// depth -- up to 16 outputs from 16 loads, written with four 16-byte stores.  Same coefficients and order of operations per
-// output as the generic kernel (ATen's); where the two outputs of a pair do not share their taps (first / last pair of an
-// axis: clamped source index) and in the first / last quad of a row the outputs are computed one by one, exactly as there.
-__device__ __forceinline__ float trilerp_at(const float* __restrict__ p, long HW, int W, int z0, int z1, int y0, int y1, int x0,
-                                            int x1, float lz0, float lz1, float ly0, float ly1, float lx0, float lx1) {
-  const float v000 = p[z0 * HW + y0 * W + x0], v001 = p[z0 * HW + y0 * W + x1];
-  const float v010 = p[z0 * HW + y1 * W + x0], v011 = p[z0 * HW + y1 * W + x1];
-  const float v100 = p[z1 * HW + y0 * W + x0], v101 = p[z1 * HW + y0 * W + x1];
-  const float v110 = p[z1 * HW + y1 * W + x0], v111 = p[z1 * HW + y1 * W + x1];
-  const float a = lz0 * (ly0 * (lx0 * v000 + lx1 * v001) + ly1 * (lx0 * v010 + lx1 * v011));
-  const float b = lz1 * (ly0 * (lx0 * v100 + lx1 * v101) + ly1 * (lx0 * v110 + lx1 * v111));
-  return a + b;
-}
+// rate at a fifth of the HBM rate of its bytes.  Here one thread produces a BLOCK of outputs that share their inputs: four
+// consecutive columns 4m .. 4m + 3 (input columns 2m - 1 .. 2m + 2) x the output rows 2k - 1, 2k (both interpolate the input
+// rows k - 1, k; a factor-1 axis: one row) x the same pairing in depth -- up to 16 outputs from 16 loads (8 where the depth or
+// the height factor is 1: both taps of that axis are the same row), written with four 16-byte stores.  Same coefficients and
+// order of operations per output as the generic kernel (ATen's).
+//   * First / last quad of a row: the input columns are clamped into the row, which IS the tap of the generic kernel there
+//     (last column: x0 = x1 = W - 1); the first output of a row (source index clamped to 0: taps 0 and 1, weights 1 and 0) takes
+//     its two values one register further right.  Round 4 sent those two quads of every row through the one-output-at-a-time
+//     code -- 2 lanes in 16, so EVERY wave ran both paths, the second one with 128 scalar loads: 1.7 TB/s of the kernel's bytes.
+//   * The first / last pair of an axis has one valid output (2k - 1 = -1, or 2k = 2 * in): its taps are used; two valid outputs
+//     of a pair always share theirs (src = k - 0.75 and k - 0.25: both between the rows k - 1 and k).
+//   * Work is laid out as runs of `cr` consecutive (sample, channel) volumes x `split` slices of a run's thread blocks
+//     (grid = runs x split).  STATS: a run is a GroupNorm group (cr = C / G channels: one contiguous reduction domain of the
+//     OUTPUT), and every block leaves the fp64 (sum, sum of squares) of the outputs it produced in partial[run][slice] -- the
+//     layout gn_partial_kernel (groupnorm.hip) writes, so the norm in front of the next convolution needs no pass of its own
+//     over the upsampled tensor (WarpGenerator: warp_generator_resnet.py:163-166 -> ResBlock3d's first norm).
+constexpr int UPS_MAX_SPLIT = 64;         // == GN_MAX_SPLIT (groupnorm.hip): the partial-sum layout [run][64][2]
 
+template <bool STATS>
 __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                                     unsigned nblocks, int D, int H, int W, int fd, int fh) {
+                                                                     unsigned qrun, unsigned per, unsigned cr, int D, int H,
+                                                                     int W, int fd, int fh, double* __restrict__ partial) {
   const int Do = D * fd, Ho = H * fh;
   const unsigned Wq = (unsigned)W >> 1;                      // quads per output row: 2 W / 4
   const unsigned Ky = fh == 2 ? H + 1 : H, Kz = fd == 2 ? D + 1 : D;   // pairs (2k - 1, 2k), k = 0 .. in; or single rows
   const long HW = (long)H * W;
-  for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < nblocks; q += gridDim.x * 256u) {
+  const unsigned run = blockIdx.x, sp = blockIdx.y;
+  const unsigned lo = sp * per, hi = lo + per < qrun ? lo + per : qrun;
+  double s_sum = 0.0, s_sq = 0.0;
+  for (unsigned q = lo + threadIdx.x; q < hi; q += 256u) {
     const unsigned xq = q % Wq;
     unsigned r = q / Wq;
     const unsigned ky = r % Ky; r /= Ky;
     const unsigned kz = r % Kz;
-    const unsigned nc = r / Kz;
+    const long nc = (long)run * cr + r / Kz;
     // the (up to two) outputs of the pair along y and z: first = 2k - 1 (factor 2) or k (factor 1)
     const int ya = fh == 2 ? 2 * (int)ky - 1 : (int)ky, za = fd == 2 ? 2 * (int)kz - 1 : (int)kz;
     const int ny = fh == 2 ? 2 : 1, nz = fd == 2 ? 2 : 1;
-    const float* p = x + (long)nc * D * HW;
-    float* const o = out + (long)nc * Do * Ho * (2l * W) + 4 * xq;
+    const float* p = x + nc * D * HW;
+    float* const o = out + nc * Do * Ho * (2l * W) + 4 * xq;
     int yi0[2], yi1[2], zi0[2], zi1[2];
     float yl0[2], yl1[2], zl0[2], zl1[2];
     bool yv[2], zv[2];
@@ -101,59 +107,99 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
       lin_coeff(zv[e] ? zo : 0, D, fd, zi0[e], zi1[e], zl0[e], zl1[e]);
     }
     const int xb = 2 * (int)xq - 1;
-    // shared taps: both outputs of a pair valid with the same (i0, i1) -- or a single output; and an interior quad
-    const bool ysh = !(yv[0] && yv[1]) || (yi0[0] == yi0[1] && yi1[0] == yi1[1]);
-    const bool zsh = !(zv[0] && zv[1]) || (zi0[0] == zi0[1] && zi1[0] == zi1[1]);
-    if (ysh && zsh && xb >= 0 && xb + 3 <= W - 1) {
-      const int ey = yv[0] ? 0 : 1, ez = zv[0] ? 0 : 1;       // (a pair has at least one valid output)
-      const float* r00 = p + zi0[ez] * HW + (long)yi0[ey] * W + xb;
-      const float* r01 = p + zi0[ez] * HW + (long)yi1[ey] * W + xb;
-      const float* r10 = p + zi1[ez] * HW + (long)yi0[ey] * W + xb;
-      const float* r11 = p + zi1[ez] * HW + (long)yi1[ey] * W + xb;
-      float a00[4], a01[4], a10[4], a11[4];
+    const int ey = yv[0] ? 0 : 1, ez = zv[0] ? 0 : 1;         // (a pair has at least one valid output)
+    int col[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a00[k] = r00[k]; a01[k] = r01[k]; a10[k] = r10[k]; a11[k] = r11[k]; }
-      int k0[4];
-      float lx0[4], lx1[4];
+    for (int k = 0; k < 4; ++k) { const int c = xb + k; col[k] = c < 0 ? 0 : (c > W - 1 ? W - 1 : c); }
+    const float* r00 = p + zi0[ez] * HW + (long)yi0[ey] * W;
+    float a00[4], a01[4], a10[4], a11[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int x0, x1;
-        lin_coeff(4 * (int)xq + j, W, 2, x0, x1, lx0[j], lx1[j]);
-        k0[j] = (j + 1) >> 1;                                   // x0 - xb (x1 = x0 + 1)
-      }
+    for (int k = 0; k < 4; ++k) a00[k] = r00[col[k]];
+    if (fh == 2) {
+      const float* r01 = p + zi0[ez] * HW + (long)yi1[ey] * W;
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (!(zv[c] && yv[e])) continue;
-          float res[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int u = (j + 1) >> 1;
-            const float a = zl0[c] * (yl0[e] * (lx0[j] * a00[u] + lx1[j] * a00[u + 1]) + yl1[e] * (lx0[j] * a01[u] + lx1[j] * a01[u + 1]));
-            const float b = zl1[c] * (yl0[e] * (lx0[j] * a10[u] + lx1[j] * a10[u + 1]) + yl1[e] * (lx0[j] * a11[u] + lx1[j] * a11[u + 1]));
-            res[j] = a + b;
-          }
-          *reinterpret_cast<float4*>(o + ((long)(za + c) * Ho + (ya + e)) * (2l * W)) = make_float4(res[0], res[1], res[2], res[3]);
-        }
+      for (int k = 0; k < 4; ++k) a01[k] = r01[col[k]];
     } else {
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int k = 0; k < 4; ++k) a01[k] = a00[k];            // (factor 1: i1 == i0)
+    }
+    if (fd == 2) {
+      const float* r10 = p + zi1[ez] * HW + (long)yi0[ey] * W;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (!(zv[c] && yv[e])) continue;
-          float res[4];
+      for (int k = 0; k < 4; ++k) a10[k] = r10[col[k]];
+      if (fh == 2) {
+        const float* r11 = p + zi1[ez] * HW + (long)yi1[ey] * W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a11[k] = r11[col[k]];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a11[k] = a10[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a10[k] = a00[k]; a11[k] = a01[k]; }
+    }
+    float lx0[4], lx1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      lin_coeff(4 * (int)xq + j, W, 2, x0, x1, lx0[j], lx1[j]);
+    }
+    // the first output of a row: taps (0, 1) = registers 1, 2 (register 0 holds the clamped column -1)
+    const bool le = xq == 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!(zv[c] && yv[e])) continue;
+        float res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int u = (j + 1) >> 1;
+          float p00 = a00[u], q00 = a00[u + 1], p01 = a01[u], q01 = a01[u + 1];
+          float p10 = a10[u], q10 = a10[u + 1], p11 = a11[u], q11 = a11[u + 1];
+          if (j == 0) {
+            p00 = le ? a00[1] : p00; q00 = le ? a00[2] : q00; p01 = le ? a01[1] : p01; q01 = le ? a01[2] : q01;
+            p10 = le ? a10[1] : p10; q10 = le ? a10[2] : q10; p11 = le ? a11[1] : p11; q11 = le ? a11[2] : q11;
+          }
+          const float a = zl0[c] * (yl0[e] * (lx0[j] * p00 + lx1[j] * q00) + yl1[e] * (lx0[j] * p01 + lx1[j] * q01));
+          const float b = zl1[c] * (yl0[e] * (lx0[j] * p10 + lx1[j] * q10) + yl1[e] * (lx0[j] * p11 + lx1[j] * q11));
+          res[j] = a + b;
+        }
+        *reinterpret_cast<float4*>(o + ((long)(za + c) * Ho + (ya + e)) * (2l * W)) = make_float4(res[0], res[1], res[2], res[3]);
+        if constexpr (STATS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            int x0, x1;
-            float l0, l1;
-            lin_coeff(4 * (int)xq + j, W, 2, x0, x1, l0, l1);
-            res[j] = trilerp_at(p, HW, W, zi0[c], zi1[c], yi0[e], yi1[e], x0, x1, zl0[c], zl1[c], yl0[e], yl1[e], l0, l1);
+            const double v = (double)res[j];
+            s_sum += v;
+            s_sq += v * v;
           }
-          *reinterpret_cast<float4*>(o + ((long)(za + c) * Ho + (ya + e)) * (2l * W)) = make_float4(res[0], res[1], res[2], res[3]);
         }
+      }
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s_sum += __shfl_down(s_sum, o, 64); s_sq += __shfl_down(s_sq, o, 64); }
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s_sum; red[1][wave] = s_sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* pp = partial + ((long)run * UPS_MAX_SPLIT + sp) * 2;
+      pp[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+      pp[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
   }
+}
+
+// launch plan of the block kernel: runs x slices, a slice >= 2048 thread blocks of outputs where the run is that long
+inline bool ups_w2_plan(long runs, long qrun, unsigned& split, unsigned& per) {
+  if (runs < 1 || runs > 0x7fffffffL || qrun < 1 || qrun >= (1l << 31)) return false;
+  long sp = (qrun + 2047) / 2048;
+  sp = sp < 1 ? 1 : (sp > UPS_MAX_SPLIT ? UPS_MAX_SPLIT : sp);
+  split = (unsigned)sp;
+  per = (unsigned)((qrun + sp - 1) / sp);
+  return true;
 }
 
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ out, long NC,
@@ -274,14 +320,39 @@ extern "C" int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC
   if (!x || !out || NC <= 0 || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
   if ((fd != 1 && fd != 2) || (fh != 1 && fh != 2) || (fw != 1 && fw != 2)) return EMO_ERR_UNSUPPORTED;
   const long total = NC * D * fd * H * fh * W * fw;
-  const long nblk = NC * (fd == 2 ? D + 1 : D) * (fh == 2 ? H + 1 : H) * (W / 2);
-  if (fw == 2 && (W & 1) == 0 && nblk < (1l << 32) && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-    hipLaunchKernelGGL(upsample_trilinear_w2_kernel, dim3(grid_for(nblk)), dim3(256), 0, (hipStream_t)stream, x, out,
-                       (unsigned)nblk, D, H, W, fd, fh);
+  const long qvol = (long)(fd == 2 ? D + 1 : D) * (fh == 2 ? H + 1 : H) * (W / 2);      // thread blocks of outputs per volume
+  long cr = 1;                                                                         // volumes per run: small ones in groups
+  while (qvol * cr < 2048 && NC % (2 * cr) == 0) cr *= 2;
+  unsigned split, per;
+  if (fw == 2 && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ups_w2_plan(NC / cr, qvol * cr, split, per)) {
+    hipLaunchKernelGGL(upsample_trilinear_w2_kernel<false>, dim3((unsigned)(NC / cr), split), dim3(256), 0, (hipStream_t)stream,
+                       x, out, (unsigned)(qvol * cr), per, (unsigned)cr, D, H, W, fd, fh, (double*)nullptr);
     return emo_launch_status();
   }
   hipLaunchKernelGGL(upsample_trilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out,
                      (long)NC, D, H, W, fd, fh, fw);
+  return emo_launch_status();
+}
+
+// The upsampling with the GroupNorm statistics of its OUTPUT reduced on the way: out as emo_upsample_trilinear_f32, and in
+// `partial` ([N * G][64][2] doubles: emo_groupnorm_workspace_bytes(N, G)) the (sum, sum of squares) slices of every (sample,
+// group) in the layout emo_groupnorm_affine_from_sums_f32 (groupnorm.hip) finishes; *split_out = the slices written per group.
+// Width factor 2, an even input width and a 16-byte aligned output only (EMO_ERR_UNSUPPORTED otherwise: the caller runs the
+// two operations one after the other).
+extern "C" int emo_upsample_trilinear_gn_sums_f32(const float* x, float* out, int N, int C, int G, int D, int H, int W, int fd,
+                                                  int fh, int fw, void* partial, int64_t partial_bytes, int* split_out,
+                                                  void* stream) {
+  if (!x || !out || !partial || !split_out || N <= 0 || C <= 0 || G <= 0 || C % G || D <= 0 || H <= 0 || W <= 0) return EMO_ERR_BAD_ARG;
+  if ((fd != 1 && fd != 2) || (fh != 1 && fh != 2) || fw != 2 || (W & 1)) return EMO_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return EMO_ERR_UNSUPPORTED;
+  if (partial_bytes < (int64_t)N * G * UPS_MAX_SPLIT * 2 * (int64_t)sizeof(double)) return EMO_ERR_BAD_ARG;
+  const unsigned cpg = (unsigned)(C / G);
+  const long qrun = (long)cpg * (fd == 2 ? D + 1 : D) * (fh == 2 ? H + 1 : H) * (W / 2);
+  unsigned split, per;
+  if (!ups_w2_plan((long)N * G, qrun, split, per)) return EMO_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(upsample_trilinear_w2_kernel<true>, dim3((unsigned)(N * G), split), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (unsigned)qrun, per, cpg, D, H, W, fd, fh, reinterpret_cast<double*>(partial));
+  *split_out = (int)split;
   return emo_launch_status();
 }
 

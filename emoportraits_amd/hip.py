@@ -29,6 +29,8 @@ SIGNATURES = {
                                 + [_c_void] * 5 + [_c_i64, _c_void],
     "emo_groupnorm_affine_from_tiles_f32": [_c_void, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_float] + [_c_void] * 4
                                            + [_c_i64] + [_c_void] * 5,
+    "emo_groupnorm_affine_from_sums_f32": [_c_void, _c_int, _c_int, _c_int, _c_i64, _c_int, _c_float] + [_c_void] * 4
+                                          + [_c_i64] + [_c_void] * 5,
     "emo_conv_pack_info": [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
     "emo_conv_tile_positions": [_c_int],
     "emo_conv_igemm_f32": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void],
@@ -40,6 +42,7 @@ SIGNATURES = {
     "emo_conv_igemm_f16x2": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, ctypes.c_float, ctypes.c_float, _c_void],
     "emo_conv_igemm_f32_guarded": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, _c_void],
     "emo_upsample_trilinear_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
+    "emo_upsample_trilinear_gn_sums_f32": [_c_void, _c_void] + [_c_int] * 9 + [_c_void, _c_i64, ctypes.POINTER(_c_int), _c_void],
     "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_add_f32": [_c_void, _c_void, _c_void, _c_i64, _c_i64, _c_float, _c_void],
     "emo_resize2d_f32": [_c_void, _c_i64, _c_i64, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],

@@ -175,9 +175,11 @@ class WarpGenerator:
             depth_new = min(self.out_depth * 2 ** (self.n_depth_resize - i), size[1]) if i < self.n_depth_resize else self.out_depth
             up, down = depth_new > size[0], depth_new < size[0]
             size[0] = depth_new
-            x = ops.upsample_trilinear(x, (2, 2, 2) if up else (1, 2, 2))
+            # (the block's first norm takes its statistics from the upsampling kernel: no pass of its own over the big tensor)
+            fac = (2, 2, 2) if up else (1, 2, 2)
+            x, xs = (ops.upsample_trilinear(x, fac), None) if blk.n1.bn else ops.upsample_trilinear(x, fac, gn_groups=32)
             (a0, a1), (b0, b1) = self.slices[2 * (i - 1)], self.slices[2 * (i - 1) + 1]
-            x = blk(x, ada1=(ag[:, a0:a1], ab[:, a0:a1]), ada2=(ag[:, b0:b1], ab[:, b0:b1]))
+            x = blk(x, ada1=(ag[:, a0:a1], ab[:, a0:a1]), ada2=(ag[:, b0:b1], ab[:, b0:b1]), x_stats=xs)
             if down:
                 x = ops.avgpool(x, (2, 1, 1))
         s, h = self.nh.affine(x)

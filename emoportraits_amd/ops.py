@@ -5,6 +5,7 @@ the parity tests read like `ours(x) == torch_cpu(x)`.
 """
 import ctypes
 import functools
+import os
 
 import torch
 
@@ -208,7 +209,7 @@ def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, gr
     """scale, shift [N,C] such that GroupNorm(x) == x*scale + shift (per sample and channel).
     ada_gamma / ada_beta: [N, C] views (row stride arbitrary, unit column stride) of the adaptive weights.
     stats: the TileStats the producing conv_igemm(..., want_stats=True) returned for x -- the statistics are then
-    combined from the tiles and x itself is not read."""
+    combined from the tiles and x itself is not read; or the RunSums of upsample_trilinear(..., gn_groups=)."""
     lib = hip.load()
     hip.require_cuda_f32(x, gamma, beta)
     N, C = x.shape[0], x.shape[1]
@@ -220,7 +221,15 @@ def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, gr
     if want_stats:
         mean = torch.empty((N, groups), device=x.device, dtype=torch.float32)
         rstd = torch.empty((N, groups), device=x.device, dtype=torch.float32)
-    if stats is not None:
+    if isinstance(stats, RunSums):
+        if stats.shape != tuple(x.shape) or stats.groups != groups:
+            raise ValueError("run sums do not belong to this tensor")
+        rc = lib.emo_groupnorm_affine_from_sums_f32(hip.ptr(stats.partial), stats.split, N, C, S, groups, eps, hip.ptr(gamma),
+                                                    hip.ptr(beta), hip.ptr(ada_gamma), hip.ptr(ada_beta), ada_stride,
+                                                    hip.ptr(scale), hip.ptr(shift), hip.ptr(mean), hip.ptr(rstd),
+                                                    hip.current_stream())
+        hip.check(rc, "emo_groupnorm_affine_from_sums_f32")
+    elif stats is not None:
         T = stats.stats.shape[1]
         if tuple(stats.stats.shape) != (N, T, C, 2) or T * stats.cnt != S:
             raise ValueError("tile statistics do not belong to this tensor")
@@ -244,6 +253,15 @@ def groupnorm_affine(x, gamma=None, beta=None, ada_gamma=None, ada_beta=None, gr
 # ----------------------------------------------------------------------------------------------------------------
 # implicit-GEMM convolution
 # ----------------------------------------------------------------------------------------------------------------
+class RunSums:
+    """fp64 (sum, sum of squares) slices per (sample, group) of a tensor, in the GroupNorm workspace layout
+    ([N * G][64][2] doubles), written by the kernel that produced the tensor (upsample_trilinear(..., gn_groups=))."""
+    __slots__ = ("partial", "split", "shape", "groups")
+
+    def __init__(self, partial, split, shape, groups):
+        self.partial, self.split, self.shape, self.groups = partial, split, tuple(shape), groups
+
+
 class TileStats:
     """Per-tile GroupNorm statistics written by the conv epilogue: stats [N, T, C, 2] = (mean, centred sum of squares)
     of `cnt` output values per (sample, tile, channel).  Handed to groupnorm_affine(..., stats=) instead of the tensor."""
@@ -356,16 +374,29 @@ overflow_events = pack_mod.overflow_events
 # ----------------------------------------------------------------------------------------------------------------
 # resampling / pointwise
 # ----------------------------------------------------------------------------------------------------------------
-def upsample_trilinear(x, factors):
-    """F.interpolate(x, scale_factor=factors, mode='trilinear') for 5-D x, factors in {1,2}^3"""
+def upsample_trilinear(x, factors, gn_groups=None):
+    """F.interpolate(x, scale_factor=factors, mode='trilinear') for 5-D x, factors in {1,2}^3.
+    gn_groups: also return the RunSums of the OUTPUT for a GroupNorm of that many groups (reduced by the upsampling kernel
+    from the values it writes) -> (out, sums); sums is None where the fused kernel does not apply (width factor 1, odd width)."""
     lib = hip.load()
     hip.require_cuda_f32(x)
     N, C, D, H, W = x.shape
     fd, fh, fw = factors
     out = torch.empty((N, C, D * fd, H * fh, W * fw), device=x.device, dtype=torch.float32)
+    if gn_groups is not None and FUSE_UPSAMPLE_STATS and fw == 2 and W % 2 == 0 and C % gn_groups == 0:
+        ws, need = _gn_workspace(N, gn_groups, x.device)
+        split = ctypes.c_int(0)
+        hip.check(lib.emo_upsample_trilinear_gn_sums_f32(hip.ptr(x), hip.ptr(out), N, C, gn_groups, D, H, W, fd, fh, fw,
+                                                         hip.ptr(ws), need, ctypes.byref(split), hip.current_stream()),
+                  "emo_upsample_trilinear_gn_sums_f32")
+        return out, RunSums(ws, split.value, out.shape, gn_groups)
     hip.check(lib.emo_upsample_trilinear_f32(hip.ptr(x), hip.ptr(out), N * C, D, H, W, fd, fh, fw, hip.current_stream()),
               "emo_upsample_trilinear_f32")
-    return out
+    return (out, None) if gn_groups is not None else out
+
+
+# A/B switch (measurements only): 0 reduces the statistics of an upsampled tensor with a pass of its own, as round 4 did
+FUSE_UPSAMPLE_STATS = os.environ.get("EMO_FUSE_UPSAMPLE_STATS", "1") != "0"
 
 
 def avgpool(x, kernel):

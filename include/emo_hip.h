@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 7
+#define EMO_ABI_VERSION 8
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
@@ -131,6 +131,14 @@ int emo_groupnorm_affine_from_tiles_f32(const float* stats, int N, int C, int64_
                                         const float* gamma, const float* beta,
                                         const float* ada_gamma, const float* ada_beta, int64_t ada_stride,
                                         float* scale, float* shift, float* mean_out, float* rstd_out, void* stream);
+
+/* ABI 8.  The second half of emo_groupnorm_affine_f32 alone: `partial` = `split` (sum, sum of squares) fp64 slices per (sample,
+ * group), workspace layout [N * G][64][2], left by a producer that had the tensor in registers (emo_upsample_trilinear_gn_sums_f32);
+ * S = elements per (sample, channel) of the tensor the sums are of.  Other arguments as emo_groupnorm_affine_f32. */
+int emo_groupnorm_affine_from_sums_f32(const void* partial, int split, int N, int C, int64_t S, int G, float eps,
+                                       const float* gamma, const float* beta,
+                                       const float* ada_gamma, const float* ada_beta, int64_t ada_stride,
+                                       float* scale, float* shift, float* mean_out, float* rstd_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a5/a9/a10 -- implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
@@ -262,6 +270,14 @@ int emo_conv_igemm_f32_guarded(const float* x, const float* wpk, const float* bi
  */
 int emo_upsample_trilinear_f32(const float* x, float* out, int64_t NC, int D, int H, int W,
                                int fd, int fh, int fw, void* stream);
+/* ABI 8.  emo_upsample_trilinear_f32 with the GroupNorm statistics of its OUTPUT reduced on the way (WarpGenerator:
+ * F.interpolate -> ResBlock3d, whose first norm would otherwise read the upsampled tensor once more;
+ * warp_generator_resnet.py:163-166, utils.py:711-731).  x [N, C, D, H, W]; `partial` (>= emo_groupnorm_workspace_bytes(N, G)
+ * bytes) receives *split_out slices per (sample, group) for emo_groupnorm_affine_from_sums_f32.  fw = 2, W even and a 16-byte
+ * aligned `out` only: EMO_ERR_UNSUPPORTED otherwise (run the two operations one after the other). */
+int emo_upsample_trilinear_gn_sums_f32(const float* x, float* out, int N, int C, int G, int D, int H, int W,
+                                       int fd, int fh, int fw, void* partial, int64_t partial_bytes, int* split_out,
+                                       void* stream);
 int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, int H, int W, int kd, int kh, int kw, void* stream);
 int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t period, float alpha, void* stream);
 

@@ -497,6 +497,39 @@ def test_upsample_trilinear_even_widths_take_the_block_kernel(shape, factors):
     assert rel_err(got, ref) < 1e-6
 
 
+@pytest.mark.parametrize("factors", [(2, 2, 2), (1, 2, 2)])
+@pytest.mark.parametrize("shape", [(2, 64, 4, 4, 4), (3, 32, 2, 6, 8), (1, 128, 8, 8, 8), (2, 64, 8, 32, 32)])
+def test_upsample_trilinear_leaves_the_groupnorm_sums_of_its_output(shape, factors):
+    """ops.upsample_trilinear(..., gn_groups=32): the tensor is bit for bit the plain call's; the (scale, shift) GroupNorm makes
+    of the sums the kernel left behind are those of a reduction pass over the tensor (both accumulate fp64 sums of the same
+    fp32 values, in different orders: 1e-6 of the affine's magnitude), adaptive weights and group statistics included
+    (WarpGenerator: F.interpolate -> ResBlock3d's first norm, warp_generator_resnet.py:163-166)"""
+    g = torch.Generator().manual_seed(11)
+    N, C = shape[:2]
+    x = (torch.randn(*shape, generator=g) * 3.0 + 0.7).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    ag, ab = torch.randn(N, C, generator=g).to(DEV), torch.randn(N, C, generator=g).to(DEV)
+    plain = ops.upsample_trilinear(x, factors)
+    out, sums = ops.upsample_trilinear(x, factors, gn_groups=32)
+    assert sums is not None and sums.split >= 1 and torch.equal(out, plain)
+    want = ops.groupnorm_affine(plain, gamma, beta, ag, ab, want_stats=True)
+    got = ops.groupnorm_affine(out, gamma, beta, ag, ab, want_stats=True, stats=sums)
+    for a, b in zip(got, want):
+        assert rel_err(a, b.cpu()) < 1e-6
+    ref = F.group_norm(plain.cpu().double(), 32, gamma.cpu().double(), beta.cpu().double(), 1e-5)
+    ref = ref * ag.cpu().double().view(N, C, 1, 1, 1) + ab.cpu().double().view(N, C, 1, 1, 1)
+    mine = plain.cpu().double() * got[0].cpu().double().view(N, C, 1, 1, 1) + got[1].cpu().double().view(N, C, 1, 1, 1)
+    assert rel_err(mine, ref) < 1e-5
+    with pytest.raises(ValueError):
+        ops.groupnorm_affine(x, gamma, beta, stats=sums)          # the sums of another tensor
+
+
+def test_upsample_trilinear_without_a_fused_form_returns_no_sums():
+    x = torch.randn(1, 32, 2, 4, 5, generator=torch.Generator().manual_seed(12)).to(DEV)      # odd width
+    out, sums = ops.upsample_trilinear(x, (1, 2, 2), gn_groups=32)
+    assert sums is None and torch.equal(out, ops.upsample_trilinear(x, (1, 2, 2)))
+
+
 @pytest.mark.parametrize("kernel", [(2, 1, 1), (1, 2, 2), (2, 2, 2)])
 def test_avgpool3d(kernel):
     x = torch.randn(2, 3, 4, 6, 8, generator=torch.Generator().manual_seed(2))
