@@ -49,6 +49,7 @@ class ConvMeter:
     def __init__(self):
         self.events = []            # (start, stop, kernel = 'f32' | 'bf16x3' | 'f16', algorithmic FLOPs)
         self.flops = 0.0
+        self.stream_bytes = 0.0     # algorithmic bytes of the launches of the stream kernel (csrc/conv_head.hip)
         self.launches = 0
         self._orig = None
 
@@ -74,11 +75,33 @@ class ConvMeter:
 
         ops.conv_igemm = wrapped
         nets.ops.conv_igemm = wrapped
+        self._orig_head = ops.conv_head
+
+        def wrapped_head(x, layer, *a, **kw):
+            # the image head as a stream (csrc/conv_head.hip): HBM-bound, metered by its algorithmic bytes.  A launch form the
+            # stream kernel does not take goes through ops.conv_igemm inside and is metered there
+            layer.last_plan = None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = meter._orig_head(x, layer, *a, **kw)
+            e1.record()
+            if layer.last_plan is not None and layer.last_plan[2] == "stream":
+                positions = out.numel() // layer.cout
+                meter.events.append((e0, e1, "head_stream", 2.0 * positions * layer.macs_per_position))
+                meter.stream_bytes += 4.0 * positions * (layer.cin + layer.cout)
+                meter.flops += 2.0 * positions * layer.macs_per_position
+                meter.launches += 1
+            return out
+
+        ops.conv_head = wrapped_head
+        nets.ops.conv_head = wrapped_head
         return self
 
     def __exit__(self, *exc):
         ops.conv_igemm = self._orig
         nets.ops.conv_igemm = self._orig
+        ops.conv_head = self._orig_head
+        nets.ops.conv_head = self._orig_head
 
     def total_ms(self):
         return sum(e[0].elapsed_time(e[1]) for e in self.events)
@@ -742,6 +765,14 @@ def main():
 
     def conv_roofline(k):
         ms, fl, n = by_k[k]
+        if k == "head_stream":
+            gbps = conv_meter.stream_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"bound": "hbm", "kernel": "conv_head_kernel<3> (the image head 128 -> 3, 1x1, GroupNorm affine + ReLU on the way in, "
+                                              "sigmoid on the way out, as a stream: no LDS, fp32 FMAs)",
+                    "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                    "traffic": None, "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
+                    "share_of_step": round(ms / (elapsed_metered * 1e3), 3),
+                    "note": "achieved = 4 bytes x (Cin + Cout) x positions / event time"}
         tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM traffic per launch: a PMC figure of this command from separate rocprofv3 --pmc passes (it cannot be measured inside
         # the run).  Only a profile taken on THESE kernel sources is quoted: the file records the hash of the conv kernel headers

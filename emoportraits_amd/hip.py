@@ -41,6 +41,7 @@ SIGNATURES = {
     "emo_conv_igemm_bf16x3": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, _c_void],
     "emo_conv_igemm_f16x2": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, ctypes.c_float, ctypes.c_float, _c_void],
     "emo_conv_igemm_f32_guarded": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, _c_void],
+    "emo_conv_head_f32": [_c_void] * 6 + [_c_int, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_void],
     "emo_upsample_trilinear_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_upsample_trilinear_gn_sums_f32": [_c_void, _c_void] + [_c_int] * 9 + [_c_void, _c_i64, ctypes.POINTER(_c_int), _c_void],
     "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],

@@ -212,7 +212,7 @@ class Decoder:
         for blk, ups in self.up:
             x, st = blk(x, ups=ups, x_stats=st, want_stats=True)
         s, h = self.nh.affine(x, stats=st)
-        img = ops.conv_igemm(x, self.head, s, h, relu_in=True, act="sigmoid")
+        img = ops.conv_head(x, self.head, s, h, relu_in=True, act="sigmoid")       # 3 output channels: a stream, not a GEMM
         return img, feat, x
 
 

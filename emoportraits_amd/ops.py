@@ -365,6 +365,31 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
     return (out, stats) if want_stats else out
 
 
+def conv_head(x, layer, scale=None, shift=None, relu_in=False, act="none"):
+    """A 1x1(x1) convolution with at most 4 output channels as a stream (csrc/conv_head.hip; the decoder's image head):
+    same arguments and result as conv_igemm(x, layer, scale, shift, relu_in=, act=).  Launch forms the stream kernel does not
+    take (positions per channel not a multiple of 4, unaligned views, EMO_CONV_HEAD=0) run conv_igemm."""
+    lib = hip.load()
+    hip.require_cuda_f32(x, scale, shift)
+    N, Cin = x.shape[0], x.shape[1]
+    S = x.numel() // max(1, N * Cin)
+    if (not CONV_HEAD_STREAM or (layer.kd, layer.kh, layer.kw) != (1, 1, 1) or layer.cout > 4 or S % 4 or N > 65535
+            or x.data_ptr() % 16 or not x.is_contiguous()):
+        return conv_igemm(x, layer, scale, shift, relu_in=relu_in, act=act)
+    if Cin != layer.cin:
+        raise ValueError(f"conv expects {layer.cin} input channels, got {Cin}")
+    out = torch.empty((N, layer.cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+    layer.last_plan = ("head", 1, "stream")
+    hip.check(lib.emo_conv_head_f32(hip.ptr(x), hip.ptr(layer.plain_weight()), hip.ptr(layer.bias), hip.ptr(scale), hip.ptr(shift),
+                                    hip.ptr(out), N, Cin, layer.cout, S, int(relu_in), hip.ACT[act], hip.current_stream()),
+              f"emo_conv_head_f32[{layer.name}]")
+    return out
+
+
+# A/B switch (measurements only): 0 runs the image head on the fp32 MFMA implicit-GEMM kernel, as round 4 did
+CONV_HEAD_STREAM = os.environ.get("EMO_CONV_HEAD", "1") != "0"
+
+
 # A/B switch (measurements only): 0 launches the fp16 split without its device-side range check and guarded recomputation
 F16X2_GUARD = pack_mod.F16X2_GUARD_DEFAULT
 clear_overflow_flags = pack_mod.clear_overflow_flags

@@ -471,6 +471,12 @@ class PackedConv:
                     self.packed(CFG_D, "bf16x3")    # the guard on later -- 1.5x the fp16 planes' memory otherwise)
                 self.flag_slot = overflow_flag_slot(device, name)
 
+    def plain_weight(self):
+        """the folded weight as [Cout, Cin * KD * KH * KW] fp32 on the device (ops.conv_head: no packed layout)"""
+        if "plain" not in self._packed:
+            self._packed["plain"] = self._weight.reshape(self.cout, -1).contiguous().to(self.device)
+        return self._packed["plain"]
+
     def packed(self, cfg, precision="f32"):
         """packed weights for a block config: fp32 layout, or the fp16 operand layout (64 x 256 and 128 x 256 tiles)"""
         if precision == "f16":

@@ -260,6 +260,17 @@ int emo_conv_igemm_f32_guarded(const float* x, const float* wpk, const float* bi
                                int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
                                float* gn_stats, void* stream, const int* run_if);
 
+/* ABI 8.  Pointwise convolution with at most 4 output channels as a stream (the decoder's image head: GroupNorm -> ReLU ->
+ * 1x1 conv 128 -> 3 -> sigmoid, decoder.py:381-392): one 16-byte load per (channel, four positions), fp32 FMAs, no LDS.
+ *   out[n][o][p] = act(bias[o] + sum_c w[o][c] * in(x[n][c][p])),  in(v) = v * scale[n][c] + shift[n][c], then max(., 0) if relu_in
+ *   x [N, Cin, S] (S positions per channel: any spatial rank), w [Cout, Cin] plain row-major fp32 (NOT a packed layout),
+ *   bias [Cout] or NULL, scale / shift [N, Cin] both or neither, act EMO_ACT_*.
+ * Cout <= 4, S % 4 == 0 (EMO_ERR_UNSUPPORTED otherwise), 16-byte aligned x / out (EMO_ERR_ALIGN): such launches run
+ * emo_conv_igemm_f32.  The sum over the channels is sequential in fp32 (the MFMA kernel's is blocked): same bounds against the
+ * oracle, not the same bits. */
+int emo_conv_head_f32(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                      float* out, int N, int Cin, int Cout, int64_t S, int relu_in, int act, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * resampling / pointwise helpers (HBM-bound, one pass)
  *   emo_upsample_trilinear_f32: F.interpolate(x, scale_factor=(fd,fh,fw), mode='trilinear'), factors in {1,2}

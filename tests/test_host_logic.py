@@ -360,14 +360,16 @@ def test_split_convolution_arithmetic_on_the_cpu():
     assert err(f16x2) < e32
 
 
-@pytest.mark.parametrize("mode,expect", [("bf16x3", {"emo_conv_igemm_bf16x3": 28, "emo_conv_igemm_f32": 14}),
-                                          ("f32", {"emo_conv_igemm_f32": 42}),
+@pytest.mark.parametrize("mode,expect", [("bf16x3", {"emo_conv_igemm_bf16x3": 28, "emo_conv_igemm_f32": 13}),
+                                          ("f32", {"emo_conv_igemm_f32": 41}),
                                           # (every fp16-split launch is followed by its guarded bf16x3 recomputation launch)
                                           # (... and the fp16 split also takes the two 32-channel 3-D layers of the WarpGenerator)
                                           # (... and, since round 5, the decoder's four 1x1 layers -- 1536 -> 512 and the skips of its
                                           # up-blocks -- on the pointwise kernel, each followed by its guarded fp32 MFMA launch)
                                           # (... and the 3-channel warp head on the 32-row channel tile of the fp16 split)
-                                          (None, {"emo_conv_igemm_f16x2": 35, "emo_conv_igemm_bf16x3": 31, "emo_conv_igemm_f32": 7,
+                                          # (the image head, 128 -> 3 at the output resolution, is a stream in every mode:
+                                          # emo_conv_head_f32, one call)
+                                          (None, {"emo_conv_igemm_f16x2": 35, "emo_conv_igemm_bf16x3": 31, "emo_conv_igemm_f32": 6,
                                                   "emo_conv_igemm_f32_guarded": 4})])
 def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect):
     """the host side of the released R512 driver pass without a GPU (tools/host_overhead.py: every kernel entry point of the
@@ -391,6 +393,9 @@ def test_driver_pass_host_side_against_a_stub_library(monkeypatch, mode, expect)
     assert tuple(img.shape) == (B, 3, 512, 512)
     convs = {k: v for k, v in stub.calls.items() if k.startswith("emo_conv_igemm")}
     assert convs == expect, convs
+    # the image head as a stream; the WarpGenerator's four upsamplings leave the GroupNorm sums of their outputs behind
+    assert stub.calls["emo_conv_head_f32"] == 1 and stub.calls["emo_upsample_trilinear_gn_sums_f32"] == 4
+    assert stub.calls["emo_groupnorm_affine_from_sums_f32"] == 4 and "emo_upsample_trilinear_f32" not in stub.calls
     assert sum(stub.calls.values()) == 95 + (35 if mode is None else 0), dict(stub.calls)
 
 

@@ -467,6 +467,53 @@ def test_adaptive_groupnorm_matches_reference_quirk():
 
 
 # ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", ["none", "tanh", "sigmoid"])
+@pytest.mark.parametrize("N,cin,cout,dims,affine,relu_in", [
+    (2, 128, 3, (16, 24), True, True),         # the image head's form (decoder.py:381-392) on a small map
+    (3, 40, 4, (4, 6, 8), True, False),        # 3-D positions, a channel count off the unroll, no ReLU
+    (1, 7, 1, (8, 4), False, True),            # fewer channels than one unrolled group, no affine
+    (2, 64, 2, (32, 32), False, False),
+])
+def test_conv_head_stream(N, cin, cout, dims, affine, relu_in, act):
+    """ops.conv_head (csrc/conv_head.hip): a 1x1 convolution with at most 4 output channels as a stream -- against torch's CPU
+    convolution of the same operands (2e-5 of the output's magnitude: the bound of the implicit-GEMM kernel it replaces for the
+    image head) and against that kernel on the same tensors"""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(N, cin, *dims, generator=g)
+    w = torch.randn(cout, cin, *([1] * len(dims)), generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    scale = shift = None
+    xin = x
+    if affine:
+        scale, shift = torch.rand(N, cin, generator=g) + 0.5, torch.randn(N, cin, generator=g) * 0.3
+        bs = (N, cin) + (1,) * len(dims)
+        xin = x * scale.view(bs) + shift.view(bs)
+    if relu_in:
+        xin = F.relu(xin)
+    ref = (F.conv3d if len(dims) == 3 else F.conv2d)(xin, w, b)
+    ref = {"none": lambda t: t, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act](ref)
+    layer = pack.PackedConv("head", w, b, DEV)
+    args = (x.to(DEV), layer, None if scale is None else scale.to(DEV), None if shift is None else shift.to(DEV))
+    got = ops.conv_head(*args, relu_in=relu_in, act=act)
+    assert layer.last_plan == ("head", 1, "stream") and got.shape == ref.shape
+    assert rel_err(got, ref) < 2e-5
+    mfma = ops.conv_igemm(*args, relu_in=relu_in, act=act)
+    assert layer.last_plan[2] == "f32" and rel_err(got, mfma.cpu()) < 2e-5
+
+
+def test_conv_head_launch_forms_the_stream_does_not_take_run_the_mfma_kernel():
+    g = torch.Generator().manual_seed(3)
+    w, b = torch.randn(3, 16, 1, 1, generator=g) / 4, torch.randn(3, generator=g)
+    layer = pack.PackedConv("head", w, b, DEV)
+    x = torch.randn(1, 16, 5, 7, generator=g)                                   # 35 positions: not whole quads
+    got = ops.conv_head(x.to(DEV), layer, act="sigmoid")
+    assert layer.last_plan[2] == "f32" and rel_err(got, torch.sigmoid(F.conv2d(x, w, b))) < 2e-5
+    wide = pack.PackedConv("wide", torch.randn(8, 16, 1, 1, generator=g), None, DEV)   # more than 4 output channels
+    x = torch.randn(1, 16, 8, 8, generator=g)
+    got = ops.conv_head(x.to(DEV), wide)
+    assert wide.last_plan[2] == "f32" and rel_err(got, F.conv2d(x, wide._weight)) < 2e-5
+
+
 @pytest.mark.parametrize("factors", [(2, 2, 2), (1, 2, 2), (2, 1, 1)])
 def test_upsample_trilinear(factors):
     x = torch.randn(2, 5, 4, 6, 7, generator=torch.Generator().manual_seed(1))
