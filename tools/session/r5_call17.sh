@@ -2,7 +2,7 @@
 # round 5, call 17: the image head as a stream (csrc/conv_head.hip): its tests, the networks' and the bench configuration's parity
 # tests, A/B against the fp32 MFMA kernel on one box, kernel trace of the bench command
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_nets_gpu.py tests/test_bench_config_parity_gpu.py tests/test_infer_gpu.py -m gpu -x -q -k "head or upsample or Decoder or decoder or driver or bench or parity or forward or animate" > gpurun_out/r5_call17_pytest.log 2>&1
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_nets_gpu.py tests/test_bench_config_parity_gpu.py tests/test_infer_gpu.py -m gpu -x -q  > gpurun_out/r5_call17_pytest.log 2>&1
 tail -5 gpurun_out/r5_call17_pytest.log
 for f in 1 0; do
   EMO_CONV_HEAD=$f timeout 600 python bench.py --no-extras --no-cpu-baseline --no-source-pass > gpurun_out/r5_call17_bench_head$f.json 2>> gpurun_out/r5_call17.err
