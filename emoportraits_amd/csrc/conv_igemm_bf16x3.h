@@ -53,6 +53,29 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+
+// The fp16 split of two values at once: (h, m) planes with h = fp16(v), m = fp16(v - h), round to nearest even at both levels --
+// the bits of `(_Float16)v` and `(_Float16)(v - (float)h)`.  Written on PAIRS so that each plane costs one v_cvt_pk_f16_f32 per
+// two values: from the scalar form the compiler derives the residual from a v_cvt_f16_f32 of its own and converts the same
+// value a second time to build the packed operand (ISA of round 5's first builds: 6.5 vector instructions per element of the
+// patch, 5.5 here; the subtractions stay scalar -- a packed one costs more beside an MFMA stream than the two it replaces).
+#ifndef EMO_S_PAIR_CVT
+#define EMO_S_PAIR_CVT 1      // 0: the scalar form (A/B builds only; the same bits)
+#endif
+template <typename V8>
+__device__ __forceinline__ void emo_split_f16x2_pair(float v0, float v1, V8& h, V8& m, int u) {
+#if EMO_S_PAIR_CVT
+  const halfx2 h2 = __builtin_convertvector(floatx2{v0, v1}, halfx2);
+  const float r0 = v0 - (float)h2[0], r1 = v1 - (float)h2[1];
+  const halfx2 m2 = __builtin_convertvector(floatx2{r0, r1}, halfx2);
+  h[u] = h2[0]; h[u + 1] = h2[1];
+  m[u] = m2[0]; m[u + 1] = m2[1];
+#else
+  h[u] = (_Float16)v0; m[u] = (_Float16)(v0 - (float)h[u]);
+  h[u + 1] = (_Float16)v1; m[u + 1] = (_Float16)(v1 - (float)h[u + 1]);
+#endif
+}
 
 #ifndef EMO_S_PIN
 #define EMO_S_PIN 1   /* 0: A/B switch -- the compiler schedules the inside of a step on its own */
@@ -752,19 +775,20 @@ void conv_igemm_bf16x3_kernel(const ConvArgs a) {
       sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[0])), __builtin_fabsf(t_[1])); \
       sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[2])), __builtin_fabsf(t_[3])); \
     }                                                                                                 \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                   \
-      const int u = 4 * (hf_) + k;                                                                    \
-      const float v = __builtin_amdgcn_fmed3f(t_[k], q_lo[b_], q_hi[b_]);                             \
-      if constexpr (SPLIT == 3) {                                                                     \
+    if constexpr (SPLIT == 3) {                                                                       \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                 \
+        const int u = 4 * (hf_) + k;                                                                  \
+        const float v = __builtin_amdgcn_fmed3f(t_[k], q_lo[b_], q_hi[b_]);                           \
         cv_h[u] = (__bf16)v;                                                                          \
         const float r1 = v - (float)cv_h[u];                                                          \
         cv_m[u] = (__bf16)r1;                                                                         \
         const float r2 = r1 - (float)cv_m[u];                                                         \
         cv_l[u] = (__bf16)r2;                                                                         \
-      } else {                                                                                        \
-        cv_h[u] = (_Float16)v;                                                                        \
-        cv_m[u] = (_Float16)(v - (float)cv_h[u]);                                                     \
       }                                                                                               \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int k = 0; k < 4; k += 2)                                                \
+        emo_split_f16x2_pair(__builtin_amdgcn_fmed3f(t_[k], q_lo[b_], q_hi[b_]),                      \
+                             __builtin_amdgcn_fmed3f(t_[k + 1], q_lo[b_], q_hi[b_]), cv_h, cv_m, 4 * (hf_) + k); \
     }                                                                                                 \
     if ((hf_) == 1) {                                                                                 \
       char* d_ = lds_w + q_slb[i_] + (pbase_) * 16;                                                   \

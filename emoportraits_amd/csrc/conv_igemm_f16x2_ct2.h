@@ -229,12 +229,9 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
       t_[k] = __fmaf_rn(qv[4 * (hf_) + k][i_], q_sc[k], q_sh[k]);                                     \
     sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[0])), __builtin_fabsf(t_[1])); \
     sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[2])), __builtin_fabsf(t_[3])); \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                   \
-      const int u = 4 * (hf_) + k;                                                                    \
-      const float v = __builtin_amdgcn_fmed3f(t_[k], q_lo, q_hi);                                     \
-      cv_h[u] = (_Float16)v;                                                                          \
-      cv_m[u] = (_Float16)(v - (float)cv_h[u]);                                                       \
-    }                                                                                                 \
+    _Pragma("unroll") for (int k = 0; k < 4; k += 2)                                                  \
+      emo_split_f16x2_pair(__builtin_amdgcn_fmed3f(t_[k], q_lo, q_hi), __builtin_amdgcn_fmed3f(t_[k + 1], q_lo, q_hi), \
+                           cv_h, cv_m, 4 * (hf_) + k);                                                \
     if ((hf_) == 1) {                                                                                 \
       char* d_ = lds_w + (q_slb[i_] + (pbyte_));                                                      \
       *reinterpret_cast<opx8*>(d_) = cv_h;                                                            \
