@@ -2,8 +2,10 @@
 // emoportraits_amd/csrc (resample.hip, conv_head.hip: the SAME sources the product is built from) as host C++ and run them
 // thread by thread (tests/emul/stream_kernels_emul.cpp, tests/test_stream_kernels_emul.py).  A launch is a loop over blocks and
 // threads; every thread runs to completion before the next one starts, so kernels that exchange data between threads
-// (__shfl_*, __syncthreads + shared memory) do NOT compute what they compute on the GPU here: those intrinsics are stubs that
-// keep such kernels compiling, and the tests only look at results that do not pass through them.
+// (__shfl_*, __syncthreads + shared memory) do NOT compute what they compute on the GPU in this (default, fast) mode: those
+// intrinsics are stubs that keep such kernels compiling, and the tests only look at results that do not pass through them.
+// With -DHIPSHIM_THREADS the threads of a block are OS threads, __syncthreads is a barrier and __shfl_* exchange between the
+// lanes of a 64-thread wave: block reductions compute what they compute on the GPU (tiny grids: a thread per GPU thread).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -20,7 +22,6 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
-inline dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
@@ -36,6 +37,18 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+
+#ifndef HIPSHIM_THREADS
+// ---- sequential mode: one thread after the other; kernels that exchange data between threads are NOT modelled ----
+// (the built-in variables live in a namespace of the mode: inline variables are process-wide unique symbols, and a test process
+// loads a library of each mode)
+inline namespace hipshim_sequential {
+inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+}
 template <typename T> static inline T __shfl_down(T v, int, int = 64) { return v; }   // stub (see the header comment)
 template <typename T> static inline T __shfl_xor(T v, int, int = 64) { return v; }    // stub
 static inline void __syncthreads() {}                                                  // stub
@@ -56,4 +69,76 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
             }
       }
 }
+#else
+// ---- threaded mode (-DHIPSHIM_THREADS): the threads of a block are OS threads, one block at a time.  __syncthreads is a
+//      barrier of the block; __shfl_* exchange through a slot per lane behind barriers of the 64-thread wave (every lane of a
+//      wave that has not returned must reach the shuffle, as on the GPU).  Slow (a thread per GPU thread): tiny grids only ----
+#include <pthread.h>
+#include <thread>
+#include <vector>
+inline namespace hipshim_threaded {
+inline dim3 blockIdx, blockDim, gridDim;
+inline thread_local dim3 threadIdx;
+}
+namespace hipshim {
+struct Block {
+  pthread_barrier_t all;
+  std::vector<pthread_barrier_t> wave;
+  std::vector<unsigned long long> slot;      // one 8-byte exchange slot per thread
+};
+inline Block* cur = nullptr;
+inline unsigned linear_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
+template <typename T> static inline T shfl(T v, int src_lane_delta, bool xor_mode, int width) {
+  static_assert(sizeof(T) <= 8, "4- or 8-byte shuffles");
+  const unsigned t = linear_tid(), w = t / 64, lane = t % 64;
+  unsigned long long bits = 0;
+  memcpy(&bits, &v, sizeof(T));
+  cur->slot[t] = bits;
+  pthread_barrier_wait(&cur->wave[w]);
+  int src = xor_mode ? (int)(lane ^ (unsigned)src_lane_delta) : (int)lane + src_lane_delta;
+  const int seg = (int)lane / width * width;
+  if (src < seg || src >= seg + width) src = (int)lane;                      // out of the segment: the lane's own value
+  unsigned long long got = cur->slot[w * 64 + (unsigned)src];
+  pthread_barrier_wait(&cur->wave[w]);
+  T out;
+  memcpy(&out, &got, sizeof(T));
+  return out;
+}
+}  // namespace hipshim
+template <typename T> static inline T __shfl_down(T v, int delta, int width = 64) { return hipshim::shfl(v, delta, false, width); }
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { return hipshim::shfl(v, mask, true, width); }
+static inline void __syncthreads() { pthread_barrier_wait(&hipshim::cur->all); }
+
+template <typename K, typename... A>
+static inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
+  gridDim = grid;
+  blockDim = block;
+  const unsigned nthreads = block.x * block.y * block.z, nwaves = (nthreads + 63) / 64;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = dim3(bx, by, bz);
+        hipshim::Block blk;
+        pthread_barrier_init(&blk.all, nullptr, nthreads);
+        blk.wave.resize(nwaves);
+        for (unsigned w = 0; w < nwaves; ++w) {
+          const unsigned n = w + 1 < nwaves ? 64 : nthreads - 64 * w;
+          pthread_barrier_init(&blk.wave[w], nullptr, n);
+        }
+        blk.slot.assign(nthreads, 0ull);
+        hipshim::cur = &blk;
+        std::vector<std::thread> ts;
+        ts.reserve(nthreads);
+        for (unsigned t = 0; t < nthreads; ++t)
+          ts.emplace_back([=]() {
+            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            kernel(args...);
+          });
+        for (auto& th : ts) th.join();
+        for (unsigned w = 0; w < nwaves; ++w) pthread_barrier_destroy(&blk.wave[w]);
+        pthread_barrier_destroy(&blk.all);
+        hipshim::cur = nullptr;
+      }
+}
+#endif
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
