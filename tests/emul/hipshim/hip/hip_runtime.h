@@ -36,6 +36,26 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+// Wave votes are evaluated PER LANE (as if every lane were a wave of its own).  Valid for the product's uses only because the
+// branches they select are result-equivalent per lane: the samplers' `__all(all eight corners in range)` picks between an
+// unmasked and a masked accumulation that perform the same operations on the same operands for a lane whose own corners are
+// all in range (csrc/grid_sample3d.hip: gather_quad).
+static inline bool __all(bool pred) { return pred; }
+// dynamic shared memory: the launch's `shmem` bytes, one buffer per block (a kernel's `extern __shared__ T name[];` is rewritten
+// by the test into `T* const name = (T*)hipshim_dynamic_smem();`)
+inline unsigned char* hipshim_dyn_smem_ptr = nullptr;
+static inline void* hipshim_dynamic_smem() { return hipshim_dyn_smem_ptr; }
+struct hipshim_smem_buffer {
+  unsigned char* raw;
+  explicit hipshim_smem_buffer(size_t n) : raw(new unsigned char[n + 64]) {
+    hipshim_dyn_smem_ptr = raw + (64 - reinterpret_cast<uintptr_t>(raw) % 64) % 64;
+    memset(hipshim_dyn_smem_ptr, 0xff, n);
+  }
+  ~hipshim_smem_buffer() { delete[] raw; hipshim_dyn_smem_ptr = nullptr; }
+};
+
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
@@ -54,13 +74,14 @@ template <typename T> static inline T __shfl_xor(T v, int, int = 64) { return v;
 static inline void __syncthreads() {}                                                  // stub
 
 template <typename K, typename... A>
-static inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
+static inline void emu_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
   gridDim = grid;
   blockDim = block;
   for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
         blockIdx = dim3(bx, by, bz);
+        hipshim_smem_buffer smem_(shmem);
         for (unsigned tz = 0; tz < block.z; ++tz)
           for (unsigned ty = 0; ty < block.y; ++ty)
             for (unsigned tx = 0; tx < block.x; ++tx) {
@@ -110,7 +131,7 @@ template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) 
 static inline void __syncthreads() { pthread_barrier_wait(&hipshim::cur->all); }
 
 template <typename K, typename... A>
-static inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
+static inline void emu_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
   gridDim = grid;
   blockDim = block;
   const unsigned nthreads = block.x * block.y * block.z, nwaves = (nthreads + 63) / 64;
@@ -118,6 +139,7 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
         blockIdx = dim3(bx, by, bz);
+        hipshim_smem_buffer smem_(shmem);
         hipshim::Block blk;
         pthread_barrier_init(&blk.all, nullptr, nthreads);
         blk.wave.resize(nwaves);
@@ -141,4 +163,4 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
       }
 }
 #endif
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, (size_t)(shmem), __VA_ARGS__)
