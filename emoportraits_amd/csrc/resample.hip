@@ -84,9 +84,31 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
   const unsigned run = blockIdx.x, sp = blockIdx.y;
   const unsigned lo = sp * per, hi = lo + per < qrun ? lo + per : qrun;
   double s_sum = 0.0, s_sq = 0.0;
+  // A thread's quads are 256 apart: where the quads of a row divide 256 (a power of two: every call of the driver pass) its
+  // column is the same in every iteration, and the clamped input columns, the four pairs of x coefficients and one of the three
+  // divisions of the index leave the loop (the kernel is bound by this arithmetic, not by HBM: 3.3 TB/s of its bytes before).
+  const bool xinv = (256u % Wq) == 0u;
+  const unsigned wshift = (unsigned)__builtin_ctz(Wq);
+  unsigned xq = 0;
+  int col[4];
+  float lx0[4], lx1[4];
+  bool le = false;
+  auto xsetup = [&](unsigned xq_) {
+    xq = xq_;
+    const int xb_ = 2 * (int)xq_ - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int c = xb_ + k; col[k] = c < 0 ? 0 : (c > W - 1 ? W - 1 : c); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      lin_coeff(4 * (int)xq_ + j, W, 2, x0, x1, lx0[j], lx1[j]);
+    }
+    le = xq_ == 0;      // the first output of a row: taps (0, 1) = registers 1, 2 (register 0 holds the clamped column -1)
+  };
+  xsetup((lo + threadIdx.x) % Wq);
   for (unsigned q = lo + threadIdx.x; q < hi; q += 256u) {
-    const unsigned xq = q % Wq;
-    unsigned r = q / Wq;
+    unsigned r;
+    if (xinv) { r = q >> wshift; } else { xsetup(q % Wq); r = q / Wq; }
     const unsigned ky = r % Ky; r /= Ky;
     const unsigned kz = r % Kz;
     const long nc = (long)run * cr + r / Kz;
@@ -106,11 +128,7 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
       lin_coeff(yv[e] ? yo : 0, H, fh, yi0[e], yi1[e], yl0[e], yl1[e]);
       lin_coeff(zv[e] ? zo : 0, D, fd, zi0[e], zi1[e], zl0[e], zl1[e]);
     }
-    const int xb = 2 * (int)xq - 1;
     const int ey = yv[0] ? 0 : 1, ez = zv[0] ? 0 : 1;         // (a pair has at least one valid output)
-    int col[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const int c = xb + k; col[k] = c < 0 ? 0 : (c > W - 1 ? W - 1 : c); }
     const float* r00 = p + zi0[ez] * HW + (long)yi0[ey] * W;
     float a00[4], a01[4], a10[4], a11[4];
 #pragma unroll
@@ -139,14 +157,6 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
 #pragma unroll
       for (int k = 0; k < 4; ++k) { a10[k] = a00[k]; a11[k] = a01[k]; }
     }
-    float lx0[4], lx1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int x0, x1;
-      lin_coeff(4 * (int)xq + j, W, 2, x0, x1, lx0[j], lx1[j]);
-    }
-    // the first output of a row: taps (0, 1) = registers 1, 2 (register 0 holds the clamped column -1)
-    const bool le = xq == 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -221,6 +231,41 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
     out[i] = s * inv;
   }
 }
+
+// The same for a window width of 1 or 2 on rows of whole quads (every call of the driver pass: the depth pooling (2, 1, 1) of the
+// WarpGenerator's last block, 268 MB in, and the (1, 2, 2) / (2, 2, 2) poolings of the source pass): one thread produces four
+// consecutive outputs from 16-byte loads and stores them with one 16-byte store, 32-bit index arithmetic.  The sum of an output
+// runs over (depth, row, column) of its window in that order, as in the one-output-per-thread kernel: the same bits.
+template <int KW>
+__global__ __launch_bounds__(256) void avgpool_x4_kernel(const float* __restrict__ x, float* __restrict__ out, unsigned quads,
+                                                         int D, int H, int W, int kd, int kh) {
+  const unsigned Do = D / kd, Ho = H / kh, Wq = (unsigned)(W / KW) >> 2;
+  const float inv = 1.0f / (float)(kd * kh * KW);
+  const long vol = (long)D * H * W;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < quads; i += gridDim.x * 256u) {
+    const unsigned xq = i % Wq;
+    unsigned r = i / Wq;
+    const unsigned yo = r % Ho; r /= Ho;
+    const unsigned zo = r % Do;
+    const unsigned nc = r / Do;
+    const float* p = x + nc * vol + 4 * KW * xq;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int a = 0; a < kd; ++a)
+      for (int b = 0; b < kh; ++b) {
+        const float4* row = reinterpret_cast<const float4*>(p + ((long)(zo * kd + a) * H + (yo * kh + b)) * W);
+        const float4 v0 = row[0];
+        if (KW == 1) {
+          s[0] += v0.x; s[1] += v0.y; s[2] += v0.z; s[3] += v0.w;
+        } else {
+          const float4 v1 = row[1];
+          s[0] += v0.x; s[0] += v0.y; s[1] += v0.z; s[1] += v0.w;
+          s[2] += v1.x; s[2] += v1.y; s[3] += v1.z; s[3] += v1.w;
+        }
+      }
+    reinterpret_cast<float4*>(out)[i] = make_float4(s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv);
+  }
+}
+
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ out, long n, long period, float alpha) {
@@ -362,6 +407,15 @@ extern "C" int emo_avgpool_f32(const float* x, float* out, int64_t NC, int D, in
   if (kd < 1 || kh < 1 || kw < 1 || kd > 16 || kh > 16 || kw > 16) return EMO_ERR_UNSUPPORTED;
   if (D % kd || H % kh || W % kw) return EMO_ERR_UNSUPPORTED;
   const long total = NC * (D / kd) * (H / kh) * (W / kw);
+  if ((kw == 1 || kw == 2) && W % (4 * kw) == 0 && total / 4 < (1l << 32) &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const long quads = total / 4;
+    if (kw == 1)
+      hipLaunchKernelGGL(avgpool_x4_kernel<1>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, x, out, (unsigned)quads, D, H, W, kd, kh);
+    else
+      hipLaunchKernelGGL(avgpool_x4_kernel<2>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, x, out, (unsigned)quads, D, H, W, kd, kh);
+    return emo_launch_status();
+  }
   hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, (long)NC, D, H,
                      W, kd, kh, kw);
   return emo_launch_status();

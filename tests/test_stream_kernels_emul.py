@@ -78,7 +78,7 @@ def upsample(lib, x, factors, misalign=False):
 
 @pytest.mark.parametrize("factors", [(2, 2, 2), (1, 2, 2), (2, 1, 2), (1, 1, 2)])
 @pytest.mark.parametrize("shape", [(10, 4, 6, 8), (3, 2, 4, 2), (2, 3, 5, 4), (8, 4, 16, 32), (2, 1, 1, 64), (1, 2, 2, 6), (64, 4, 4, 4),
-                                   (2, 32, 64, 64)])
+                                   (2, 32, 64, 64), (2, 3, 20, 12), (1, 5, 30, 10)])      # (quads per row that do not divide 256)
 def test_block_upsampling_kernel_is_the_generic_kernel_bit_for_bit(lib, shape, factors):
     """upsample_trilinear_w2_kernel (one thread per block of up to 4 x 2 x 2 outputs; the first / last quad of a row through the
     same code with clamped columns) against the one-output-per-thread kernel (reached through an output pointer that is not
@@ -115,14 +115,30 @@ def test_upsampling_with_groupnorm_sums_writes_the_same_tensor(lib, N, C, G, dim
                                                   ctypes.byref(split), None) == -2
 
 
-@pytest.mark.parametrize("kernel", [(2, 1, 1), (1, 2, 2), (2, 2, 2), (1, 4, 4)])
-def test_avgpool_add(lib, kernel):
-    x = np.random.default_rng(2).standard_normal((6, 4, 8, 8)).astype(np.float32)
+@pytest.mark.parametrize("kernel", [(2, 1, 1), (1, 2, 2), (2, 2, 2), (1, 4, 4), (3, 1, 2)])
+@pytest.mark.parametrize("dims", [(6, 8, 8), (6, 4, 16), (12, 6, 40)])
+def test_avgpool_four_outputs_per_thread_is_the_generic_kernel_bit_for_bit(lib, kernel, dims):
+    """avgpool_x4_kernel (window width 1 or 2 on rows of whole quads) against the one-output-per-thread kernel (reached through
+    an input pointer that is not 16-byte aligned) and against ATen's CPU kernel"""
+    D, H, W = dims
     kd, kh, kw = kernel
-    out = np.empty((6, 4 // kd, 8 // kh, 8 // kw), np.float32)
-    assert lib.emo_avgpool_f32(_p(x), _p(out), ctypes.c_int64(6), 4, 8, 8, kd, kh, kw, None) == 0
+    if D % kd or H % kh or W % kw:
+        pytest.skip("window does not tile the volume")
+    x = np.random.default_rng(2).standard_normal((5, D, H, W)).astype(np.float32)
+    xa, xm = _aligned(x.size), _aligned(x.size, 1)
+    xa[:] = x.ravel()
+    xm[:] = x.ravel()
+    oshape = (5, D // kd, H // kh, W // kw)
+    out, plain = _aligned(int(np.prod(oshape))), _aligned(int(np.prod(oshape)))
+    assert lib.emo_avgpool_f32(_p(xa), _p(out), ctypes.c_int64(5), D, H, W, kd, kh, kw, None) == 0
+    assert lib.emo_avgpool_f32(_p(xm), _p(plain), ctypes.c_int64(5), D, H, W, kd, kh, kw, None) == 0
+    assert np.array_equal(out.view(np.uint32), plain.view(np.uint32))
     ref = F.avg_pool3d(torch.from_numpy(x)[None], kernel, kernel)[0].numpy()
-    assert np.abs(out - ref).max() < 1e-6
+    assert np.abs(out.reshape(oshape) - ref).max() < 1e-6
+
+
+def test_add(lib):
+    x = np.random.default_rng(2).standard_normal((6, 4, 8, 8)).astype(np.float32)
     b = np.random.default_rng(3).standard_normal(4 * 8 * 8).astype(np.float32)
     s = np.empty_like(x)
     assert lib.emo_add_f32(_p(x), _p(b), _p(s), ctypes.c_int64(x.size), ctypes.c_int64(b.size), ctypes.c_float(0.5), None) == 0
