@@ -84,31 +84,9 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
   const unsigned run = blockIdx.x, sp = blockIdx.y;
   const unsigned lo = sp * per, hi = lo + per < qrun ? lo + per : qrun;
   double s_sum = 0.0, s_sq = 0.0;
-  // A thread's quads are 256 apart: where the quads of a row divide 256 (a power of two: every call of the driver pass) its
-  // column is the same in every iteration, and the clamped input columns, the four pairs of x coefficients and one of the three
-  // divisions of the index leave the loop (the kernel is bound by this arithmetic, not by HBM: 3.3 TB/s of its bytes before).
-  const bool xinv = (256u % Wq) == 0u;
-  const unsigned wshift = (unsigned)__builtin_ctz(Wq);
-  unsigned xq = 0;
-  int col[4];
-  float lx0[4], lx1[4];
-  bool le = false;
-  auto xsetup = [&](unsigned xq_) {
-    xq = xq_;
-    const int xb_ = 2 * (int)xq_ - 1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const int c = xb_ + k; col[k] = c < 0 ? 0 : (c > W - 1 ? W - 1 : c); }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int x0, x1;
-      lin_coeff(4 * (int)xq_ + j, W, 2, x0, x1, lx0[j], lx1[j]);
-    }
-    le = xq_ == 0;      // the first output of a row: taps (0, 1) = registers 1, 2 (register 0 holds the clamped column -1)
-  };
-  xsetup((lo + threadIdx.x) % Wq);
   for (unsigned q = lo + threadIdx.x; q < hi; q += 256u) {
-    unsigned r;
-    if (xinv) { r = q >> wshift; } else { xsetup(q % Wq); r = q / Wq; }
+    const unsigned xq = q % Wq;
+    unsigned r = q / Wq;
     const unsigned ky = r % Ky; r /= Ky;
     const unsigned kz = r % Kz;
     const long nc = (long)run * cr + r / Kz;
@@ -128,7 +106,11 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
       lin_coeff(yv[e] ? yo : 0, H, fh, yi0[e], yi1[e], yl0[e], yl1[e]);
       lin_coeff(zv[e] ? zo : 0, D, fd, zi0[e], zi1[e], zl0[e], zl1[e]);
     }
+    const int xb = 2 * (int)xq - 1;
     const int ey = yv[0] ? 0 : 1, ez = zv[0] ? 0 : 1;         // (a pair has at least one valid output)
+    int col[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int c = xb + k; col[k] = c < 0 ? 0 : (c > W - 1 ? W - 1 : c); }
     const float* r00 = p + zi0[ez] * HW + (long)yi0[ey] * W;
     float a00[4], a01[4], a10[4], a11[4];
 #pragma unroll
@@ -157,6 +139,14 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
 #pragma unroll
       for (int k = 0; k < 4; ++k) { a10[k] = a00[k]; a11[k] = a01[k]; }
     }
+    float lx0[4], lx1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      lin_coeff(4 * (int)xq + j, W, 2, x0, x1, lx0[j], lx1[j]);
+    }
+    // the first output of a row: taps (0, 1) = registers 1, 2 (register 0 holds the clamped column -1)
+    const bool le = xq == 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
