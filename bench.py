@@ -20,7 +20,8 @@ The JSON line also carries
                 region / their duration measured with HIP events on the launch stream (in the default mode the pair of
                 launches of a layer: the fp16-split launch and the guarded bf16x3 launch that exits when the range check
                 passed), vs 2500 / 3 TF (three fp16 products per fp32 product), 2500 / 6 TF resp. the 157.3 TF fp32 MFMA
-                peak; roofline_other_convs: the same for the remaining conv launches
+                peak; roofline_other_convs: the same for the remaining conv launches (the pointwise fp16-split kernel and the
+                fp32 MFMA kernel as classes of their own; the image head, a stream kernel, with "bound": "hbm" against 8 TB/s)
   roofline_sampler  the 3-D grid_sample kernels, algorithmic bytes / event time vs 8 TB/s
   cpu_baseline  the oracle (oracle/restate.py, a port of the reference's PyTorch forward) timed on this box's host cores
                 on a bounded sample (rank 0, N=1 only)
