@@ -126,6 +126,25 @@ template <typename T> static inline T shfl(T v, int src_lane_delta, bool xor_mod
   return out;
 }
 }  // namespace hipshim
+// v_mfma_f32_32x32x2_f32 as an exchange between the 64 lanes of a wave: D[i][j] += A[i][0] B[0][j], then += A[i][1] B[1][j] (a
+// k-ordered chain of fused multiply-adds); lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31] and holds, in register r,
+// D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].  Every lane of the wave must execute it (as on the GPU).
+template <typename V16>
+static inline V16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, V16 c, int, int, int) {
+  const unsigned t = hipshim::linear_tid(), w = t / 64, lane = t % 64;
+  float ab[2] = {a, b};
+  memcpy(&hipshim::cur->slot[t], ab, 8);
+  pthread_barrier_wait(&hipshim::cur->wave[w]);
+  auto A = [&](unsigned i, unsigned k) { float v[2]; memcpy(v, &hipshim::cur->slot[w * 64 + 32 * k + i], 8); return v[0]; };
+  auto B = [&](unsigned k, unsigned j) { float v[2]; memcpy(v, &hipshim::cur->slot[w * 64 + 32 * k + j], 8); return v[1]; };
+  const unsigned j = lane & 31;
+  for (unsigned r = 0; r < 16; ++r) {
+    const unsigned i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    c[r] = fmaf(A(i, 1), B(1, j), fmaf(A(i, 0), B(0, j), c[r]));
+  }
+  pthread_barrier_wait(&hipshim::cur->wave[w]);
+  return c;
+}
 template <typename T> static inline T __shfl_down(T v, int delta, int width = 64) { return hipshim::shfl(v, delta, false, width); }
 template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { return hipshim::shfl(v, mask, true, width); }
 static inline void __syncthreads() { pthread_barrier_wait(&hipshim::cur->all); }
