@@ -56,6 +56,19 @@ struct hipshim_smem_buffer {
   ~hipshim_smem_buffer() { delete[] raw; hipshim_dyn_smem_ptr = nullptr; }
 };
 
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+// scalar-unit / scheduler intrinsics of the kernels that mean nothing on the host
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      // (the product only applies it to wave-uniform values)
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {   // v_med3_f32: the median of three
+  return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
+
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
@@ -144,6 +157,13 @@ static inline V16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, V16 c, 
   }
   pthread_barrier_wait(&hipshim::cur->wave[w]);
   return c;
+}
+// global_load_lds (LDS-DMA): every lane copies `size` bytes from its own global address to LDS at the wave-uniform base the
+// instruction names + offset + lane * size
+template <typename G, typename L>
+static inline void __builtin_amdgcn_global_load_lds(G gptr, L ldsptr, unsigned size, unsigned offset, unsigned) {
+  const unsigned lane = hipshim::linear_tid() % 64;
+  memcpy(reinterpret_cast<char*>((uintptr_t)ldsptr) + offset + lane * size, reinterpret_cast<const char*>((uintptr_t)gptr), size);
 }
 template <typename T> static inline T __shfl_down(T v, int delta, int width = 64) { return hipshim::shfl(v, delta, false, width); }
 template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { return hipshim::shfl(v, mask, true, width); }
