@@ -34,7 +34,18 @@ enum { hipSuccess = 0 };
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+#ifdef HIPSHIM_THREADS
+#include <stdlib.h>
+// "compute units": persistent kernels launch one block each (HIPSHIM_CUS, default 8: few blocks, several chained items per block)
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+  const char* e = getenv("HIPSHIM_CUS");
+  const int n = e ? atoi(e) : 8;
+  *v = n > 0 ? n : 8;
+  return hipSuccess;
+}
+#else
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
+#endif
 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
@@ -65,6 +76,12 @@ static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
+// raw buffer resource of the kernels (base in words 0 / 1, no range limit) and LDS byte addresses (offsets into the block's buffer)
+static inline const char* hipshim_buffer_base(int w0, int w1) {
+  return reinterpret_cast<const char*>(((unsigned long long)(unsigned)w0) | (((unsigned long long)(unsigned)w1 & 0xffffull) << 32));
+}
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {   // v_med3_f32: the median of three
   return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
 }
@@ -107,18 +124,39 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A..
 // ---- threaded mode (-DHIPSHIM_THREADS): the threads of a block are OS threads, one block at a time.  __syncthreads is a
 //      barrier of the block; __shfl_* exchange through a slot per lane behind barriers of the 64-thread wave (every lane of a
 //      wave that has not returned must reach the shuffle, as on the GPU).  Slow (a thread per GPU thread): tiny grids only ----
-#include <pthread.h>
+#include <atomic>
+#include <memory>
+#include <sched.h>
 #include <thread>
 #include <vector>
+// A block is 256 OS threads on however few cores the test machine has, and an emulated MFMA is an exchange between the 64
+// threads of a wave: a futex barrier (sleep / wake) costs a millisecond there.  This one spins on its generation word and
+// yields the core while it waits.
+struct hipshim_barrier {
+  std::atomic<unsigned> count{0}, generation{0};
+  unsigned n = 1;
+};
+static inline void pthread_barrier_init(hipshim_barrier* b, void*, unsigned n) { b->n = n; b->count = 0; b->generation = 0; }
+static inline void pthread_barrier_destroy(hipshim_barrier*) {}
+static inline void pthread_barrier_wait(hipshim_barrier* b) {
+  const unsigned gen = b->generation.load(std::memory_order_acquire);
+  if (b->count.fetch_add(1, std::memory_order_acq_rel) + 1 == b->n) {
+    b->count.store(0, std::memory_order_relaxed);
+    b->generation.store(gen + 1, std::memory_order_release);
+  } else {
+    while (b->generation.load(std::memory_order_acquire) == gen) sched_yield();
+  }
+}
 inline namespace hipshim_threaded {
 inline dim3 blockIdx, blockDim, gridDim;
 inline thread_local dim3 threadIdx;
 }
 namespace hipshim {
 struct Block {
-  pthread_barrier_t all;
-  std::vector<pthread_barrier_t> wave;
+  hipshim_barrier all;
+  std::unique_ptr<hipshim_barrier[]> wave;
   std::vector<unsigned long long> slot;      // one 8-byte exchange slot per thread
+  std::vector<unsigned long long> wide;      // 32 bytes per thread: the operands of a 16-bit MFMA
 };
 inline Block* cur = nullptr;
 inline unsigned linear_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
@@ -158,6 +196,57 @@ static inline V16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, V16 c, 
   pthread_barrier_wait(&hipshim::cur->wave[w]);
   return c;
 }
+// The lanes of a wave run in lock step on the GPU: code may exchange data through LDS between the lanes of ONE wave without a
+// barrier in the source.  Here they are independent threads; the tests' rewrites put this barrier of the wave where a kernel
+// relies on it (the epilogues' transposition through a wave-private LDS region).
+static inline void hipshim_wave_sync() { pthread_barrier_wait(&hipshim::cur->wave[hipshim::linear_tid() / 64]); }
+// LDS-DMA of the split kernels (global_load_lds_dwordx4 with M0 = lds_dst): 16 bytes per lane to LDS byte lds_dst + lane * 16
+static inline void hipshim_lds_dma16(const void* gsrc, unsigned lds_dst) {
+  const unsigned lane = hipshim::linear_tid() % 64;
+  memcpy(hipshim_dyn_smem_ptr + lds_dst + lane * 16, gsrc, 16);
+}
+// DPP row operations the kernels use (v_mov_b32_dpp with all rows and banks enabled): quad_perm (ctrl < 0x100), row_mirror
+// (0x140), row_half_mirror (0x141) -- lane l of a 16-lane row reads another lane of its row
+static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+  const unsigned t = hipshim::linear_tid(), w = t / 64, lane = t % 64;
+  hipshim::cur->slot[t] = (unsigned)src;
+  pthread_barrier_wait(&hipshim::cur->wave[w]);
+  unsigned from;
+  if (ctrl < 0x100) from = (lane & ~3u) | (((unsigned)ctrl >> (2 * (lane & 3))) & 3u);
+  else if (ctrl == 0x140) from = (lane & ~15u) | (15u - (lane & 15u));
+  else if (ctrl == 0x141) from = (lane & ~7u) | (7u - (lane & 7u));
+  else { from = lane; __builtin_trap(); }
+  const int got = (int)(unsigned)hipshim::cur->slot[w * 64 + from];
+  pthread_barrier_wait(&hipshim::cur->wave[w]);
+  return got;
+}
+// v_mfma_f32_32x32x16_{f16,bf16}: lane l supplies A[l & 31][8 (l >> 5) + 0..7] and B[8 (l >> 5) + 0..7][l & 31]; the result
+// layout is that of v_mfma_f32_32x32x2_f32.  Products of 16-bit operands are exact in fp32; they are added to the accumulator in
+// the order of k (the hardware's internal order and width are not modelled: results are compared within tolerances, never bits).
+template <typename V8, typename V16>
+static inline V16 hipshim_mfma_32x32x16(V8 a, V8 b, V16 c) {
+  const unsigned t = hipshim::linear_tid(), w = t / 64, lane = t % 64;
+  static_assert(sizeof(V8) == 16, "eight 16-bit operands per lane");
+  memcpy(&hipshim::cur->wide[4 * (size_t)t], &a, 16);
+  memcpy(&hipshim::cur->wide[4 * (size_t)t + 2], &b, 16);
+  pthread_barrier_wait(&hipshim::cur->wave[w]);
+  const unsigned j = lane & 31;
+  for (unsigned r = 0; r < 16; ++r) {
+    const unsigned i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (unsigned kh = 0; kh < 2; ++kh) {
+      V8 av, bv;
+      memcpy(&av, &hipshim::cur->wide[4 * (size_t)(w * 64 + 32 * kh + i)], 16);
+      memcpy(&bv, &hipshim::cur->wide[4 * (size_t)(w * 64 + 32 * kh + j) + 2], 16);
+      for (int e = 0; e < 8; ++e) acc += (float)av[e] * (float)bv[e];
+    }
+    c[r] = acc;
+  }
+  pthread_barrier_wait(&hipshim::cur->wave[w]);
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipshim_mfma_32x32x16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipshim_mfma_32x32x16(a, b, c)
 // global_load_lds (LDS-DMA): every lane copies `size` bytes from its own global address to LDS at the wave-uniform base the
 // instruction names + offset + lane * size
 template <typename G, typename L>
@@ -181,12 +270,13 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A..
         hipshim_smem_buffer smem_(shmem);
         hipshim::Block blk;
         pthread_barrier_init(&blk.all, nullptr, nthreads);
-        blk.wave.resize(nwaves);
+        blk.wave.reset(new hipshim_barrier[nwaves]);
         for (unsigned w = 0; w < nwaves; ++w) {
           const unsigned n = w + 1 < nwaves ? 64 : nthreads - 64 * w;
           pthread_barrier_init(&blk.wave[w], nullptr, n);
         }
         blk.slot.assign(nthreads, 0ull);
+        blk.wide.assign(4 * (size_t)nthreads, 0ull);
         hipshim::cur = &blk;
         std::vector<std::thread> ts;
         ts.reserve(nthreads);

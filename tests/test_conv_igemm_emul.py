@@ -2,22 +2,17 @@
 taps, fused GroupNorm affine + ReLU, nearest x2 upsample, residual forms, activations, K split, tile statistics), run on the CPU
 from the product's own sources through its C ABI (emo_conv_igemm_f32) -- SURVEY.md section 8 rows a5 .. a10 without a GPU.
 
-The sources are compiled as host C++ by ROCm's clang++ against the stand-in <hip/hip_runtime.h> of tests/emul/hipshim in its
-threaded mode: the threads of a block are OS threads, __syncthreads is a barrier, v_mfma_f32_32x32x2_f32 is an exchange between
-the 64 lanes of a wave with the hardware's operand / result layout, global_load_lds copies into the block's LDS buffer.  The
-test rewrites, in a COPY of conv_igemm.h, what only the GPU toolchain understands: the five inline-asm helpers (pinned loads
-become plain loads, waits and scheduling fences become nothing: the host run checks index arithmetic, LDS image, fragment
+tests/emul/convlib.py compiles copies of the sources as host C++ (ROCm's clang++, the stand-in <hip/hip_runtime.h> of
+tests/emul/hipshim in its threaded mode: the threads of a block are OS threads, __syncthreads is a barrier,
+v_mfma_f32_32x32x2_f32 is an exchange between the 64 lanes of a wave with the hardware's operand / result layout, global_load_lds
+copies into the block's LDS buffer) and rewrites in the copies what only the GPU toolchain understands: the inline-asm helpers
+(pinned loads become plain loads, waits and scheduling fences nothing: the host run checks index arithmetic, LDS image, fragment
 addressing and epilogue, not pipelining -- that is the ISA audit's and the GPU tests' job), the dynamic shared-memory
-declaration and the occupancy attribute.  The lookups of the 16-bit kernels are stubs that refuse.  The product never loads
-this library, and the product sources are not touched.
+declaration and the occupancy attribute.  The product never loads this library, and the product sources are not touched.
 """
-import concurrent.futures
 import ctypes
 import math
 import os
-import re
-import shutil
-import subprocess
 import sys
 
 import numpy as np
@@ -30,57 +25,18 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from emoportraits_amd import pack  # noqa: E402
 
-CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-CSRC = os.path.join(ROOT, "emoportraits_amd", "csrc")
-SHIM = os.path.join(HERE, "emul", "hipshim")
-GEN = os.path.join(HERE, "emul", "_build", "gen_conv_igemm")
-UNITS = ["conv_api.hip"] + [f"conv_inst_3x3_{c}.hip" for c in "ABCDEF"] + [f"conv_inst_1x1_{c}.hip" for c in "ABC"] + \
-        ["conv_inst_1x7_A.hip", "conv_inst_1x7_B.hip"]
+sys.path.insert(0, os.path.join(HERE, "emul"))
+import convlib  # noqa: E402
+
 ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 CFG = {"A": 0, "B": 1, "C": 2, "D": 3, "E": 4, "F": 5}
 
-pytestmark = pytest.mark.skipif(not (os.path.exists(CLANG) and os.path.exists(os.path.join(ROOT, "emoportraits_amd", "lib", "libemoportraits_hip.so"))),
-                                reason="needs ROCm clang++ and the built product library (weight packing asks it for the tile sizes)")
-
-REWRITES = [      # (pattern, replacement, occurrences expected in conv_igemm.h)
-    (r'asm volatile\(EMO_SGPR_HAZARD_NOP "global_load_dword %0, %1, %2" : "=v"\(v\) : "v"\(voff\), "s"\(sbase\) : "memory"\);',
-     'memcpy(&v, reinterpret_cast<const char*>(sbase) + voff, 4);', 1),
-    (r'asm volatile\(EMO_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2" : "=v"\(v\) : "v"\(voff\), "s"\(sbase\) : "memory"\);',
-     'memcpy(&v, reinterpret_cast<const char*>(sbase) + voff, 16);', 1),
-    (r'asm volatile\("" : "\+v"\(v\)\);', ';', 2),
-    (r'asm volatile\("s_waitcnt vmcnt\(0\)" ::: "memory"\);', ';', 1),
-    (r'extern\s+__shared__\s+__attribute__\(\(aligned\(16\)\)\)\s+float\s+smem\[\];',
-     'float* const smem = reinterpret_cast<float*>(hipshim_dynamic_smem());', 1),
-    (r'__attribute__\(\(amdgpu_waves_per_eu\(.*?\)\)\)', '', 1),
-]
+pytestmark = pytest.mark.skipif(not convlib.available(), reason="needs ROCm clang++ and the built product library (weight packing asks it for the tile sizes)")
 
 
 @pytest.fixture(scope="module")
 def lib():
-    out = os.path.join(GEN, "libconv_igemm_emul.so")
-    deps = [os.path.join(CSRC, f) for f in UNITS + ["conv_igemm.h", "conv_dispatch.h", "common.h"]] + [os.path.join(SHIM, "hip", "hip_runtime.h"), __file__]
-    if not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
-        os.makedirs(GEN, exist_ok=True)
-        text = open(os.path.join(CSRC, "conv_igemm.h")).read()
-        for pat, rep, cnt in REWRITES:
-            text, n = re.subn(pat, rep, text, flags=re.S)
-            assert n == cnt, f"conv_igemm.h changed under the emulation's rewrites: {pat!r} matched {n} times, expected {cnt}"
-        assert "asm" not in re.sub(r"//[^\n]*|/\*.*?\*/", "", text, flags=re.S), "an inline-asm statement the rewrites do not know"
-        open(os.path.join(GEN, "conv_igemm.h"), "w").write(text)
-        for f in UNITS + ["conv_dispatch.h"]:
-            shutil.copy(os.path.join(CSRC, f), os.path.join(GEN, f))
-        open(os.path.join(GEN, "stubs.cpp"), "w").write(
-            '#include "conv_dispatch.h"\n' + "".join(f"conv_launch_fn conv_lookup_{n}(int, int) {{ return nullptr; }}\n" for n in (
-                "f16_3x3_D", "f16_1x1_D", "f16_3x3_G", "bf16x3_3x3", "f16x2_3x3", "f16x2_1x1", "f16x2_3x3_bm32")))
-        flags = [CLANG, "-O1", "-std=c++17", "-ffp-contract=off", "-DHIPSHIM_THREADS", "-pthread", "-I" + SHIM, "-I" + CSRC, "-w", "-fPIC"]
-
-        def cc(f):
-            subprocess.run(flags + ["-c", "-x", "c++", os.path.join(GEN, f), "-o", os.path.join(GEN, f + ".o")], check=True, cwd=GEN)
-            return os.path.join(GEN, f + ".o")
-        with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
-            objs = list(ex.map(cc, UNITS + ["stubs.cpp"]))
-        subprocess.run([CLANG, "-shared", "-pthread", "-o", out] + objs, check=True)
-    return ctypes.CDLL(out)
+    return convlib.build()
 
 
 def _buf(t):

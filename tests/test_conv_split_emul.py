@@ -1,0 +1,237 @@
+"""The DOMINANT kernels of the hot path -- fp32 convolutions on the 16-bit matrix pipes (csrc/conv_igemm_bf16x3.h: the two-term
+fp16 split with its device-side range check and the exact three-term bf16 split; csrc/conv_igemm_f16x2_ct2.h: two channel tiles
+per work item; csrc/conv_igemm_f16x2_p1.h: pointwise layers; csrc/conv_igemm_f16.h: the opt-in fp16-operand mode) -- run on the
+CPU from copies of the product's own sources through the C ABI, against fp64 convolutions.  SURVEY.md section 8 rows a5 .. a10.
+
+tests/emul/convlib.py builds the library (ROCm's clang++, the stand-in runtime of tests/emul/hipshim in its threaded mode:
+v_mfma_f32_32x32x16_{f16,bf16}, the DPP row operations of the statistics and LDS-DMA are modelled; pinned loads are plain loads,
+`s_waitcnt; s_barrier` a barrier of the block).  What this checks without a GPU: operand conversion and range check, LDS images
+and fragment addressing, the persistent item loop with chained items, channel-tile pairs on one converted patch, 32-row channel
+tiles, depth taps as K stages, the fused upsample, the straight-line and the general epilogue, tile statistics, the guarded exact
+recomputation.  What it cannot check: pipelining (a load is complete when issued here) -- the ISA audit's and the GPU tests' job.
+"""
+import ctypes
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "emul"))
+import convlib  # noqa: E402
+from emoportraits_amd import pack  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not convlib.available(), reason="needs ROCm clang++ and the built product library (weight packing asks it for tile sizes)")
+ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+CFG_D, CFG_F = 3, 5
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return convlib.build()
+
+
+def _buf(t):
+    a = np.ascontiguousarray(t.numpy() if isinstance(t, torch.Tensor) else t)
+    raw = np.empty(a.nbytes + 64, np.uint8)
+    off = (-raw.ctypes.data) % 16
+    out = raw[off:off + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def _p(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def _half_bits(t):
+    return t.view(torch.int16) if t.dtype in (torch.float16, torch.bfloat16) else t
+
+
+class Case:
+    """one convolution: operands, fp64 reference, and launches of it in the split modes"""
+
+    def __init__(self, N, Cin, Cout, dims, k=3, affine=True, relu_in=True, ups=False, res=False, res_ups=False, bias=True, seed=0, amp=1.0):
+        g = torch.Generator().manual_seed(seed)
+        self.three_d = len(dims) == 3
+        self.N, self.Cin, self.Cout, self.k, self.ups, self.relu_in, self.res_ups = N, Cin, Cout, k, ups, relu_in, res_ups
+        self.x = torch.randn(N, Cin, *dims, generator=g) * amp
+        kd = k if self.three_d else 1
+        wshape = (Cout, Cin, k, k, k) if self.three_d else (Cout, Cin, k, k)
+        self.w = torch.randn(*wshape, generator=g) / math.sqrt(Cin * k * k * kd)
+        self.b = torch.randn(Cout, generator=g) if bias else None
+        self.scale = self.shift = None
+        xin = self.x
+        if affine:
+            self.scale, self.shift = torch.rand(N, Cin, generator=g) + 0.5, torch.randn(N, Cin, generator=g) * 0.3
+            bs = (N, Cin) + (1,) * len(dims)
+            xin = self.x * self.scale.view(bs) + self.shift.view(bs)
+        if relu_in:
+            xin = F.relu(xin)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        ref = (F.conv3d if self.three_d else F.conv2d)(xin.double(), self.w.double(), None if self.b is None else self.b.double(), padding=k // 2)
+        self.r = None
+        if res:
+            rshape = list(ref.shape)
+            if res_ups:
+                rshape[-1] //= 2
+                rshape[-2] //= 2
+            self.r = torch.randn(*rshape, generator=g)
+            ref = ref + (F.interpolate(self.r, scale_factor=2, mode="nearest") if res_ups else self.r).double()
+        self.ref = ref.numpy()
+        self.D, self.H, self.W = (dims if self.three_d else (1,) + tuple(dims))
+        self.kd = kd
+
+    def launch(self, lib, mode, cfg=CFG_D, stats=False, flag=None, run_if=None, act="none", out=None):
+        arr = lambda t: None if t is None else _buf(t)
+        xa, ba, sc, sh, ra = _buf(self.x), arr(self.b), arr(self.scale), arr(self.shift), arr(self.r)
+        out = _buf(np.full(self.ref.shape, np.nan, np.float32)) if out is None else out
+        Hl, Wl = (2 * self.H, 2 * self.W) if self.ups else (self.H, self.W)
+        st = None
+        if stats:
+            cnt = 128 if (mode == "f16x2" and self.k == 1) else 256
+            st = _buf(np.full((self.N, self.D * Hl * Wl // cnt, self.Cout, 2), np.nan, np.float32))
+        common = [_p(ba), _p(sc), _p(sh), _p(ra), _p(out), self.N, self.Cin, self.Cout, self.D, self.H, self.W, self.kd, self.k, self.k,
+                  int(self.ups), int(self.relu_in), ACT[act], int(self.res_ups), cfg, 1, None, _p(st), None]
+        if mode == "f16x2":
+            flat, ws = (pack.pack_weight_f16x2_1x1(self.w) if self.k == 1 else pack.pack_weight_f16x2(self.w, bm=32 if cfg == CFG_F else None))
+            wpk = _buf(_half_bits(flat))
+            rc = lib.emo_conv_igemm_f16x2(_p(xa), _p(wpk), *common, ctypes.c_float(pack.F16X2_IN_SCALE), ctypes.c_float(ws), _p(flag))
+        elif mode == "bf16x3":
+            wpk = _buf(_half_bits(pack.pack_weight_bf16x3(self.w)))
+            rc = lib.emo_conv_igemm_bf16x3(_p(xa), _p(wpk), *common, _p(run_if))
+        elif mode == "f16":
+            wpk = _buf(_half_bits(pack.pack_weight_f16(self.w, cfg)))
+            rc = lib.emo_conv_igemm_f16acc32(_p(xa), _p(wpk), *common)
+        else:
+            raise ValueError(mode)
+        assert rc == 0, (mode, rc)
+        return out, st
+
+    def err(self, out, act="none"):
+        ref = {"none": lambda t: t, "tanh": np.tanh, "sigmoid": lambda t: 1 / (1 + np.exp(-t))}[act](self.ref)
+        return np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+
+
+def _bits(a):
+    return a.view(np.uint32)
+
+
+# ---- single-tile kernel, every position-tile shape, both splits ---------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("dims,N", [((32, 64), 1), ((16, 32), 1), ((16, 16), 2), ((4, 128), 1)])      # (32 x 64: 16 items, two chained per block)
+def test_split_kernel_tile_shapes(lib, mode, dims, N):
+    """4 x 64, 8 x 32, 16 x 16 position tiles; 40 input channels (a ragged last 16-channel stage), 72 output channels (a ragged
+    second channel tile) -- a persistent block walks several chained items"""
+    c = Case(N, 40, 72, dims, res=True, seed=dims[1])
+    out, _ = c.launch(lib, mode)
+    assert c.err(out) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+def test_split_kernel_fused_upsample_residual_forms_and_general_epilogue(lib, mode):
+    c = Case(1, 32, 64, (4, 32), ups=True, res=True, res_ups=True, seed=1)             # nearest x2 in the gather, half-size residual
+    assert c.err(c.launch(lib, mode)[0]) < 2e-5
+    c = Case(1, 16, 64, (8, 64), ups=False, res=True, seed=2)
+    assert c.err(c.launch(lib, mode, act="tanh")[0], "tanh") < 2e-5                   # an activation: the general epilogue
+    c = Case(1, 16, 24, (8, 64), res=False, bias=False, affine=False, relu_in=False, seed=3)   # a 24-channel tile, plain operands
+    assert c.err(c.launch(lib, mode)[0]) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+def test_split_kernel_3d_depth_taps_as_stages(lib, mode):
+    c = Case(1, 16, 64, (3, 4, 64), res=True, seed=4)
+    assert c.err(c.launch(lib, mode)[0]) < 2e-5
+    c = Case(1, 24, 64, (2, 16, 16), res=False, seed=5)
+    assert c.err(c.launch(lib, mode)[0]) < 2e-5
+
+
+def test_split_kernel_tile_statistics(lib):
+    """(mean, centred sum of squares) per 256-position tile and channel from the DPP reductions of the epilogue, recombined over the
+    tiles (Chan) against the statistics of the whole channel; identical in both splits' layout"""
+    c = Case(2, 16, 72, (8, 64), res=True, seed=6)
+    for mode in ("f16x2", "bf16x3"):
+        out, st = c.launch(lib, mode, stats=True)
+        assert c.err(out) < 2e-5
+        o = torch.from_numpy(out.copy()).double().view(2, 72, -1)
+        s = torch.from_numpy(st.copy()).double()
+        mean = s[..., 0].mean(1)
+        m2 = s[..., 1].sum(1) + 256 * ((s[..., 0] - mean[:, None]) ** 2).sum(1)
+        assert (mean - o.mean(-1)).abs().max().item() < 1e-5
+        assert (m2 - ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1)).abs().max().item() < 1e-3 * m2.abs().max().item()
+
+
+# ---- two channel tiles per work item -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cout,ups,N", [(128, False, 2), (192, False, 1), (128, True, 1)])
+def test_two_tile_kernel_is_the_single_tile_kernel_bit_for_bit(lib, cout, ups, N, monkeypatch):
+    """conv_igemm_bf16x3_ct2_kernel (a pair of 64-channel tiles on one converted patch; an odd last tile on the single-tile kernel
+    as a second launch) against the single-tile kernel on every tile (EMO_CONV_CT2=0): output, tile statistics and overflow word.
+    N = 2: sixteen pair items on eight persistent blocks, two chained items each; N = 1: one item per block"""
+    dims = (16, 32) if ups else (32, 64)                # eight position tiles per sample
+    c = Case(N, 16, cout, dims, ups=ups, res=True, res_ups=False, seed=cout)
+    flag_a, flag_b = _buf(np.zeros(4, np.int32)), _buf(np.zeros(4, np.int32))
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "8")
+    monkeypatch.setenv("EMO_CONV_CT2", "1")
+    out_a, st_a = c.launch(lib, "f16x2", stats=True, flag=flag_a)
+    monkeypatch.setenv("EMO_CONV_CT2", "0")
+    out_b, st_b = c.launch(lib, "f16x2", stats=True, flag=flag_b)
+    assert c.err(out_a) < 2e-5
+    assert np.array_equal(_bits(out_a), _bits(out_b)) and np.array_equal(_bits(st_a), _bits(st_b)) and np.array_equal(flag_a, flag_b)
+
+
+# ---- 32-row channel tiles, pointwise layers -----------------------------------------------------------------------------------
+def test_32_row_channel_tiles(lib):
+    c = Case(1, 32, 32, (2, 8, 64), res=True, seed=8)                                   # the WarpGenerator's 32 -> 32 3-D layer form
+    out, st = c.launch(lib, "f16x2", cfg=CFG_F, stats=True)
+    assert c.err(out) < 2e-5 and not np.isnan(st).any()
+    c = Case(1, 32, 3, (2, 4, 64), res=False, seed=9)                                   # the warp head: 3 of 32 rows are real
+    assert c.err(c.launch(lib, "f16x2", cfg=CFG_F, act="tanh")[0], "tanh") < 2e-5
+
+
+def test_pointwise_kernel(lib):
+    """conv_igemm_bf16x3_p1_kernel: 1 x 1 layers on the fp16 split, 32-channel stages, two channel tiles per item (192 channels:
+    the third tile in a pair with zero weights), statistics as two half entries per 256-position tile"""
+    c = Case(1, 64, 192, (16, 64), k=1, res=True, seed=10)
+    out, st = c.launch(lib, "f16x2", stats=True)
+    assert c.err(out) < 2e-5
+    o = torch.from_numpy(out.copy()).double().view(1, 192, -1)
+    s = torch.from_numpy(st.copy()).double()
+    mean = s[..., 0].mean(1)
+    m2 = s[..., 1].sum(1) + 128 * ((s[..., 0] - mean[:, None]) ** 2).sum(1)
+    assert (mean - o.mean(-1)).abs().max().item() < 1e-5
+    assert (m2 - ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1)).abs().max().item() < 1e-3 * m2.abs().max().item()
+
+
+# ---- range check and guarded recomputation -------------------------------------------------------------------------------------
+def test_range_check_and_guarded_exact_recomputation(lib):
+    """operands beyond the fp16 range of the scaled split raise the layer's overflow word; the guarded bf16x3 launch behind it
+    recomputes the layer exactly; with the word down the guarded launch leaves the output alone"""
+    c = Case(1, 16, 64, (8, 64), res=True, seed=11, amp=4000.0)
+    flag = _buf(np.zeros(4, np.int32))
+    out, _ = c.launch(lib, "f16x2", flag=flag)
+    assert flag[0] != 0
+    c.launch(lib, "bf16x3", run_if=flag, out=out)
+    plain, _ = c.launch(lib, "bf16x3")
+    assert np.array_equal(_bits(out), _bits(plain)) and c.err(out) < 2e-5
+    calm = Case(1, 16, 64, (8, 64), res=True, seed=12)
+    flag = _buf(np.zeros(4, np.int32))
+    out, _ = calm.launch(lib, "f16x2", flag=flag)
+    assert flag[0] == 0
+    before = out.copy()
+    calm.launch(lib, "bf16x3", run_if=flag, out=out)
+    assert np.array_equal(_bits(out), _bits(before))
+
+
+# ---- the opt-in fp16-operand mode (reduced precision: BASELINE configs[4]) ----------------------------------------------------
+@pytest.mark.parametrize("k,dims", [(3, (8, 64)), (1, (8, 64)), (3, (2, 128))])
+def test_fp16_operand_kernels(lib, k, dims):
+    c = Case(1, 32, 72, dims, k=k, res=True, seed=13 + k)
+    out, _ = c.launch(lib, "f16")
+    assert c.err(out) < 2e-3                                                          # fp16 operands, fp32 accumulation
