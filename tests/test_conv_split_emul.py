@@ -235,3 +235,30 @@ def test_fp16_operand_kernels(lib, k, dims):
     c = Case(1, 32, 72, dims, k=k, res=True, seed=13 + k)
     out, _ = c.launch(lib, "f16")
     assert c.err(out) < 2e-3                                                          # fp16 operands, fp32 accumulation
+
+
+# ---- persistent grids on a part whose CU count is not a multiple of 8 ----------------------------------------------------------
+@pytest.mark.parametrize("cus", ["12", "4", "1"])
+def test_persistent_grid_covers_every_item_whatever_the_cu_count(lib, cus):
+    """the split kernels hand out their items in eight per-XCD ranges (block b walks the range of XCD b % 8): emo_cu_count()
+    (csrc/common.h) rounds the device's CU count down to a multiple of 8, at least 8, so that min(items, CUs) blocks hold all
+    eight residues.  With the raw count a 12-, 4- or 1-CU device left whole ranges uncomputed (NaN fill below) -- found by this
+    emulation.  The count is cached per process: a child process per device"""
+    import subprocess
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_conv_split_emul as T\n"
+        "lib = T.convlib.build()\n"
+        "for mode, dims in (('f16x2', (32, 64)), ('bf16x3', (16, 64))):\n"
+        "    c = T.Case(1, 16, 72, dims, res=True, seed=3)\n"
+        "    out, _ = c.launch(lib, mode)\n"
+        "    assert not np.isnan(out).any() and c.err(out) < 2e-5, (mode, float(np.isnan(out).mean()))\n"
+        "os.environ['EMO_CONV_CT2_MIN_ITEMS'] = '1'\n"
+        "c = T.Case(2, 16, 128, (32, 64), res=True, seed=4)\n"
+        "out, _ = c.launch(lib, 'f16x2')\n"
+        "assert not np.isnan(out).any() and c.err(out) < 2e-5\n"
+        "print('ok')\n") % (HERE, ROOT)
+    env = dict(os.environ, HIPSHIM_CUS=cus)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
