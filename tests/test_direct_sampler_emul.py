@@ -14,6 +14,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -34,25 +35,9 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++ 
 
 @pytest.fixture(scope="module")
 def lib():
-    out = os.path.join(BUILD, "libsampler_emul_threads.so")
-    src = os.path.join(CSRC, "grid_sample3d.hip")
-    deps = [src, os.path.join(CSRC, "gs3d_coord.h"), os.path.join(CSRC, "common.h"), os.path.join(SHIM, "hip", "hip_runtime.h"), __file__]
-    if not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
-        gen = os.path.join(BUILD, "gen")
-        os.makedirs(gen, exist_ok=True)
-        text, n = re.subn(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];",
-                          r"\1* const \2 = reinterpret_cast<\1*>(hipshim_dynamic_smem());", open(src).read())
-        assert n == 1, "one dynamic shared-memory declaration expected in grid_sample3d.hip"
-        open(os.path.join(gen, "grid_sample3d.hip"), "w").write(text)
-        open(os.path.join(gen, "stubs.cpp"), "w").write(
-            "#include <stdint.h>\n"
-            "int emo_gs3d_tile_dispatch(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int, "
-            "int, int, int, int, int, int, int64_t, int, int, int, int, int, void*) { return -2; }\n"
-            "int emo_repack_p4_dispatch(const float*, float*, int, int, int, int, void*) { return -2; }\n")
-        subprocess.run([CLANG, "-O1", "-std=c++17", "-ffp-contract=off", "-DHIPSHIM_THREADS", "-pthread", "-I" + SHIM, "-I" + CSRC, "-w",
-                        "-shared", "-fPIC", "-o", out, "-x", "c++", os.path.join(gen, "grid_sample3d.hip"), os.path.join(gen, "stubs.cpp")],
-                       check=True)
-    return ctypes.CDLL(out)
+    sys.path.insert(0, os.path.join(HERE, "emul"))
+    import emulibs
+    return emulibs.sampler()
 
 
 def _buf(t):

@@ -12,6 +12,7 @@ import ctypes
 import math
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -24,30 +25,20 @@ CSRC = os.path.join(ROOT, "emoportraits_amd", "csrc")
 SHIM = os.path.join(HERE, "emul", "hipshim")
 SOURCES = [os.path.join(CSRC, f) for f in ("resample.hip", "conv_head.hip", "embed_ops.hip", "smallops.hip", "groupnorm.hip")]
 ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
-
-
-def _build(name, extra):
-    """every source is a translation unit of its own (`g++ -x c++ file.hip`), with the flags that matter for the arithmetic
-    taken from emoportraits_amd/build.py (-ffp-contract=off: no multiply-add is fused that the source does not spell)"""
-    out = os.path.join(HERE, "emul", "_build", name)
-    deps = SOURCES + [os.path.join(SHIM, "hip", "hip_runtime.h"), os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "emo_hip.h")]
-    if not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I" + SHIM, "-shared", "-fPIC"] + extra +
-                       ["-o", out, "-x", "c++"] + SOURCES, check=True)
-    return ctypes.CDLL(out)
+sys.path.insert(0, os.path.join(HERE, "emul"))
+import emulibs  # noqa: E402
 
 
 @pytest.fixture(scope="module")
 def lib():
     """sequential mode: one GPU thread after the other (barrier-free kernels)"""
-    return _build("libstream_emul.so", [])
+    return emulibs.stream(False)
 
 
 @pytest.fixture(scope="module")
 def tlib():
     """threaded mode: the threads of a block are OS threads, __syncthreads / __shfl_* are real exchanges (block reductions)"""
-    return _build("libstream_emul_threads.so", ["-DHIPSHIM_THREADS", "-pthread"])
+    return emulibs.stream(True)
 
 
 def _p(a):
