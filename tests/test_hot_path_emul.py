@@ -8,7 +8,7 @@ This is test infrastructure, not a CPU path of the product: the package is point
 emoportraits_amd.hip inside this test only; emoportraits_amd itself refuses to run without its GPU library.
 
     default            one driver frame (about 50 s on 8 cores)
-    EMO_EMUL_FULL=1    + the source pass and both golden driver frames (about 4 minutes more)
+    EMO_EMUL_FULL=1    + the source pass, both golden driver frames and the stage-2 refinement (about 5 minutes more)
 """
 import os
 import sys
@@ -74,3 +74,20 @@ def test_source_pass_and_both_frames_through_the_emulated_kernels(hot_path):
     e_gold = max((img[i:i + 1] - tiny["driver"][i]["img"]).abs().max().item() for i in range(2))
     print(f"PARITY emulated source pass: canonical rel err {e_src:.2e}; two driver frames vs reference golden {e_gold:.2e}")
     assert e_src < 1e-3 and e_gold < 5e-3                              # __graft_entry__.smoke()'s bounds
+
+
+@pytest.mark.skipif(not FULL, reason="EMO_EMUL_FULL=1: the stage-2 refinement (about a minute)")
+def test_stage2_refinement_through_the_emulated_kernels(monkeypatch):
+    """Stage2.refine (LocalEncoderOld + Decoder_stage2, BatchNorm default flags) on the golden outputs of
+    the real reference (tests/golden/tiny_stage2.pt) -- the bounds of tests/test_stage2_gpu.py"""
+    lib = emulibs.install(monkeypatch.setattr)
+    from emoportraits_amd import stage2
+    monkeypatch.delenv("EMO_CONV_PRECISION", raising=False)
+    tiny = torch.load(os.path.join(HERE, "golden", "tiny_stage2.pt"), weights_only=False)
+    s2 = stage2.Stage2(tiny["state_dict"], stage2.stage2_config(tiny["cfg"]), "cpu")
+    got = s2.refine(tiny["img"], tiny["mask"], tiny["face_mask"], keep=True)
+    rel = lambda a, b: (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
+    e = {k: rel(got[k], tiny[k]) for k in ("latents", "add")}
+    e["out_abs"] = (got["out"] - tiny["out"]).abs().max().item()
+    print("PARITY emulated stage 2 (tiny golden, bn):", {k: f"{v:.2e}" for k, v in e.items()}, f"{sum(lib.calls.values())} C-ABI calls")
+    assert e["latents"] <= 5e-5 and e["add"] <= 2e-4 and e["out_abs"] <= 2e-4, e
