@@ -154,6 +154,12 @@ class SamplerMeter:
         return sum(a.elapsed_time(b) for a, b in self.events)
 
 
+# the statement of config.conv_arithmetic about the default mode's accuracy: the WORST mean-error ratio to the exact-fp32 MFMA
+# kernel over the five shapes of tests/test_conv_bf16x3_gpu.py::FP64_SHAPES (192->128 @64^2, 512->512 @64^2 with K = 4608, the
+# fused-upsample form, 128->128 @256^2, a 3-D layer), as printed into profiles/r6_parity.txt
+F16X2_FP64_RATIO = "at most 1.25x the fp32 MFMA kernel's on five layer shapes incl. K = 4608: worst measured ratio in profiles/r6_parity.txt"
+
+
 def host_cpu():
     """(physical cores, logical cpus, model string) of this box from /proc/cpuinfo"""
     model, cores, logical = "unknown", set(), 0
@@ -550,6 +556,41 @@ def strong_scaling(hp, cfg, dev, rank, world, total, B, S, seed, clips, warm, gr
                                            "frames (pose theta, driver pass, uint8 pack; hipGraph replay per batch), uint8 D2H into a pinned ring"}
 
 
+def sustained_mfma(dev, seconds=1.2):
+    """What the POWER-MANAGED chip sustains on a kernel that does nothing but fp16 MFMAs (emo_mfma_stream_f16: one wave per SIMD on
+    every CU, v_mfma_f32_32x32x16_f16 back to back on pseudo-random operands), measured behind the timed region on the same
+    box, about `seconds` of GPU time per form after a warm-up of the same length (the clock settles within ~0.3 s).  The data
+    sheet's 2.5 PF assumes 2.4 GHz; under a matrix stream this part runs 1.5-1.7 GHz.  A reader can then tell kernel quality
+    (roofline.frac_of_sustained) from clock (roofline.frac)."""
+    sink = torch.empty(256 * ops.device_cu_count(), device=dev, dtype=torch.float32)
+    out = {}
+    for key, lds in (("bare", False), ("with_fragment_reads", True)):
+        iters = 4000
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_mfma = ops.mfma_stream(iters, lds, sink)
+        torch.cuda.synchronize()
+        per_launch = max(1e-4, time.perf_counter() - t0)
+        reps = max(2, int(seconds / per_launch))
+        for _ in range(reps):                                   # warm-up: the clock under THIS load
+            ops.mfma_stream(iters, lds, sink)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.mfma_stream(iters, lds, sink)
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3
+        tf = n_mfma * reps * 32768 / sec / 1e12
+        out[key] = {"fp16_tflops": round(tf, 1), "launches": reps, "seconds": round(sec, 3),
+                    # 1024 lanes-wide MFMA throughput per CU and clock: 4 SIMDs x 32768 flop / 32 cycles
+                    "implied_clock_ghz": round(tf * 1e12 / (ops.device_cu_count() * 4 * 32768 / 32.0) / 1e9, 3)}
+    out["what"] = ("emo_mfma_stream_f16 (csrc/api.hip): bare v_mfma_f32_32x32x16_f16 stream, one wave per SIMD, all CUs, pseudo-random "
+                   "operands; with_fragment_reads adds 8 ds_read_b128 per 12 MFMAs (a step of the split kernels' K loop); measured in "
+                   "this run, behind the timed region")
+    return out
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` with N > 1 and no rendezvous environment: start N ranks ourselves (one process per GPU,
     RCCL backend) exactly as the driver would -- python -m torch.distributed.run on 127.0.0.1 -- and relay its output."""
@@ -580,6 +621,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--raw-weights", action="store_true", help="plain seeded initialisation instead of the trained-like checkpoint")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (extras)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the sustained-MFMA-rate measurement (roofline.sustained_peak)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay of the step")
     ap.add_argument("--total-frames", type=int, default=0,
                     help="STRONG scaling (BASELINE configs[3]): a step is one whole clip of this many driver frames of one identity, "
@@ -748,8 +790,20 @@ def main():
     # fp16-split layers whose device-side range check fired during the last step (their guarded bf16x3 launch then recomputed
     # them: correct, but the step was not the fp16 split's): none on the bench checkpoint
     recomputed = sorted(v for v in hp.overflow_events().values() if v) if hp.precision == "f16x2" else []
+    # host cores of every rank (parallel.pin_to_local_cores: next to the rank's GPU), for the record
+    affinity = [parallel.affinity_record()]
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, affinity[0])
+        affinity = gathered
     if rank != 0:
         return
+    sustained = None
+    if not a.no_sustained:
+        try:
+            sustained = sustained_mfma(dev)
+        except Exception as e:                                    # a diagnostic must never cost the headline line
+            sustained = {"error": repr(e)}
     frames = world * B * a.steps
     fps = frames / elapsed
     weak = {"scaling": "weak", "frames_per_s": round(fps, 3), "ms_per_step": round(elapsed / a.steps * 1e3, 3),
@@ -826,6 +880,15 @@ def main():
              "share_of_step": round(ms / (elapsed_metered * 1e3), 3)}
         if note:
             r["note"] = note
+        products = {"f16x2": 3, "f16x2_pointwise": 3, "bf16x3": 6, "f16": 1}.get(k)
+        if products and sustained and "bare" in sustained:
+            # the same fraction against what the chip SUSTAINS on a pure matrix stream at its power-managed clock (measured in this
+            # run): kernel quality apart from clock.  `frac` stays the fraction of the data-sheet peak
+            sp = sustained["bare"]["fp16_tflops"] / products
+            r["sustained_peak"] = round(sp, 1)
+            r["frac_of_sustained"] = round(tf / sp, 4) if sp > 0 else None
+            r["sustained_peak_note"] = (f"bare fp16 MFMA stream measured behind the timed region: {sustained['bare']['fp16_tflops']} TF "
+                                        f"(implied clock {sustained['bare']['implied_clock_ghz']} GHz) / {products} products")
         return r
 
     rec = {
@@ -847,8 +910,8 @@ def main():
                                                  "into 3 bf16 terms, 6 partial products on the bf16 matrix pipes (error vs fp64 <= "
                                                  "the fp32 MFMA kernel's, tests/test_conv_bf16x3_gpu.py); other convs: fp32 MFMA",
                                        "f16x2": "fp32 tensors and accumulation; 3x3 / 3x3x3 convs of the decoder and the WarpGenerator that a 256-position tile of the split kernel fits: every scaled fp32 operand as two "
-                                                "fp16 terms (2^-24 relative), 3 partial products on the fp16 matrix pipes (error vs fp64 "
-                                                "1.1x the fp32 MFMA kernel's); the operand range is checked on the device by every "
+                                                "fp16 terms (2^-24 relative), 3 partial products on the fp16 matrix pipes (mean error vs fp64 "
+                                                + F16X2_FP64_RATIO + "); the operand range is checked on the device by every "
                                                 "launch and a guarded bf16x3 launch recomputes a layer that left it "
                                                 "(tests/test_conv_bf16x3_gpu.py); the decoder's four 1x1 layers: the same split on "
                                                 "the pointwise kernel (guarded fp32 MFMA recomputation); other convs: fp32 MFMA",
@@ -866,6 +929,8 @@ def main():
                              "frac": round(samp_gbps / PEAK_HBM_GBPS, 4),
                              "avg_launch_ms": round(samp_ms / max(1, len(samp_meter.events)), 4)},
         "roofline_other_convs": {k: conv_roofline(k) for k in by_k if k != dom},
+        "sustained_mfma": sustained,
+        "host_affinity": affinity,
         "strong_scaling": strong if strong is not None else strong_extra,
         "weak_scaling": weak if strong is not None else None,
         "source_pass_ms": None if source_ms is None else round(source_ms, 2),

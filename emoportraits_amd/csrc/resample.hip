@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void upsample_trilinear_w2_kernel(const float*
       for (int k = 0; k < 4; ++k) a01[k] = r01[col[k]];
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a01[k] = a00[k];            // (factor 1: i1 == i0)
+      // (factor 1 along y: the generic kernel / ATen form 1 * v[i0] + 0 * v[i1] with i1 = i0 + 1; here the second tap is a copy of
+      // the first, i.e. v[i1] is never loaded.  Same bits for FINITE data; an Inf / NaN in v[i1] would propagate there (0 * Inf =
+      // NaN) and does not here -- the "same bits as ATen" statement of this kernel holds for finite inputs, which is what a
+      // GroupNorm'ed activation tensor is)
+      for (int k = 0; k < 4; ++k) a01[k] = a00[k];
     }
     if (fd == 2) {
       const float* r10 = p + zi1[ez] * HW + (long)yi0[ey] * W;
@@ -270,6 +274,43 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
 
+// one output element of F.interpolate(size=(Ho, Wo), align_corners=False) from the H x W window at p (row stride in floats)
+__device__ __forceinline__ float resize2d_at(const float* __restrict__ p, long row_stride, int H, int W, float sh, float sw,
+                                             int yo, int xo, int bicubic, int clamp01) {
+  float sy = sh * ((float)yo + 0.5f) - 0.5f, sx = sw * ((float)xo + 0.5f) - 0.5f;
+  if (!bicubic) {
+    sy = sy < 0.0f ? 0.0f : sy;
+    sx = sx < 0.0f ? 0.0f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const float v = ly0 * (lx0 * p[y0 * row_stride + x0] + lx1 * p[y0 * row_stride + x1]) +
+                    ly1 * (lx0 * p[y1 * row_stride + x0] + lx1 * p[y1 * row_stride + x1]);
+    return clamp01 ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
+  }
+  const float fy = floorf(sy), fx = floorf(sx);
+  const int iy = (int)fy, ix = (int)fx;
+  const float ty = sy - fy, tx = sx - fx;
+  const float A = -0.75f;
+  const float wy[4] = {cubic2(ty + 1.0f, A), cubic1(ty, A), cubic1(1.0f - ty, A), cubic2(2.0f - ty, A)};
+  const float wx[4] = {cubic2(tx + 1.0f, A), cubic1(tx, A), cubic1(1.0f - tx, A), cubic2(2.0f - tx, A)};
+  float acc = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    int yy = iy - 1 + a;
+    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+    float row = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int xx = ix - 1 + b;
+      xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+      row += p[yy * row_stride + xx] * wx[b];
+    }
+    acc += row * wy[a];
+  }
+  return clamp01 ? fminf(fmaxf(acc, 0.0f), 1.0f) : acc;   // bicubic overshoots: crop_image clips (infer.py:350)
+}
+
 __global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__ x, long plane_stride, long row_stride,
                                                        float* __restrict__ out, long NC,
                                                        int H, int W, int Ho, int Wo, int bicubic, int clamp01) {
@@ -280,40 +321,27 @@ __global__ __launch_bounds__(256) void resize2d_kernel(const float* __restrict__
     const long r = i / Wo;
     const int yo = (int)(r % Ho);
     const long nc = r / Ho;
-    const float* p = x + nc * plane_stride;
-    float sy = sh * ((float)yo + 0.5f) - 0.5f, sx = sw * ((float)xo + 0.5f) - 0.5f;
-    if (!bicubic) {
-      sy = sy < 0.0f ? 0.0f : sy;
-      sx = sx < 0.0f ? 0.0f : sx;
-      const int y0 = (int)sy, x0 = (int)sx;
-      const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-      const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-      const float v = ly0 * (lx0 * p[y0 * row_stride + x0] + lx1 * p[y0 * row_stride + x1]) +
-                      ly1 * (lx0 * p[y1 * row_stride + x0] + lx1 * p[y1 * row_stride + x1]);
-      out[i] = clamp01 ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
-    } else {
-      const float fy = floorf(sy), fx = floorf(sx);
-      const int iy = (int)fy, ix = (int)fx;
-      const float ty = sy - fy, tx = sx - fx;
-      const float A = -0.75f;
-      const float wy[4] = {cubic2(ty + 1.0f, A), cubic1(ty, A), cubic1(1.0f - ty, A), cubic2(2.0f - ty, A)};
-      const float wx[4] = {cubic2(tx + 1.0f, A), cubic1(tx, A), cubic1(1.0f - tx, A), cubic2(2.0f - tx, A)};
-      float acc = 0.0f;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        int yy = iy - 1 + a;
-        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-        float row = 0.0f;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          int xx = ix - 1 + b;
-          xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-          row += p[yy * row_stride + xx] * wx[b];
-        }
-        acc += row * wy[a];
-      }
-      out[i] = clamp01 ? fminf(fmaxf(acc, 0.0f), 1.0f) : acc;   // bicubic overshoots: crop_image clips (infer.py:350)
-    }
+    out[i] = resize2d_at(x + nc * plane_stride, row_stride, H, W, sh, sw, yo, xo, bicubic, clamp01);
+  }
+}
+
+// The same with one crop window PER SAMPLE (ABI 9; animate_frames' `windows`: the reference crops every frame around its own
+// face box, notebooks/infer.py:301-352): win[n] = (x0, y0, w, h) of sample n inside its Hf x Wf frame, read from device memory,
+// so that a batch of B frames is ONE launch instead of B (round 5: a Python loop of single-frame launches).  Per element the
+// arithmetic is resize2d_kernel's on the window's first pixel: the two are bit-identical.
+__global__ __launch_bounds__(256) void resize2d_windows_kernel(const float* __restrict__ x, long plane_stride, long row_stride,
+                                                               const int* __restrict__ win, float* __restrict__ out, long N,
+                                                               int C, int Ho, int Wo, int bicubic, int clamp01) {
+  const long total = N * C * Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xo = (int)(i % Wo);
+    const long r = i / Wo;
+    const int yo = (int)(r % Ho);
+    const long nc = r / Ho;
+    const int* const w4 = win + 4 * (nc / C);
+    const int wx0 = w4[0], wy0 = w4[1], ww = w4[2], wh = w4[3];
+    const float sh = (float)wh / (float)Ho, sw = (float)ww / (float)Wo;
+    out[i] = resize2d_at(x + nc * plane_stride + (long)wy0 * row_stride + wx0, row_stride, wh, ww, sh, sw, yo, xo, bicubic, clamp01);
   }
 }
 
@@ -439,5 +467,13 @@ extern "C" int emo_resize2d_f32(const float* x, int64_t plane_stride, int64_t ro
   if (!x || !out || NC <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || row_stride < W || plane_stride < 0) return EMO_ERR_BAD_ARG;
   hipLaunchKernelGGL(resize2d_kernel, dim3(grid_for(NC * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x,
                      (long)plane_stride, (long)row_stride, out, (long)NC, H, W, Ho, Wo, bicubic, clamp01);
+  return emo_launch_status();
+}
+
+extern "C" int emo_resize2d_windows_f32(const float* x, int64_t plane_stride, int64_t row_stride, const int* windows, float* out,
+                                        int N, int C, int Ho, int Wo, int bicubic, int clamp01, void* stream) {
+  if (!x || !out || !windows || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || row_stride <= 0 || plane_stride < 0) return EMO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(resize2d_windows_kernel, dim3(grid_for((long)N * C * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)plane_stride, (long)row_stride, windows, out, (long)N, C, Ho, Wo, bicubic, clamp01);
   return emo_launch_status();
 }

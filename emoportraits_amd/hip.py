@@ -21,6 +21,8 @@ _c_int, _c_i64, _c_void, _c_float = ctypes.c_int, ctypes.c_int64, ctypes.c_void_
 SIGNATURES = {
     "emo_abi_version": [],
     "emo_build_info": [],
+    "emo_device_cu_count": [],
+    "emo_mfma_stream_f16": [_c_void, _c_int, _c_int, ctypes.POINTER(_c_i64), _c_void],
     "emo_grid_sample3d_f32": [_c_void] * 7 + [_c_int] * 8 + [_c_i64] + [_c_int] * 5 + [_c_void],
     "emo_affine_grid3d_f32": [_c_void] * 5 + [_c_int] * 4 + [_c_void],
     "emo_volume_repack_f32": [_c_void, _c_void, _c_int, _c_int, _c_int, _c_int, _c_void],
@@ -47,6 +49,7 @@ SIGNATURES = {
     "emo_avgpool_f32": [_c_void, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
     "emo_add_f32": [_c_void, _c_void, _c_void, _c_i64, _c_i64, _c_float, _c_void],
     "emo_resize2d_f32": [_c_void, _c_i64, _c_i64, _c_void, _c_i64] + [_c_int] * 6 + [_c_void],
+    "emo_resize2d_windows_f32": [_c_void, _c_i64, _c_i64, _c_void, _c_void] + [_c_int] * 6 + [_c_void],
     "emo_conv2d_generic_f32": [_c_void] * 6 + [_c_int] * 11 + [_c_void, _c_void],
     "emo_conv2d_generic_splits": [_c_int] * 9,
     "emo_maxpool2d_f32": [_c_void] * 4 + [_c_i64] + [_c_int] * 6 + [_c_void],

@@ -105,3 +105,21 @@ def mixing_theta(source_theta, target_theta, mix_old=True):
             else:
                 out.append(src_stretch * tgt_stretch.mean() / src_stretch.mean() @ tgt_rot @ translation[i])   # :729-730
     return np.stack(out)[:, :3]
+
+
+def ema_scan(values, state, momentum):
+    """The `smooth_pose` recurrence of notebooks/infer.py:571-581 over a whole clip on the host:
+        theta_i = pred[i] * momentum + theta_{i-1} * (1 - momentum),   theta_{-1} = state, or pred[0] on the first call
+    values [n, ...] fp32 (n x 16 floats: cheap), state [...] or None -> (smoothed [n, ...], new state).  fp32 element for
+    element in the reference's operation order (two rounded products, one rounded sum; `1 - momentum` formed in double and
+    rounded to fp32 once, as torch does with a Python scalar), so the result is bit-identical to the reference's per-frame loop
+    of device ops -- and, being a scan over the FRAME ORDER, it has to run before the frames are sharded across ranks
+    (SURVEY.md section 8e)."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    m, om = np.float32(momentum), np.float32(1 - momentum)
+    cur = v[0].copy() if state is None else np.asarray(state, dtype=np.float32).reshape(v.shape[1:])
+    out = np.empty_like(v)
+    for i in range(v.shape[0]):
+        cur = v[i] * m + cur * om
+        out[i] = cur
+    return out, cur

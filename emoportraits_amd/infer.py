@@ -31,6 +31,11 @@ from . import embedders as emb_mod
 from . import graphs, hostglue, nets, ops, parallel, schema
 
 
+# smooth_pose in animate_frames: the crops of a rank's shard stay resident between the head-pose pass and the render pass up to
+# this many bytes (3 MB per 512^2 frame; beyond it they are cropped a second time)
+_SMOOTH_KEEP_BYTES = int(float(os.environ.get("EMO_SMOOTH_KEEP_GB", "16")) * (1 << 30))
+
+
 class HipModel:
     """The `self.model` attribute seam (b2): reference attribute names and call signatures over the HIP executors."""
 
@@ -315,6 +320,15 @@ class InferenceWrapper:
         srt = tuple(t.to(self.device).float().contiguous() for t in embed)
         return ops.pose_theta(*srt), srt
 
+    def _smooth_thetas(self, thetas):
+        """notebooks/infer.py:571-581 for a batch of thetas IN FRAME ORDER: the EMA runs once on the host over the 16 floats
+        per frame (hostglue.ema_scan: bit-identical to the reference's per-frame loop of device ops), `self.theta` carries the
+        state between calls as it does there.  One device -> host read of B x 16 floats instead of 3 B tiny launches + clones."""
+        state = None if self.theta is None else self.theta.detach().cpu().numpy()
+        sm, state = hostglue.ema_scan(thetas.detach().float().cpu().numpy(), state, self.pose_momentum)
+        self.theta = torch.from_numpy(state).to(self.device)
+        return torch.from_numpy(sm).to(self.device)
+
     def to_image(self, img_u8_hwc):
         from PIL import Image
         return Image.fromarray(img_u8_hwc)
@@ -423,13 +437,7 @@ class InferenceWrapper:
             if mix:                                                                                    # infer.py:568-569
                 pred_target_theta = self.get_mixing_theta(self.pred_source_theta, pred_target_theta)
             if smooth_pose:                                                                            # infer.py:571-581
-                if self.theta is None:
-                    self.theta = pred_target_theta[0].clone()
-                sm = []
-                for i in range(pred_target_theta.shape[0]):
-                    self.theta = pred_target_theta[i] * self.pose_momentum + self.theta * (1 - self.pose_momentum)
-                    sm.append(self.theta.clone())
-                pred_target_theta = torch.stack(sm)
+                pred_target_theta = self._smooth_thetas(pred_target_theta)
             self.pred_target_theta = pred_target_theta
             theta_used = pred_target_theta if target_theta else self.pred_source_theta
             # the reference runs the expression embedder on every driver frame (infer.py:596-601) and only then overrides
@@ -475,10 +483,17 @@ class InferenceWrapper:
         """Video in -> video out, device resident (notebooks/infer.py:511-556, :562-601, :641-644 per
         frame there).  frames: uint8 [N,H,W,3] tensor (host, ideally pinned, or device) or an iterable of such chunks --
         decoded video frames, uploaded as BYTES.  Per batch, all on the device and without a host synchronisation:
-            byte -> fp32 CHW (emo_unpack_rgb8) -> crop window read in place + bicubic resize to image_size
-            (emo_resize2d_f32; `windows[i] = (x_lo, y_lo, side)` from the face detector + hostglue.crop_window, host
-            arithmetic; None = whole frame) -> HeadPoseRegressor -> ExpressionEmbed -> hot path -> uint8 HWC.
+            byte -> fp32 CHW (emo_unpack_rgb8) -> crop windows read in place + bicubic resize to image_size, the whole batch in
+            one launch (emo_resize2d_windows_f32; `windows[i] = (x_lo, y_lo, side)` from the face detector +
+            hostglue.crop_window, host arithmetic; None = whole frame) -> HeadPoseRegressor -> ExpressionEmbed -> hot path ->
+            uint8 HWC.
         The driver-side matte (MODNet) of the reference is computed but unused with use_seg=False (infer.py:592-601): skipped.
+        smooth_pose (infer.py:571-581) is a scan over the FRAME ORDER, so it runs before the frames are sharded (SURVEY.md
+        section 8e): per chunk, every rank regresses the head pose of its own shard, the thetas (16 floats per frame) are
+        gathered on every rank, the EMA runs once on the host over the whole chunk (hostglue.ema_scan, state carried from chunk
+        to chunk in `self.theta` exactly as the reference carries it from call to call), and only then does each rank render
+        its shard with its slice of the smoothed thetas -- 1 rank and N ranks produce the same frames.  That pass costs one
+        host synchronisation per chunk; the crops of the shard stay resident between the two passes (3 MB per frame).
         to_host: results go D2H into a ring of `ring` pinned buffers on a copy stream; a batch is yielded once ITS copy
         event has completed, i.e. the host only ever waits for a batch that is `ring - 1` batches behind the GPU.
         Yields (first_frame_index, uint8 [b,S,S,3]) -- a view of a pinned ring slot, valid ONLY until the generator is resumed
@@ -497,34 +512,42 @@ class InferenceWrapper:
                 ev.synchronize()
                 yield b0, slots[slot][:nb]
 
+        def crops_of(chunk, base, b0, b1):
+            u8 = chunk[b0:b1].to(self.device, non_blocking=True).contiguous()
+            x = ops.unpack_rgb8(u8)
+            if windows is not None:
+                wins = [(w[0], w[1], w[2], w[2]) for w in windows[base + b0:base + b1]]
+                return ops.resize2d_windows(x, (S, S), wins, "bicubic", clamp01=True)
+            if x.shape[-2:] != (S, S):
+                return ops.resize2d(x, (S, S), "bicubic")
+            return x
+
         base, k = 0, 0
         for chunk in chunks:
             if chunk.dtype != torch.uint8 or chunk.dim() != 4 or chunk.shape[-1] != 3:
                 raise ValueError("frames must be uint8 [N,H,W,3]")
             n = chunk.shape[0]
             lo, hi = parallel.shard_range(n, self.rank, self.world)
+            smoothed, kept = None, {}
+            if smooth_pose:
+                keep_crops = (hi - lo) * 3 * S * S * 4 <= _SMOOTH_KEEP_BYTES
+                local = []
+                for b0 in range(lo, hi, batch_size):
+                    b1 = min(b0 + batch_size, hi)
+                    crops = crops_of(chunk, base, b0, b1)
+                    local.append(self._head_pose(crops)[0].clone())
+                    if keep_crops:
+                        kept[b0] = crops
+                local = torch.cat(local) if local else torch.empty((0, 4, 4), device=self.device)
+                every = parallel.gather_shards(local, n, self.rank, self.world)        # [n,4,4] on every rank, frame order
+                smoothed = self._smooth_thetas(every)[lo:hi]
             for b0 in range(lo, hi, batch_size):
                 b1 = min(b0 + batch_size, hi)
-                u8 = chunk[b0:b1].to(self.device, non_blocking=True).contiguous()
-                x = ops.unpack_rgb8(u8)
-                if windows is not None:
-                    crops = torch.cat([ops.resize2d(x[i:i + 1], (S, S), "bicubic",
-                                                    window=(*windows[base + b0 + i][:2], windows[base + b0 + i][2],
-                                                            windows[base + b0 + i][2]), clamp01=True)
-                                       for i in range(b1 - b0)])
-                elif x.shape[-2:] != (S, S):
-                    crops = ops.resize2d(x, (S, S), "bicubic")
-                else:
-                    crops = x
-                theta, *_ = self._head_pose(crops)
-                if smooth_pose:                      # scan over frame order (infer.py:571-581): a per-rank host loop
-                    if self.theta is None:
-                        self.theta = theta[0].clone()
-                    sm = []
-                    for i in range(theta.shape[0]):
-                        self.theta = theta[i] * self.pose_momentum + self.theta * (1 - self.pose_momentum)
-                        sm.append(self.theta.clone())
-                    theta = torch.stack(sm)
+                crops = kept.pop(b0, None)
+                if crops is None:
+                    crops = crops_of(chunk, base, b0, b1)
+                theta = smoothed[b0 - lo:b1 - lo] if smoothed is not None else self._head_pose(crops)[0]
+                self.pred_target_theta = theta                                   # (as forward() leaves it: infer.py:584)
                 pose, _ = self._expression(crops, theta, 'a driver call')
                 out = ops.pack_rgb8(self._drive(pose, theta.float().contiguous()))
                 if not to_host:

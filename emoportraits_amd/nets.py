@@ -323,10 +323,13 @@ class HotPath:
         # (archive/profiles/r3_sampler_microbench.jsonl): off
         self.sampler_rot_variant = int(os.environ.get("EMO_SAMPLER_ROT_VARIANT", "0"))
         from .pack import conv_precision
-        # fp16 mode: the WarpGenerators stay exact fp32 (EMO_WARP_PRECISION=f16 overrides) -- their output is GEOMETRY (where
-        # the volume is sampled): measured at R256, fp16 operands there put 2e-3 on the deltas and 2e-2 of max on the warped
-        # volume, 10x the 1-2e-3 the decoder's own fp16 rounding causes (tools/diag_f16.py), for 10 % of the time
-        wprec = os.environ.get("EMO_WARP_PRECISION", "f32") if precision == "f16" else precision
+        # fp16 mode: the WarpGenerators keep fp32-accurate arithmetic (EMO_WARP_PRECISION=f16 overrides) -- their output is
+        # GEOMETRY (where the volume is sampled): measured at R256, fp16 operands there put 2e-3 on the deltas and 2e-2 of max
+        # on the warped volume, 10x the 1-2e-3 the decoder's own fp16 rounding causes (tools/diag_f16.py), for 10 % of the
+        # time.  fp32-accurate means the range-checked fp16 SPLIT (round 6; 4.9 ms per 16 frames), not the fp32 MFMA kernel
+        # (8.8 ms; EMO_WARP_PRECISION=f32 restores it): same deltas to 1e-5
+        wprec = os.environ.get("EMO_WARP_PRECISION", "f16x2") if precision == "f16" else precision
+        self.warp_precision = wprec
         with conv_precision(wprec):
             self.uv_generator = WarpGenerator(sd, "uv_generator_nw", cfg, self.device)
             if with_source:
@@ -344,7 +347,7 @@ class HotPath:
         """'f16x2': zero the overflow words of the fp16-split layers at the start of a pass (one fill kernel, stream-ordered,
         captured with the pass).  A word raised during the pass makes the guarded bf16x3 launch behind that layer recompute it
         (ops.conv_igemm); overflow_events() reports which layers did."""
-        if self.precision == "f16x2":
+        if "f16x2" in (self.precision, self.warp_precision):
             ops.clear_overflow_flags(self.device)
 
     def overflow_events(self):

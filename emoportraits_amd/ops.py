@@ -336,28 +336,41 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         # the fp16 split checks its operand range on the device (overflow word of the layer); the guarded bf16x3 launch behind
         # it recomputes the layer with exact operands when the word is raised -- no host synchronisation, graph-capturable
         flag = pack_mod.overflow_flag_ptr(x.device, layer.flag_slot) if F16X2_GUARD else None
+        caller_out = None
         if F16X2_GUARD and res is not None and _shares_storage(out, res):
             # the guarded launch re-reads res AFTER the first launch has written out: an output that aliases it (a residual
-            # updated in place) would feed the first launch's result into the recomputation -- conv + clipped conv + res
+            # updated in place) would feed the first launch's result into the recomputation -- conv + clipped conv + res.
+            # Both launches write a private buffer; the caller's `out` receives the result behind them, so that `out=` means
+            # the same in every precision mode and guard state
+            caller_out = out
             out = torch.empty(shape, device=x.device, dtype=torch.float32)
             common = common[:4] + (hip.ptr(out),) + common[5:]
-        rc = entry(hip.ptr(x), hip.ptr(wpk), *common, pack_mod.F16X2_IN_SCALE, layer.w_scale, flag)
-        hip.check(rc, f"emo_conv_igemm_f16x2[{layer.name}]")
+        gplan = None
         if F16X2_GUARD and pointwise_split:
-            # (pointwise layer: the exact recomputation is the fp32 MFMA kernel at its own launch plan)
+            # (pointwise layer: the exact recomputation is the fp32 MFMA kernel at its own launch plan -- made BEFORE the fp16-split
+            # launch is enqueued, and without a K split when tile statistics travel with the output: a split launch cannot
+            # produce them, and raising behind the first launch would leave `out` / `stats` un-recomputed with the word raised)
             gcfg, gks = pack_mod.plan_launch(layer.cout, layer.cin, layer.kd, layer.kh, layer.kw, max(1, -(-positions // 128)),
                                              layer.allowed, "f32")
-            if gks > 1 and stats is not None:
-                raise RuntimeError("pointwise fp16-split launch with tile statistics: the guarded fp32 launch may not split K")
+            if stats is not None:
+                gks = 1
+            gplan = (gcfg, gks, layer.packed(gcfg))
+        rc = entry(hip.ptr(x), hip.ptr(wpk), *common, pack_mod.F16X2_IN_SCALE, layer.w_scale, flag)
+        hip.check(rc, f"emo_conv_igemm_f16x2[{layer.name}]")
+        if gplan is not None:
+            gcfg, gks, gw = gplan
             gws = torch.empty((gks, out.numel()), device=x.device, dtype=torch.float32) if gks > 1 else None
             gcommon = common[:18] + (gcfg, gks, hip.ptr(gws), None if gks > 1 else common[21], common[22])
-            rc = lib.emo_conv_igemm_f32_guarded(hip.ptr(x), hip.ptr(layer.packed(gcfg)), *gcommon, flag)
+            rc = lib.emo_conv_igemm_f32_guarded(hip.ptr(x), hip.ptr(gw), *gcommon, flag)
             hip.check(rc, f"emo_conv_igemm_f32_guarded[{layer.name}]")
         elif F16X2_GUARD:
             # (the exact recomputation runs the 64-row tile of the bf16 split whatever tile the fp16-split launch used)
             gcommon = common[:18] + (pack_mod.CFG_D,) + common[19:]
             rc = lib.emo_conv_igemm_bf16x3(hip.ptr(x), hip.ptr(layer.packed(pack_mod.CFG_D, "bf16x3")), *gcommon, flag)
             hip.check(rc, f"emo_conv_igemm_bf16x3[{layer.name}, guarded]")
+        if caller_out is not None:
+            caller_out.copy_(out)
+            out = caller_out
     else:
         extra = (None,) if prec == "bf16x3" else ()
         rc = entry(hip.ptr(x), hip.ptr(wpk), *common, *extra)
@@ -561,6 +574,49 @@ def resize2d(x, size, mode="bilinear", window=None, clamp01=False):
                                    {"bilinear": 0, "bicubic": 1}[mode], int(clamp01), hip.current_stream()),
               "emo_resize2d_f32")
     return out
+
+
+def resize2d_windows(x, size, windows, mode="bicubic", clamp01=False):
+    """torch.cat([F.interpolate(x[i:i+1, :, y0:y0+h, x0:x0+w], size=size, mode=mode, align_corners=False) for i ...]) in ONE
+    launch (notebooks/infer.py:301-352 crops every frame around its own face box): windows = one (x0, y0, w, h) per frame --
+    a host sequence (uploaded here: 16 bytes per frame) or an int32 [N,4] device tensor.  Bit-identical to resize2d per frame."""
+    lib = hip.load()
+    hip.require_cuda_f32(x)
+    N, C, H, W = x.shape
+    if isinstance(windows, torch.Tensor):
+        win = windows
+        if not win.is_cuda or win.dtype != torch.int32 or tuple(win.shape) != (N, 4) or not win.is_contiguous():
+            raise RuntimeError("windows must be a contiguous int32 cuda tensor [N,4]")
+    else:
+        host = torch.tensor([[int(v) for v in w] for w in windows], dtype=torch.int32).reshape(-1, 4)
+        if host.shape[0] != N:
+            raise ValueError(f"{host.shape[0]} windows for {N} frames")
+        lo, hi = host[:, :2], host[:, :2] + host[:, 2:]
+        if not (bool((lo >= 0).all()) and bool((host[:, 2:] > 0).all()) and bool((hi[:, 0] <= W).all()) and bool((hi[:, 1] <= H).all())):
+            raise ValueError(f"a resize window is not inside the {W}x{H} frame")
+        win = host.to(x.device, non_blocking=True)
+    Ho, Wo = size
+    out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    hip.check(lib.emo_resize2d_windows_f32(hip.ptr(x), H * W, W, hip.ptr(win), hip.ptr(out), N, C, Ho, Wo,
+                                           {"bilinear": 0, "bicubic": 1}[mode], int(clamp01), hip.current_stream()),
+              "emo_resize2d_windows_f32")
+    return out
+
+
+def device_cu_count():
+    """compute units of the current device as the C launchers count them (include/emo_hip.h, ABI 9)"""
+    return hip.load().emo_device_cu_count()
+
+
+def mfma_stream(iters=2000, lds_reads=False, sink=None):
+    """one launch of the bare fp16 MFMA stream (diagnostic: bench.py `roofline.sustained_peak`) -> MFMA instructions issued"""
+    lib = hip.load()
+    if sink is None:
+        sink = torch.empty(256 * device_cu_count(), device="cuda", dtype=torch.float32)
+    n = ctypes.c_int64(0)
+    hip.check(lib.emo_mfma_stream_f16(hip.ptr(sink), int(iters), int(bool(lds_reads)), ctypes.byref(n), hip.current_stream()),
+              "emo_mfma_stream_f16")
+    return n.value
 
 
 # ---- embedder ResNets (SURVEY.md section 8f-1) -----------------------------------------------------------------------

@@ -262,7 +262,21 @@ if __import__("os").environ.get("EMO_CONV_CFG_D") == "0":   # A/B switch: plan w
     _CFG_EFF[CFG_D] = 0.0
 if __import__("os").environ.get("EMO_CONV_CFG_E") == "1":   # A/B switch: plan with the 64 x 512 tile
     _CFG_EFF[CFG_E] = 1.06
-_FILL_BLOCKS = 512   # 2 blocks per CU on 256 CUs
+
+
+@functools.lru_cache(maxsize=None)
+def cu_count():
+    """compute units the C launchers size their grids by (emo_device_cu_count, ABI 9: the current device's, a multiple of 8; 256
+    on MI355X, 32 .. 128 on its partitions; 256 without a device) -- the planner's fill targets follow it, so that Python and C
+    agree on when the pointwise / two-tile launch forms pay off.  Read once per process (one process per GPU)."""
+    try:
+        return int(hip.load().emo_device_cu_count())
+    except Exception:
+        return 256
+
+
+def _fill_blocks():
+    return 2 * cu_count()   # 2 blocks per CU
 
 
 def cfg_d_fits(kd, kh, kw, Hl, Wl):
@@ -287,7 +301,7 @@ def choose_cfg_for_launch(cout, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C)):
         bm = _BM[cfg]
         cot = -(-cout // bm)
         blocks = cot * n_pos_tiles
-        score = min(blocks, _FILL_BLOCKS) / _FILL_BLOCKS * (cout / (cot * bm)) * _CFG_EFF[cfg]
+        score = min(blocks, _fill_blocks()) / _fill_blocks() * (cout / (cot * bm)) * _CFG_EFF[cfg]
         if best is None or score > best[0] + 1e-9:
             best = (score, cfg)
     return best[1]
@@ -305,17 +319,20 @@ _MAX_KSPLIT = 16
 
 
 def ksplit_for(blocks, nstages):
-    """split the K loop until the launch has _FILL_BLOCKS blocks, keeping >= 8 stages per split
+    """split the K loop until the launch has two blocks per CU, keeping >= 8 stages per split
     (same rule as emo_conv_igemm_ksplit in csrc/conv_api.hip)"""
-    if blocks >= _FILL_BLOCKS:
+    fill = _fill_blocks()
+    if blocks >= fill:
         return 1
-    return max(1, min(-(-_FILL_BLOCKS // blocks), nstages // 8, _MAX_KSPLIT))
+    return max(1, min(-(-fill // blocks), nstages // 8, _MAX_KSPLIT))
 
 
-def _quantisation(nblocks, cus=256):
+def _quantisation(nblocks, cus=None):
     """a launch of a few blocks per CU finishes when the most loaded CU does: 640 blocks put 3 on half of the CUs and 2 on
     the rest -- 2.5 / 3 of the machine.  Measured at batch 2 (archive/profiles/r3_conv_microbench_b2.jsonl): 320 -> 320 @128^2 runs at
     113 TF on the 64 x 256 tile (640 blocks) and at 130 TF on the 64 x 128 tile (1280 blocks)."""
+    if cus is None:
+        cus = cu_count()
     if nblocks < cus or EMO_PLAN_QUANTISATION == 0:
         return 1.0
     per_cu = nblocks / cus
@@ -335,7 +352,7 @@ def plan_launch(cout, cin, kd, kh, kw, n_pos_tiles, allowed=(CFG_A, CFG_B, CFG_C
         cot = -(-cout // bm)
         blocks = cot * max(1, n_pos_tiles * 128 // _BP[cfg])
         ks = ksplit_for(blocks, nstages)
-        score = min(blocks * ks, _FILL_BLOCKS) / _FILL_BLOCKS * (cout / (cot * bm)) * _CFG_EFF[cfg] * (0.97 if ks > 1 else 1.0)
+        score = min(blocks * ks, _fill_blocks()) / _fill_blocks() * (cout / (cot * bm)) * _CFG_EFF[cfg] * (0.97 if ks > 1 else 1.0)
         score *= _quantisation(blocks * ks)
         if best is None or score > best[0] + 1e-9:
             best = (score, cfg, ks)
@@ -397,12 +414,14 @@ def supports_f16x2_pointwise(cout, cin, kd, kh, kw):
         and (-(-cin // F16X2_P1_KC)) % 2 == 0          # (its K loop runs two 32-channel stages per iteration)
 
 
-def f16x2_pointwise_launch_fits(Hl, Wl, ups, n_pos_tiles, cout, act="none"):
-    """the launch form of the pointwise kernel: 4 x 64 position tiles on the source grid, no activation, and enough pair items
-    for two per CU (below that the fp32 MFMA kernel's K split fills the chip better)"""
-    if Hl is None or ups or act != "none" or Wl % 64 or Hl % 4:
+def f16x2_pointwise_launch_fits(Hl, Wl, ups, n_pos_tiles, cout, act="none", positions_per_sample=0):
+    """the launch form of the pointwise kernel (conv_f16x2_p1_launch, csrc/conv_igemm_f16x2_p1.h -- every check of the C launcher
+    has its mirror here, so that a launch it would refuse with EMO_ERR_UNSUPPORTED is planned onto the fp32 MFMA kernel instead):
+    4 x 64 position tiles on the source grid, no activation, at most 2^23 positions per sample (its 32-bit offsets), and enough
+    pair items for two per CU of THIS device (below that the fp32 MFMA kernel's K split fills the chip better)"""
+    if Hl is None or ups or act != "none" or Wl % 64 or Hl % 4 or positions_per_sample > (1 << 23):
         return False
-    min_items = int(__import__("os").environ.get("EMO_F16X2_P1_MIN_ITEMS", 2 * 256))      # (tests lower it to reach small shapes)
+    min_items = int(__import__("os").environ.get("EMO_F16X2_P1_MIN_ITEMS", 2 * cu_count()))      # (tests lower it to reach small shapes)
     return (n_pos_tiles // 2) * (-(-(cout // BF16X3_BM) // 2)) >= min_items
 
 
@@ -443,7 +462,9 @@ class PackedConv:
         self.pinned_cfg = cfg
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
-        self.pointwise_split = precision == "f16x2" and supports_f16x2_pointwise(cout, cin, kd, kh, kw)
+        self.pointwise_split = precision == "f16x2" and F16X2_POINTWISE and supports_f16x2_pointwise(cout, cin, kd, kh, kw)
+        if precision == "f16x2" and not F16X2_POINTWISE and (kd, kh, kw) == (1, 1, 1):
+            precision = "f32"           # (EMO_F16X2_POINTWISE=0: the A/B switch also holds for an explicitly requested precision)
         if precision in ("bf16x3", "f16x2") and not self.pointwise_split and not supports_bf16x3(cout, cin, kd, kh, kw, precision):
             raise ValueError(f"{name}: the split-operand kernel covers 3x3 / 3x3x3 convolutions with a multiple of 8 input channels "
                              f"(fp16 split: also 1x1 layers with at least 128 output channels)")
@@ -465,7 +486,8 @@ class PackedConv:
             self.packed(first if first in self.allowed else CFG_B)
             self.flag_slot = overflow_flag_slot(device, name)
         elif precision in ("bf16x3", "f16x2"):
-            self.packed(CFG_D, precision)       # eager, like the fp32 layout: the first launch is not a host-side packing job
+            # eager, like the fp32 layout: the first launch is not a host-side packing job
+            self.packed(f16x2_tile_cfg(cout) if precision == "f16x2" else CFG_D, precision)
             if precision == "f16x2":            # the guarded exact recomputation behind a raised overflow flag (ops.conv_igemm)
                 if F16X2_GUARD_DEFAULT:         # (EMO_F16X2_GUARD=0 builds never launch it: packed lazily if a caller turns
                     self.packed(CFG_D, "bf16x3")    # the guard on later -- 1.5x the fp16 planes' memory otherwise)
@@ -489,13 +511,19 @@ class PackedConv:
                 self._packed["bf16x3"] = pack_weight_bf16x3(self._weight).to(self.device)
             return self._packed["bf16x3"]
         if precision == "f16x2":
-            if "f16x2" not in self._packed:
+            # keyed by the channel tile height: a layer with <= 32 output channels is packed for the 32-row tile (block config F)
+            # eagerly and -- lazily, like the guard's bf16x3 weights -- for the 64-row tile (D) that its launches on 32- / 16-wide
+            # maps or with a fused upsample run (round 5 sent those to the fp32 MFMA kernel: another speed AND another
+            # arithmetic path).  w_scale depends on max|w| only: the same for both layouts
+            bm = BF16X3_BM if (self.pointwise_split or cfg != CFG_F) else 32
+            key = ("f16x2", bm)
+            if key not in self._packed:
                 if self.pointwise_split:
                     flat, self.w_scale = pack_weight_f16x2_1x1(self._weight)
                 else:
-                    flat, self.w_scale = pack_weight_f16x2(self._weight, bm=_BM[f16x2_tile_cfg(self.cout)])
-                self._packed["f16x2"] = flat.to(self.device)
-            return self._packed["f16x2"]
+                    flat, self.w_scale = pack_weight_f16x2(self._weight, bm=bm)
+                self._packed[key] = flat.to(self.device)
+            return self._packed[key]
         cfg = _PACK_AS.get(cfg, cfg)
         if cfg not in self._packed:
             self._packed[cfg] = pack_weight(self._weight, cfg).to(self.device)
@@ -520,19 +548,20 @@ class PackedConv:
             cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, tiles, "f16")
             return cfg, ks, "f16"
         if self.pointwise_split:
-            if f16x2_pointwise_launch_fits(Hl, Wl, ups, n_pos_tiles, self.cout, act) and self.pinned_cfg in (None, CFG_D) \
+            if f16x2_pointwise_launch_fits(Hl, Wl, ups, n_pos_tiles, self.cout, act, in_elems_per_sample // max(1, self.cin)) \
+                    and self.pinned_cfg in (None, CFG_D) \
                     and aligned16 and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
                 return CFG_D, 1, "f16x2"
         elif self.precision in ("bf16x3", "f16x2") and bf16x3_launch_fits(Hl, Wl, ups) and self.pinned_cfg in (None, CFG_D) \
                 and aligned16 and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN):
             tile = CFG_D
-            if self.precision == "f16x2" and f16x2_tile_cfg(self.cout) == CFG_F:
-                # (the weights are packed for the 32-row tile, which exists for 4 x 64 position tiles without fused upsample:
-                # other maps of such a layer run the fp32 MFMA kernel)
-                tile = CFG_F if (Wl % 64 == 0 and not ups) else None
-            if tile is not None:
-                cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (tile,), self.precision)
-                return cfg, ks, self.precision
+            if self.precision == "f16x2" and f16x2_tile_cfg(self.cout) == CFG_F and Wl % 64 == 0 and not ups:
+                # (the 32-row tile exists for 4 x 64 position tiles without fused upsample; other maps of such a layer run the
+                # half-empty 64-row tile -- still the fp16 split's arithmetic, 1.3-1.6x the fp32 MFMA kernel -- from a 64-row
+                # packing made on first use: PackedConv.packed)
+                tile = CFG_F
+            cfg, ks = plan_launch(self.cout, self.cin, self.kd, self.kh, self.kw, n_pos_tiles, (tile,), self.precision)
+            return cfg, ks, self.precision
         pinned = None if self.pinned_cfg == CFG_G else self.pinned_cfg   # (G exists for fp16 operands only)
         allowed = (pinned,) if pinned is not None else self.allowed
         if self.pinned_cfg is None and _CFG_EFF[CFG_D] > 0 and cfg_d_fits(self.kd, self.kh, self.kw, Hl, Wl):

@@ -29,9 +29,107 @@ def local_device_index():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def _parse_cpulist(text):
+    """'0-15,64-79' -> [0, ..., 15, 64, ..., 79] (the sysfs cpulist format)"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def plan_affinity(local_rank, n_local, gpu_nodes, node_cpus, allowed):
+    """Host cores for the rank that drives GPU `local_rank` of a node with `n_local` ranks (pure function: tests run it on
+    made-up topologies).  gpu_nodes[i] = NUMA node of GPU i (None / -1: unknown), node_cpus = {node: [cpus]}, allowed = the cpus
+    this process may run on.  A rank gets the cores of its GPU's NUMA node, split evenly between the ranks whose GPUs hang off
+    the same node (in local-rank order), so that the pinned staging rings and the launch thread sit next to the GPU's PCIe root
+    and no two ranks share a core; with an unknown topology the allowed cores are split evenly by local rank instead.
+    -> (sorted cpu list, how)"""
+    allowed = sorted(allowed)
+    node = gpu_nodes[local_rank] if local_rank < len(gpu_nodes) else None
+    if node is not None and node >= 0 and node in node_cpus:
+        mine = [c for c in node_cpus[node] if c in set(allowed)]
+        peers = [r for r in range(n_local) if r < len(gpu_nodes) and gpu_nodes[r] == node]
+        if mine and local_rank in peers and len(mine) >= len(peers):
+            k, per = peers.index(local_rank), len(mine) // len(peers)
+            return mine[k * per:(k + 1) * per], f"numa node {node}: share {k + 1} of {len(peers)}"
+    per = len(allowed) // max(1, n_local)
+    if per == 0:
+        return allowed, "all allowed cores (fewer cores than ranks)"
+    return allowed[local_rank * per:(local_rank + 1) * per], f"even split of the allowed cores: share {local_rank + 1} of {n_local}"
+
+
+def _gpu_numa_nodes():
+    """NUMA node of every visible GPU from sysfs (PCI bus id -> /sys/bus/pci/devices/<id>/numa_node); None where unknown"""
+    nodes = []
+    for i in range(torch.cuda.device_count()):
+        node = None
+        try:
+            pr = torch.cuda.get_device_properties(i)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                node = int(f.read().strip())
+        except Exception:
+            node = None
+        nodes.append(node)
+    return nodes
+
+
+def _node_cpus():
+    out = {}
+    base = "/sys/devices/system/node"
+    try:
+        for name in os.listdir(base):
+            if name.startswith("node") and name[4:].isdigit():
+                with open(os.path.join(base, name, "cpulist")) as f:
+                    out[int(name[4:])] = _parse_cpulist(f.read())
+    except OSError:
+        pass
+    return out
+
+
+_affinity = None      # what pin_to_local_cores() did in this process (bench.py puts it into its record)
+
+
+def pin_to_local_cores(local_rank=None, n_local=None):
+    """Bind this process to the host cores next to its GPU (plan_affinity) -- BEFORE the pinned staging buffers are allocated
+    (first-touch places their pages on the node of the touching core) and before the intra-op thread pool is sized.  Multi-rank
+    runs only; EMO_PIN_CORES=0 turns it off.  -> the record, also kept for affinity_record()."""
+    global _affinity
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if n_local is None:
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    rec = {"pinned": False, "local_rank": local_rank, "n_local": n_local}
+    if os.environ.get("EMO_PIN_CORES", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        rec["how"] = "off"
+    else:
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+            nodes = _gpu_numa_nodes() if torch.cuda.is_available() else []
+            forced = os.environ.get("EMO_FORCE_DEVICE")
+            if forced is not None:            # ranks sharing one GPU (test hook): the topology says nothing, split evenly
+                nodes = []
+            cpus, how = plan_affinity(local_rank, n_local, nodes, _node_cpus(), allowed)
+            os.sched_setaffinity(0, cpus)
+            rec.update(pinned=True, how=how, n_cpus=len(cpus), cpus=f"{cpus[0]}-{cpus[-1]}" if cpus else "",
+                       gpu_numa_node=nodes[local_rank] if local_rank < len(nodes) else None)
+        except Exception as e:                # affinity is an optimisation: never fail a run over it
+            rec["how"] = f"failed: {e}"
+    _affinity = rec
+    return rec
+
+
+def affinity_record():
+    return _affinity
+
+
 def init_distributed(backend=None, force=False):
-    """-> (rank, world).  One process per GPU: rank r is bound to GPU LOCAL_RANK explicitly, the intra-op CPU thread pool is
-    capped to the rank's share of the host cores (unless OMP_NUM_THREADS is set).  Without a WORLD_SIZE > 1 environment this
+    """-> (rank, world).  One process per GPU: rank r is bound to GPU LOCAL_RANK explicitly and to the host cores of that GPU's
+    NUMA node (pin_to_local_cores), the intra-op CPU thread pool is capped to the rank's share of the host cores (unless
+    OMP_NUM_THREADS is set).  Without a WORLD_SIZE > 1 environment this
     is a no-op unless `force` (or EMO_DIST_FORCE_INIT=1): then a 1-rank group is created, so that the very same collective
     calls run through RCCL on a single-GPU box (tests/test_rccl_gpu.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -47,8 +145,12 @@ def init_distributed(backend=None, force=False):
         os.environ.setdefault("WORLD_SIZE", "1")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_device_index())
+        if world > 1:
+            # every rank on the cores next to its GPU, before anything allocates pinned memory (risk 2)
+            pin_to_local_cores()
         if "OMP_NUM_THREADS" not in os.environ:
-            torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(1, world)))
+            share = len(os.sched_getaffinity(0)) if (_affinity or {}).get("pinned") else (os.cpu_count() or 1) // max(1, world)
+            torch.set_num_threads(max(1, share))
         dist.init_process_group(backend=backend, init_method="env://")
     return dist.get_rank(), dist.get_world_size()
 
@@ -60,6 +162,35 @@ def shard_range(n_items, rank, world):
     q, r = divmod(n_items, world)
     lo = rank * q + min(rank, r)
     return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_shards(local, n_items, rank=None, world=None):
+    """Rows of the contiguous shards (shard_range) of every rank -> the whole [n_items, ...] tensor on EVERY rank, in frame
+    order.  Used for per-frame SCALARS only (the head-pose thetas of a clip, 16 floats per frame, in front of the smooth_pose
+    scan -- SURVEY.md section 8e caveat); frames themselves never travel.  One all_gather of equal-size padded shards."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_range(n_items, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} rows, its shard of {n_items} is [{lo}, {hi})")
+    if world == 1:
+        return local
+    if not dist.is_initialized():
+        raise RuntimeError(f"gather_shards(world={world}) without a process group: call init_distributed() first")
+    if world != dist.get_world_size():
+        raise RuntimeError(f"world={world} does not match the process group's {dist.get_world_size()} ranks")
+    per = -(-n_items // world)                                  # the largest shard
+    mine = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    mine[:hi - lo].copy_(local)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    rows = []
+    for r in range(world):
+        a, b = shard_range(n_items, r, world)
+        rows.append(parts[r][:b - a])
+    return torch.cat(rows)
 
 
 _MAX_DIMS = 6

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 8
+#define EMO_ABI_VERSION 9
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
@@ -54,6 +54,15 @@ extern "C" {
 int emo_abi_version(void);
 /* human-readable build string: arch, compiler, kernel variants */
 const char* emo_build_info(void);
+/* ABI 9.  Compute units of the current device as the launchers count them (rounded down to a multiple of 8, at least 8): the
+ * persistent grids of the split convolutions and the thresholds of their launch forms are sized by it, and so is the Python
+ * planner (emoportraits_amd/pack.py) -- no reference counterpart (the reference leaves launch geometry to cuDNN). */
+int emo_device_cu_count(void);
+/* ABI 9.  Diagnostic (bench.py `roofline.sustained_peak`, not on the hot path): one launch of a bare v_mfma_f32_32x32x16_f16
+ * stream -- one wave per SIMD on every CU, `iters` x 96 MFMAs per wave on pseudo-random operands; lds_reads != 0 adds the
+ * fragment reads of the split kernels' K loop (8 ds_read_b128 per 12 MFMAs).  *mfma_per_launch = MFMA instructions the launch
+ * issues (x 32768 flop each).  sink: >= 256 x CUs floats (never written in practice). */
+int emo_mfma_stream_f16(float* sink, int iters, int lds_reads, int64_t* mfma_per_launch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a1 -- 3-D trilinear grid_sample, align_corners=False.
@@ -298,6 +307,11 @@ int emo_add_f32(const float* a, const float* b, float* out, int64_t n, int64_t p
  * frame is read in place; clamp01 clips the result to [0,1] (crop_image, infer.py:350). */
 int emo_resize2d_f32(const float* x, int64_t plane_stride, int64_t row_stride, float* out, int64_t NC, int H, int W,
                      int Ho, int Wo, int bicubic, int clamp01, void* stream);
+/* ABI 9.  The same with one crop window PER SAMPLE in one launch (the reference crops every frame around its own face box,
+ * notebooks/infer.py:301-352, one frame per call): x = N frames of C planes (plane_stride / row_stride in floats), windows =
+ * N x (x0, y0, w, h) int32 in DEVICE memory, out [N, C, Ho, Wo].  Bit-identical to N single-window calls. */
+int emo_resize2d_windows_f32(const float* x, int64_t plane_stride, int64_t row_stride, const int* windows, float* out, int N,
+                             int C, int Ho, int Wo, int bicubic, int clamp01, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f1 -- embedder ResNets (networks/volumetric_avatar/identity_embedder.py:59-69, expression_embedder.py:424-459,

@@ -111,15 +111,24 @@ def test_driver_pass_R512_B16_trained_like_checkpoint_vs_oracle():
             assert hp.overflow_events() == {}, "the trained-like checkpoint tripped the fp16 split's range check"
         if mode is not None:
             del hp
-    hp = nets.HotPath(sd, cfg, DEV, with_source=False)
-    got = hp.driver_pass(hp.prepare_canonical(d(x["canonical"])), d(x["idt"]), d(x["pose_t"]), d(x["th_t"]), keep=True)
-    # the opt-in fp16-operand mode (BASELINE configs[4]) on the same checkpoint, same launch plan: its stated tolerance is
-    # 2e-3 mean / 2e-2 worst pixel of the [0, 1] image (operands carry 11 significand bits, accumulation is fp32)
+    # the opt-in fp16-operand mode (BASELINE configs[4]) on the same checkpoint, same launch plan, against the ORACLE's frames
+    # (round 5 compared it with the HIP path's fp32 output): its stated tolerance is 2e-3 mean / 2e-2 worst pixel of the
+    # [0, 1] image (decoder operands carry 11 significand bits, accumulation is fp32; the WarpGenerators -- geometry -- run
+    # the fp32-accurate fp16 split, nets.HotPath)
     hp16 = nets.HotPath(sd, cfg, DEV, with_source=False, precision="f16")
-    img16 = hp16.driver_pass(hp16.prepare_canonical(d(x["canonical"])), d(x["idt"]), d(x["pose_t"]), d(x["th_t"]))
-    e16 = (img16 - got["img"]).abs()             # vs the exact-fp32 HIP path, which is within 1.5e-5 of the oracle (above)
-    print(f"PARITY R512 B=16 trained-like checkpoint, fp16 operands: image worst {e16.max().item():.3e} mean {e16.mean().item():.3e}")
-    assert e16.max().item() <= 2e-2 and e16.mean().item() <= 2e-3
+    assert hp16.warp_precision == os.environ.get("EMO_WARP_PRECISION", "f16x2")
+    got16 = hp16.driver_pass(hp16.prepare_canonical(d(x["canonical"])), d(x["idt"]), d(x["pose_t"]), d(x["th_t"]), keep=True)
+    img16 = got16["img"].cpu()
+    worst16 = dict(max=0.0, mean=0.0, delta_abs=0.0)
+    for i in frames:
+        e16 = (img16[i:i + 1] - refs[i]["img"]).abs()
+        worst16["max"] = max(worst16["max"], e16.max().item())
+        worst16["mean"] = max(worst16["mean"], e16.mean().item())
+        worst16["delta_abs"] = max(worst16["delta_abs"], (got16["delta_uv"][i:i + 1].cpu() - refs[i]["delta_uv"]).abs().max().item())
+    print(f"PARITY R512 B=16 trained-like checkpoint, fp16 operands vs oracle: image worst {worst16['max']:.3e} mean "
+          f"{worst16['mean']:.3e}, deltas (fp16 split) {worst16['delta_abs']:.2e}")
+    assert worst16["max"] <= 2e-2 and worst16["mean"] <= 2e-3 and worst16["delta_abs"] <= 1e-4, worst16
+    assert hp16.overflow_events() == {}, "the WarpGenerators' fp16 split tripped its range check"
 
 
 def test_source_pass_R512_vs_oracle():

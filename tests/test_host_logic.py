@@ -424,3 +424,59 @@ def test_isa_audit_finds_a_scalar_operand_read_too_early_and_an_in_flight_destin
             "\tv_mfma_f32_32x32x16_f16 a[0:15], v[4:7], v[8:11], a[0:15]", "\ts_endpgm"]
     hits = K.inflight_reads(loop)
     assert len(hits) == 1 and "v100" in hits[0][1] and hits[0][2] == [47]
+
+
+def test_smooth_pose_scan_is_the_reference_loop_bit_for_bit():
+    """hostglue.ema_scan against a literal replay of notebooks/infer.py:571-581 in torch (`self.theta = pred[i] * m + self.theta *
+    (1 - m)` per frame, state carried between calls); also: scanning a clip in two chunks with the carried state equals scanning
+    it at once -- which is what lets animate_frames() run the scan per chunk before it shards the frames"""
+    import numpy as np
+    from emoportraits_amd import hostglue
+    g = torch.Generator().manual_seed(12)
+    pred = torch.randn(37, 4, 4, generator=g)
+    for m in (0.5, 0.3, 0.9, 0.01):
+        theta, want = None, []
+        for lo, hi in ((0, 11), (11, 12), (12, 37)):                # three "calls" of forward(smooth_pose=True)
+            if theta is None:
+                theta = pred[lo].clone()
+            for i in range(lo, hi):
+                theta = pred[i] * m + theta * (1 - m)
+                want.append(theta.clone())
+        want = torch.stack(want)
+        got, state = hostglue.ema_scan(pred.numpy(), None, m)
+        assert got.dtype == np.float32 and np.array_equal(got, want.numpy()) and np.array_equal(state, want[-1].numpy())
+        a, st = hostglue.ema_scan(pred[:20].numpy(), None, m)
+        b, st = hostglue.ema_scan(pred[20:].numpy(), st, m)
+        assert np.array_equal(np.concatenate([a, b]), got)
+
+
+def test_planner_mirrors_the_c_launchers():
+    """round-5 advisor findings: (1) the planner's fill targets come from the library's CU count (256 without a device), not from
+    a constant; (2) a layer with <= 32 output channels keeps the fp16 split on maps its 32-row tile does not cover (a 64-row packing
+    made on first use) instead of dropping to the fp32 MFMA kernel; (3) the pointwise launch form refuses what the C launcher
+    refuses (more than 2^23 positions per sample) instead of planning a launch that fails; (4) EMO_F16X2_POINTWISE=0 also holds
+    for an explicitly requested precision"""
+    from emoportraits_amd import hip
+    assert pack.cu_count() == hip.load().emo_device_cu_count() and pack.cu_count() % 8 == 0
+    assert pack._fill_blocks() == 2 * pack.cu_count()
+    w = torch.randn(32, 64, 3, 3, 3) / 40
+    layer = pack.PackedConv("l32", w, None, "cpu", precision="f16x2")
+    assert layer.plan_for(4096, 64, 64) [::2] == (pack.CFG_F, "f16x2")             # 4 x 64 tiles: the 32-row channel tile
+    assert layer.plan_for(256, 32, 32)[::2] == (pack.CFG_D, "f16x2")               # 8 x 32 tiles: the half-empty 64-row tile
+    assert layer.plan_for(4096, 64, 64, ups=True)[::2] == (pack.CFG_D, "f16x2")
+    n32, n64 = layer.packed(pack.CFG_F, "f16x2").numel(), layer.packed(pack.CFG_D, "f16x2").numel()
+    assert n64 == 2 * n32 == 2 * 64 * 64 * 27                                      # two fp16 planes, 64 rows (half of them zero)
+    assert torch.equal(layer.packed(pack.CFG_D, "f16x2").view(4, 3, 3, 2, 3, 2, 64, 8)[..., :32, :].reshape(-1).float().abs().sum(),
+                       layer.packed(pack.CFG_F, "f16x2").float().abs().sum())
+    assert pack.f16x2_pointwise_launch_fits(512, 512, False, 1 << 16, 512, positions_per_sample=1 << 18)
+    assert not pack.f16x2_pointwise_launch_fits(4096, 4096, False, 1 << 20, 512, positions_per_sample=(1 << 23) + 64)
+    pw = pack.PackedConv("pw", torch.randn(256, 64, 1, 1) / 8, None, "cpu", precision="f16x2")
+    assert pw.pointwise_split and pw.plan_for(1 << 14, 512, 512, in_elems_per_sample=64 * (1 << 18))[2] == "f16x2"
+    assert pw.plan_for(1 << 20, 4096, 4096, in_elems_per_sample=64 * ((1 << 23) + 4096))[2] == "f32"
+    old = pack.F16X2_POINTWISE
+    try:
+        pack.F16X2_POINTWISE = False
+        off = pack.PackedConv("pw", torch.randn(256, 64, 1, 1) / 8, None, "cpu", precision="f16x2")
+        assert not off.pointwise_split and off.precision == "f32"
+    finally:
+        pack.F16X2_POINTWISE = old

@@ -51,6 +51,10 @@ def _worker(rank, world, port, q):
     ok = ok and all(torch.equal(got2[k], full[k]) for k in shapes)
     # frame sharding: every rank processes its contiguous slice of 11 "frames"; union must be all frames
     lo, hi = parallel.shard_range(11, r, w)
+    # per-frame scalars of the shards (the smooth_pose thetas) gathered on every rank in frame order: ragged shards (6 + 5)
+    rows = torch.arange(11 * 16, dtype=torch.float32).view(11, 4, 4)
+    every = parallel.gather_shards(rows[lo:hi].clone(), 11, r, w)
+    ok = ok and torch.equal(every, rows)
     t = parallel.max_over_ranks(float(rank + 1))
     parallel.barrier()
     q.put((rank, ok, lo, hi, t))
@@ -76,3 +80,34 @@ def test_broadcast_and_sharding_world_size_2():
 def test_missing_source_cache_fails_loudly():
     with pytest.raises(RuntimeError, match="run the source pass"):
         parallel.broadcast_source_cache({"canonical": None}, {"canonical": (1, 2)}, src=0, world=1, rank=0)
+
+
+def test_gather_shards_checks_its_input():
+    assert torch.equal(parallel.gather_shards(torch.ones(5, 2), 5, 0, 1), torch.ones(5, 2))      # one rank: the shard is everything
+    with pytest.raises(ValueError, match="its shard"):
+        parallel.gather_shards(torch.ones(4, 2), 5, 0, 1)
+    with pytest.raises(RuntimeError, match="process group"):
+        parallel.gather_shards(torch.ones(3, 2), 5, 0, 2)
+
+
+def test_affinity_plan_follows_the_gpu_numa_nodes():
+    """parallel.plan_affinity on made-up topologies: 8 GPUs on 2 sockets (4 per node) -> disjoint quarter-node shares next to each
+    GPU; unknown topology -> an even split; a cgroup-restricted cpu set is respected; never an empty set"""
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    gpu_nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = list(range(256))
+    shares = [parallel.plan_affinity(r, 8, gpu_nodes, node_cpus, allowed)[0] for r in range(8)]
+    assert all(len(s) == 32 for s in shares)
+    assert sorted(c for s in shares for c in s) == allowed                       # disjoint, everything used
+    for r, s in enumerate(shares):
+        assert set(s) <= set(node_cpus[gpu_nodes[r]])                            # next to its own GPU
+    # unknown topology (None / -1) or missing sysfs: even split by local rank
+    for nodes in ([None] * 8, [-1] * 8, []):
+        s3, how = parallel.plan_affinity(3, 8, nodes, node_cpus if nodes else {}, allowed)
+        assert s3 == list(range(96, 128)) and "even split" in how
+    # a container that may only use 16 cores of node 0
+    s1, _ = parallel.plan_affinity(1, 2, [0, 0], node_cpus, list(range(16)))
+    assert s1 == list(range(8, 16))
+    # more ranks than cores: everybody keeps what is allowed
+    assert parallel.plan_affinity(5, 8, [], {}, [0, 1, 2])[0] == [0, 1, 2]
+    assert parallel._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

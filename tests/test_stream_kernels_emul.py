@@ -73,7 +73,9 @@ def upsample(lib, x, factors, misalign=False):
 def test_block_upsampling_kernel_is_the_generic_kernel_bit_for_bit(lib, shape, factors):
     """upsample_trilinear_w2_kernel (one thread per block of up to 4 x 2 x 2 outputs; the first / last quad of a row through the
     same code with clamped columns) against the one-output-per-thread kernel (reached through an output pointer that is not
-    16-byte aligned) and against ATen's CPU kernel: first / last pairs of every axis, runs of several volumes, split runs"""
+    16-byte aligned) and against ATen's CPU kernel: first / last pairs of every axis, runs of several volumes, split runs.
+    FINITE inputs: on a factor-1 axis the block kernel copies tap 0 into tap 1 instead of loading v[i1] for a weight of 0, so a
+    non-finite neighbour does not propagate as it does through `1 * v[i0] + 0 * v[i1]` (csrc/resample.hip)"""
     x = np.random.default_rng(5).standard_normal(shape).astype(np.float32)
     got = upsample(lib, x, factors)
     plain = upsample(lib, x, factors, misalign=True)

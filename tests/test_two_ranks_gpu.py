@@ -63,6 +63,20 @@ for span in spans:
     for b0, u8 in w.animate_frames(frames[sl], batch_size=4, ring=2):
         for j in range(u8.shape[0]):
             out["animate_frames"][off + b0 + j] = u8[j].clone()
+# smooth_pose (notebooks/infer.py:571-581) is a scan over the FRAME ORDER: two chunks of 16 frames, EMA state carried from chunk
+# to chunk; every rank must render its shard with the thetas of the GLOBAL scan (SURVEY.md section 8e)
+sm = {"frames": {}, "theta": {}}
+w.theta = None
+for b0, u8 in w.animate_frames([frames[:16], frames[16:32]], batch_size=4, smooth_pose=True, to_host=False):
+    th = w.pred_target_theta.cpu()
+    for j in range(u8.shape[0]):
+        sm["frames"][b0 + j] = u8[j].cpu()
+        sm["theta"][b0 + j] = th[j].clone()
+out["smooth"] = sm
+if w.rank == 0:
+    x = frames[:32].permute(0, 3, 1, 2).float().div(255.0).to(w.device)
+    out["pred_theta"] = torch.cat([w.embedders["head_pose_regressor"](x[i:i + 4].contiguous(), True)[0].cpu() for i in range(0, 32, 4)])
+    out["pose_momentum"] = w.pose_momentum
 if emulate:
     out["unsharded"] = {}
     for b0, u8 in w.animate(pose, srt, batch_size=4):
@@ -133,7 +147,31 @@ def _check(world, tmp_path, golden_dir, share_gpu):
             for i, frame in out[kind].items():
                 assert torch.equal(frame, single[kind][i]), f"{kind}: frame {i} of rank {r} differs from the single-rank run"
         assert sorted(covered) == list(range(N_FRAMES))                                       # the shards tile the range
-    print(f"PARITY two-rank product path: world {world}, {N_FRAMES} frames, animate + animate_frames bit-identical to 1 rank")
+    # smooth_pose: the thetas every rank rendered with are the global scan's -- a replay of the reference's loop
+    # (notebooks/infer.py:571-581: `self.theta = pred[i] * m + self.theta * (1 - m)`, state carried across the two chunks), in torch
+    # on the CPU, bit for bit -- whatever the world size; the frames equal the 1-rank run's bit for bit when the shards' batches
+    # line up with its batches (16-frame chunks, batch 4: world 2 and 4), to one uint8 level otherwise (other launch plans)
+    pred, m = single["pred_theta"], single["pose_momentum"]
+    state, replay = pred[0].clone(), []
+    for i in range(32):
+        state = pred[i] * m + state * (1 - m)
+        replay.append(state.clone())
+    aligned = 16 % (world * 4) == 0
+    seen = []
+    for r, out in enumerate(ranks):
+        spans = [parallel.shard_range(16, r, world) for _ in range(2)]
+        want = [c * 16 + i for c, (lo, hi) in enumerate(spans) for i in range(lo, hi)]
+        assert sorted(out["smooth"]["frames"]) == want, (r, sorted(out["smooth"]["frames"]))
+        seen += want
+        for i in want:
+            assert torch.equal(out["smooth"]["theta"][i], replay[i]), f"smooth_pose: theta of frame {i} on rank {r} is not the global scan's"
+            assert torch.equal(single["smooth"]["theta"][i], replay[i])
+            d = int((out["smooth"]["frames"][i].int() - single["smooth"]["frames"][i].int()).abs().max())
+            assert d == 0 if aligned else d <= 1, (i, r, d)
+    assert sorted(seen) == list(range(32))
+    assert not torch.equal(replay[16], pred[16])                      # (the scan does something, and it crosses the chunk boundary)
+    print(f"PARITY two-rank product path: world {world}, {N_FRAMES} frames, animate + animate_frames bit-identical to 1 rank; "
+          f"smooth_pose thetas = the reference's sequential EMA on every rank, frames {'bit-identical' if aligned else 'within 1 level'}")
 
 
 def test_two_ranks_share_one_gpu_gloo(tmp_path, golden_dir):
