@@ -35,7 +35,8 @@ EXTRA_FLAGS = {"gs3d_tile_pad_zeros.hip": ["-fno-slp-vectorize"], "gs3d_tile_pad
                # conv_igemm_bf16x3.h: SLP packs the split's subtractions into v_pk_add_f32, which beside MFMAs costs more than
                # the two scalar ops it replaces (MI355X_MICROARCH.md, filler prices of a one-wave-per-SIMD stream)
                "conv_inst_bf16x3_3x3.hip": ["-fno-slp-vectorize"], "conv_inst_f16x2_3x3.hip": ["-fno-slp-vectorize"],
-               "conv_inst_f16x2_ct2.hip": ["-fno-slp-vectorize"], "conv_inst_f16x2_p1.hip": ["-fno-slp-vectorize"]}
+               "conv_inst_f16x2_ct2.hip": ["-fno-slp-vectorize"], "conv_inst_f16x2_p1.hip": ["-fno-slp-vectorize"],
+               "conv_inst_f16x2_w8.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

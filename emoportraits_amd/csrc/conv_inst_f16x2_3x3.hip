@@ -3,12 +3,16 @@
 #include "conv_dispatch.h"
 #include "conv_igemm_bf16x3.h"
 int conv_f16x2_ct2_4x64(ConvArgs, hipStream_t, int ups, int* rest_cot0);    // conv_inst_f16x2_ct2.hip
-// 4 x 64 tiles: the layer's channel-tile pairs on the two-tile kernel where that fills the chip, the rest (an odd last tile, or
-// everything) on the single-tile one
+int conv_f16x2_w8_4x64(ConvArgs, hipStream_t, int ups, int* rest_cot0);     // conv_inst_f16x2_w8.hip
+// 4 x 64 tiles: the layer's channel-tile pairs on a two-tile kernel where that fills the chip -- the one with two waves per SIMD
+// (conv_igemm_f16x2_w8.h; EMO_CONV_W8=0: the one-wave-per-SIMD kernel of conv_igemm_f16x2_ct2.h) --, the rest (an odd last tile,
+// or everything) on the single-tile one
 template <bool UPS>
 static int conv_f16x2_4x64(ConvArgs a, hipStream_t s) {
   int rest = 0;
-  const int rc = conv_f16x2_ct2_4x64(a, s, UPS, &rest);
+  int rc = conv_f16x2_w8_4x64(a, s, UPS, &rest);
+  if (rc != EMO_OK) return rc;
+  if (rest == 0) rc = conv_f16x2_ct2_4x64(a, s, UPS, &rest);
   if (rc != EMO_OK) return rc;
   if (rest * ConvCfgS<4, 64, UPS, 2>::BM >= a.Cout) return EMO_OK;
   a.cot0 = rest;

@@ -28,7 +28,8 @@ GEN = os.path.join(HERE, "_build", "gen_convlib")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 PRODUCT_LIB = os.path.join(ROOT, "emoportraits_amd", "lib", "libemoportraits_hip.so")
 
-HEADERS = ["conv_igemm.h", "conv_igemm_f16.h", "conv_igemm_bf16x3.h", "conv_igemm_f16x2_ct2.h", "conv_igemm_f16x2_p1.h", "conv_dispatch.h"]
+HEADERS = ["conv_igemm.h", "conv_igemm_f16.h", "conv_igemm_bf16x3.h", "conv_igemm_f16x2_ct2.h", "conv_igemm_f16x2_w8.h", "conv_igemm_f16x2_p1.h",
+           "conv_dispatch.h"]
 UNITS = ["conv_api.hip"] + sorted(f for f in os.listdir(CSRC) if f.startswith("conv_inst_") and f.endswith(".hip"))
 
 # (regex, replacement) applied to every copied file; the counts are checked per file below
@@ -67,6 +68,9 @@ GENERIC = [
     # the epilogues of the split kernels transpose through a wave-private LDS region: written and read by the lanes of one wave
     # without a barrier in the source (lock step on the GPU) -- a barrier of the wave around the reads
     (r'(#pragma unroll\s*\n\s*for \(int it = 0; it < NIT; \+\+it\) v\[it\] = \*reinterpret_cast<const floatx4\*>\(scratch \+ \(4 \* it \+ g\) \* ROWF \+ 4 \* t\);)',
+     r'hipshim_wave_sync();\n\1\nhipshim_wave_sync();'),
+    # (the same in conv_igemm_f16x2_w8.h: 32-position passes, rows of 8 channels)
+    (r'(#pragma unroll\s*\n\s*for \(int it = 0; it < 4; \+\+it\) v\[J\]\[it\] = \*reinterpret_cast<const floatx4\*>\(scratch \+ \(8 \* it \+ g8\) \* ROWF \+ 4 \* t8\);)',
      r'hipshim_wave_sync();\n\1\nhipshim_wave_sync();'),
 ]
 

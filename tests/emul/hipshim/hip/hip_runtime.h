@@ -9,6 +9,8 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define __global__
@@ -263,6 +265,7 @@ static inline void emu_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A..
   gridDim = grid;
   blockDim = block;
   const unsigned nthreads = block.x * block.y * block.z, nwaves = (nthreads + 63) / 64;
+  if (getenv("HIPSHIM_TRACE")) fprintf(stderr, "hipshim launch: grid %u x %u x %u, block %u threads, %zu bytes of dynamic LDS\n", grid.x, grid.y, grid.z, nthreads, (size_t)shmem);
   for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {

@@ -286,14 +286,17 @@ CT2_CASES = [
 ]
 
 
+@pytest.mark.parametrize("kernel", ["w8", "ct2"])
 @pytest.mark.parametrize("case", CT2_CASES)
-def test_conv_f16x2_two_tile_kernel_is_bit_identical_to_the_single_tile_kernel(case, monkeypatch):
-    """same products in the same order into the same accumulator sets: the pair kernel and the single-tile kernel must agree bit
-    for bit, output and GroupNorm tile statistics; and the fp32 bound against torch CPU holds"""
+def test_conv_f16x2_two_tile_kernel_is_bit_identical_to_the_single_tile_kernel(case, kernel, monkeypatch):
+    """same products in the same order into the same accumulator sets: the pair kernels -- conv_igemm_f16x2_w8_kernel (eight waves,
+    two per SIMD: the default, round 6) and conv_igemm_bf16x3_ct2_kernel (four waves; EMO_CONV_W8=0) -- and the single-tile kernel
+    must agree bit for bit, output and GroupNorm tile statistics; and the fp32 bound against torch CPU holds"""
     monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
     monkeypatch.setenv("EMO_CONV_CT2", "1")
+    monkeypatch.setenv("EMO_CONV_W8", "1" if kernel == "w8" else "0")
     e, got, ref = run_conv(seed=27, precision="f16x2", **case)
-    print("PARITY conv f16x2 two-tile kernel:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    print(f"PARITY conv f16x2 two-tile kernel [{kernel}]:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
     assert e < 2e-5, e
     e2, got2, _ = run_conv(seed=27, precision="f16x2", **case)
     assert torch.equal(got, got2), "two launches on the same input differ: a race in the pipeline"
@@ -302,9 +305,11 @@ def test_conv_f16x2_two_tile_kernel_is_bit_identical_to_the_single_tile_kernel(c
     assert torch.equal(got, single), (got - single).abs().max().item()
 
 
-def test_conv_f16x2_two_tile_kernel_statistics_and_range_check(monkeypatch):
-    """tile statistics written by the pair kernel equal the single-tile kernel's bit for bit; an out-of-range input raises the
+@pytest.mark.parametrize("kernel", ["w8", "ct2"])
+def test_conv_f16x2_two_tile_kernel_statistics_and_range_check(kernel, monkeypatch):
+    """tile statistics written by the pair kernels equal the single-tile kernel's bit for bit; an out-of-range input raises the
     layer's overflow word from the pair kernel as well, and the guarded bf16x3 launch rewrites the whole layer"""
+    monkeypatch.setenv("EMO_CONV_W8", "1" if kernel == "w8" else "0")
     g = torch.Generator().manual_seed(33)
     N, Cin, Cout, H, W = 2, 48, 192, 32, 64
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)

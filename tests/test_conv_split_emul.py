@@ -169,9 +169,11 @@ def test_split_kernel_tile_statistics(lib):
 
 
 # ---- two channel tiles per work item -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["w8", "ct2"])
 @pytest.mark.parametrize("cout,ups,N", [(128, False, 2), (192, False, 1), (128, True, 1)])
-def test_two_tile_kernel_is_the_single_tile_kernel_bit_for_bit(lib, cout, ups, N, monkeypatch):
-    """conv_igemm_bf16x3_ct2_kernel (a pair of 64-channel tiles on one converted patch; an odd last tile on the single-tile kernel
+def test_two_tile_kernel_is_the_single_tile_kernel_bit_for_bit(lib, cout, ups, N, kernel, monkeypatch):
+    """The two-tile kernels -- conv_igemm_f16x2_w8_kernel (eight waves, two per SIMD: the default) and conv_igemm_bf16x3_ct2_kernel
+    (four waves; EMO_CONV_W8=0) -- (a pair of 64-channel tiles on one converted patch; an odd last tile on the single-tile kernel
     as a second launch) against the single-tile kernel on every tile (EMO_CONV_CT2=0): output, tile statistics and overflow word.
     N = 2: sixteen pair items on eight persistent blocks, two chained items each; N = 1: one item per block"""
     dims = (16, 32) if ups else (32, 64)                # eight position tiles per sample
@@ -179,10 +181,44 @@ def test_two_tile_kernel_is_the_single_tile_kernel_bit_for_bit(lib, cout, ups, N
     flag_a, flag_b = _buf(np.zeros(4, np.int32)), _buf(np.zeros(4, np.int32))
     monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "8")
     monkeypatch.setenv("EMO_CONV_CT2", "1")
+    monkeypatch.setenv("EMO_CONV_W8", "1" if kernel == "w8" else "0")
     out_a, st_a = c.launch(lib, "f16x2", stats=True, flag=flag_a)
     monkeypatch.setenv("EMO_CONV_CT2", "0")
     out_b, st_b = c.launch(lib, "f16x2", stats=True, flag=flag_b)
     assert c.err(out_a) < 2e-5
+    assert np.array_equal(_bits(out_a), _bits(out_b)) and np.array_equal(_bits(st_a), _bits(st_b)) and np.array_equal(flag_a, flag_b)
+
+
+W8_FORMS = [
+    dict(N=2, Cin=40, Cout=128, dims=(16, 64), res=True),                                  # three stages (the last one ragged), chained items
+    dict(N=1, Cin=16, Cout=128, dims=(32, 64), res=False),                                 # one stage per item (unchained), no residual
+    dict(N=1, Cin=24, Cout=128, dims=(8, 32), ups=True, res=True, res_ups=True),           # fused upsample, half-size residual
+    dict(N=1, Cin=16, Cout=256, dims=(3, 8, 64), res=True),                                # depth taps as K stages, two pairs
+    dict(N=2, Cin=32, Cout=128, dims=(16, 64), res=True, affine=False, relu_in=False, bias=False),
+    dict(N=1, Cin=32, Cout=128, dims=(16, 64), res=True, amp=3000.0),                      # out of range: the overflow word
+]
+
+
+@pytest.mark.parametrize("form", W8_FORMS)
+def test_eight_wave_two_tile_kernel_launch_forms(lib, form, monkeypatch):
+    """conv_igemm_f16x2_w8_kernel in every launch form of the decoders -- residual forms, fused upsample, depth taps, ragged last
+    stage, one-stage items, chains across items and their breaks at sample boundaries, plain operands, an operand range violation
+    -- bit for bit the single-tile kernel: output, tile statistics, overflow word"""
+    kw = dict(form)
+    N, Cin, Cout, dims = kw.pop("N"), kw.pop("Cin"), kw.pop("Cout"), kw.pop("dims")
+    c = Case(N, Cin, Cout, dims, seed=Cin + Cout, **kw)
+    flag_a, flag_b = _buf(np.zeros(4, np.int32)), _buf(np.zeros(4, np.int32))
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    monkeypatch.setenv("EMO_CONV_CT2", "1")
+    monkeypatch.setenv("EMO_CONV_W8", "1")
+    out_a, st_a = c.launch(lib, "f16x2", stats=True, flag=flag_a)
+    monkeypatch.setenv("EMO_CONV_CT2", "0")
+    out_b, st_b = c.launch(lib, "f16x2", stats=True, flag=flag_b)
+    assert not np.isnan(out_a).any() and not np.isnan(st_a).any()
+    if "amp" not in form:
+        assert c.err(out_a) < 2e-5 and flag_a[0] == 0
+    else:
+        assert flag_a[0] != 0
     assert np.array_equal(_bits(out_a), _bits(out_b)) and np.array_equal(_bits(st_a), _bits(st_b)) and np.array_equal(flag_a, flag_b)
 
 

@@ -266,7 +266,9 @@ def _toy_embedders(tiny, device):
     proj = (torch.randn(3 * 16, E, generator=g) * 0.5).to(device)
 
     def head_pose(crop, return_srt=False):
-        m = crop.mean(dim=(2, 3))                                             # [B,3]
+        # (frame by frame: a batched reduction may split its work differently for another batch size, and the multi-rank tests
+        # compare thetas of the same frame computed in batches of different sizes bit for bit)
+        m = torch.stack([crop[i].mean(dim=(1, 2)) for i in range(crop.shape[0])])   # [B,3]
         scale, rot, trans = 1 + 0.1 * (m - 0.5), 0.6 * (m - 0.5), 0.1 * (m.flip(1) - 0.5)
         theta = ops.pose_theta(scale.contiguous(), rot.contiguous(), trans.contiguous())
         return (theta, scale, rot, trans) if return_srt else theta
