@@ -867,6 +867,11 @@ def main():
             note = ("achieved = algorithmic fp32 FLOPs / event time; peak = 2500 TF dense bf16 / 6 products.  A bare stream of this "
                     "MFMA sustains 1.49-1.72 PF on this chip (clocks fall to 1.4-1.7 GHz under it: tools/microbench/mfma_stream.hip, "
                     "archive/profiles/r3_mfma_stream.jsonl) = 249-287 TF fp32-equivalent")
+        elif k == "f16w8":
+            peak = PEAK_BF16_MFMA_TFLOPS
+            name = ("conv_igemm_f16x2_w8_kernel<NPROD = 1> (plain fp16 operands, fp32 accumulation: two 64-channel tiles per work item, "
+                    "eight waves -- two per SIMD; opt-in precision 'f16', BASELINE configs[4])")
+            note = "achieved = algorithmic FLOPs / event time; peak = 2500 TF dense fp16"
         else:
             peak = PEAK_FP32_MFMA_TFLOPS if k == "f32" else PEAK_BF16_MFMA_TFLOPS
             name = ("conv_igemm_kernel (fp32 32x32x2 MFMA implicit-GEMM conv, all instantiations)" if k == "f32" else
@@ -881,7 +886,7 @@ def main():
              "share_of_step": round(ms / (elapsed_metered * 1e3), 3)}
         if note:
             r["note"] = note
-        products = {"f16x2": 3, "f16x2_pointwise": 3, "bf16x3": 6, "f16": 1}.get(k)
+        products = {"f16x2": 3, "f16x2_pointwise": 3, "bf16x3": 6, "f16": 1, "f16w8": 1}.get(k)
         if products and sustained and "bare" in sustained:
             # the same fraction against what the chip SUSTAINS on a pure matrix stream at its power-managed clock (measured in this
             # run): kernel quality apart from clock.  `frac` stays the fraction of the data-sheet peak

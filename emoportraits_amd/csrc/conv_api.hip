@@ -19,11 +19,14 @@ conv_launch_fn conv_lookup_bf16x3_3x3(int, int);
 conv_launch_fn conv_lookup_f16x2_3x3(int, int);
 conv_launch_fn conv_lookup_f16x2_1x1(int, int);
 conv_launch_fn conv_lookup_f16x2_3x3_bm32(int, int);
+conv_launch_fn conv_lookup_f16w8_3x3(int, int);
 
 // MFMA operand format (accumulation and all tensors in HBM are fp32 either way).  PREC_S: every fp32 operand as the exact sum
 // of three bf16 terms, six partial products (conv_igemm_bf16x3.h) -- fp32 results on the bf16 pipes
 // PREC_S2: the scaled operand as two fp16 terms, three partial products (same kernel, SPLIT = 2; opt-in)
-enum { PREC_F32 = 0, PREC_F16 = 1, PREC_S = 2, PREC_S2 = 3 };
+// PREC_H1: plain fp16 operands on the eight-wave two-tile kernel (conv_igemm_f16x2_w8.h, NPROD = 1): weights = the first plane
+// of the split layout
+enum { PREC_F32 = 0, PREC_F16 = 1, PREC_S = 2, PREC_S2 = 3, PREC_H1 = 4 };
 
 static int shape_of_width(int Wl) {
   if (Wl >= 128 && Wl % 128 == 0) return SHAPE_W128;
@@ -35,6 +38,7 @@ static int shape_of_width(int Wl) {
 }
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
+  if (prec == PREC_H1) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
   if (prec == PREC_S2 && cfg == CFG_D && KH == 1 && KW == 1) return 32;   // conv_igemm_f16x2_p1.h: pointwise, 32 channels per stage
   if (prec == PREC_S2 && cfg == CFG_F && KH == 3 && KW == 3) return 16;   // fp16 split on 32-row channel tiles (conv_igemm_bf16x3.h, BMT = 32)
   if (prec == PREC_S || prec == PREC_S2) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
@@ -156,7 +160,11 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   const int shape = shape_of_width(a.Wl);
   if (shape < 0) return EMO_ERR_UNSUPPORTED;
   conv_launch_fn fn = nullptr;
-  if (prec == PREC_S2 && KH == 1 && KW == 1) {
+  if (prec == PREC_H1) {
+    if (!(KH == 3 && KW == 3 && (KD == 1 || KD == 3)) || cfg != CFG_D || Cin % 8 || ksplit != 1 || run_if != nullptr) return EMO_ERR_UNSUPPORTED;
+    if (!(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;
+    fn = conv_lookup_f16w8_3x3(a.Wl, ups);
+  } else if (prec == PREC_S2 && KH == 1 && KW == 1) {
     // pointwise layers on the fp16 split (conv_igemm_f16x2_p1.h): one launch form, no K split
     if (KD != 1 || cfg != CFG_D || Cin % 8 || ksplit != 1 || run_if != nullptr) return EMO_ERR_UNSUPPORTED;
     if (!(in_scale > 0.0f && w_scale > 0.0f)) return EMO_ERR_BAD_ARG;
@@ -252,4 +260,13 @@ extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const 
                                        int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
   return conv_igemm_dispatch(PREC_F16, x, wpk16, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
                              relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
+}
+
+// ABI 9.  Plain fp16 operands (BASELINE configs[4]) on the eight-wave two-tile kernel: see include/emo_hip.h
+extern "C" int emo_conv_igemm_f16w8(const float* x, const void* wpk1, const float* bias, const float* scale,
+                                    const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D,
+                                    int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups,
+                                    int cfg, int ksplit, float* workspace, float* gn_stats, void* stream, float w_scale) {
+  return conv_igemm_dispatch(PREC_H1, x, wpk1, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
+                             relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream, 1.0f, w_scale, nullptr, nullptr);
 }

@@ -95,11 +95,13 @@ __device__ __forceinline__ void conv_w8_res_issue(const ConvArgs& a, floatx4 (&r
 // NEXT: the residual loads of the pair's SECOND tile (32-row tile cot32 + 2) are issued from here, pass J of them behind pass J of
 // this tile -- into the registers this tile's residual has just left (with both tiles' 64 residual registers live from the top the
 // compiler spilled the chained item's raw patch across the epilogue).
-template <int TW, int BM, int ROWF, int RES, bool NEXT>
+// HI: the kernel keeps a second accumulator set (the fp16 SPLIT's small products); false for plain fp16 operands (NPROD = 1).
+// issue_next (wave-uniform, with NEXT): false for the half-empty last pair of a layer with an odd number of channel tiles.
+template <int TW, int BM, int ROWF, int RES, bool NEXT, bool HI>
 __device__ __forceinline__ void conv_w8_epilogue_tile(const ConvArgs& a, floatx16 (&acc_lo)[2], floatx16 (&acc_hi)[2],
                                                       floatx4 (&rv)[2][4], floatx4 (&rvn)[2][4], float* scratch, const float* sbias,
                                                       float* st_lds, int n, int cot32, int x0, int y0, int z0, int wp, int ch,
-                                                      int half, int l32, int lane) {
+                                                      int half, int l32, int lane, bool issue_next) {
   const int g8 = lane >> 3, t8 = lane & 7;
   const bool want_stats = a.gn_stats != nullptr;
   const unsigned plane = (unsigned)a.Hl * a.Wl;
@@ -113,10 +115,12 @@ __device__ __forceinline__ void conv_w8_epilogue_tile(const ConvArgs& a, floatx1
     // accumulator layout -> LDS: position tile J, register quad q of lane (half, l32) = channel l32, positions 32 J + 8 q + 4 half .. + 3
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      floatx2 c01 = floatx2{emo_acc_read(acc_lo[J][4 * q + 0]), emo_acc_read(acc_lo[J][4 * q + 1])} +
-                    floatx2{emo_acc_read(acc_hi[J][4 * q + 0]), emo_acc_read(acc_hi[J][4 * q + 1])};
-      floatx2 c23 = floatx2{emo_acc_read(acc_lo[J][4 * q + 2]), emo_acc_read(acc_lo[J][4 * q + 3])} +
-                    floatx2{emo_acc_read(acc_hi[J][4 * q + 2]), emo_acc_read(acc_hi[J][4 * q + 3])};
+      floatx2 c01 = floatx2{emo_acc_read(acc_lo[J][4 * q + 0]), emo_acc_read(acc_lo[J][4 * q + 1])};
+      floatx2 c23 = floatx2{emo_acc_read(acc_lo[J][4 * q + 2]), emo_acc_read(acc_lo[J][4 * q + 3])};
+      if constexpr (HI) {
+        c01 = c01 + floatx2{emo_acc_read(acc_hi[J][4 * q + 0]), emo_acc_read(acc_hi[J][4 * q + 1])};
+        c23 = c23 + floatx2{emo_acc_read(acc_hi[J][4 * q + 2]), emo_acc_read(acc_hi[J][4 * q + 3])};
+      }
       const floatx2 sc2 = floatx2{a.out_scale, a.out_scale};
       c01 = c01 * sc2;
       c23 = c23 * sc2;
@@ -142,8 +146,10 @@ __device__ __forceinline__ void conv_w8_epilogue_tile(const ConvArgs& a, floatx1
       else *reinterpret_cast<floatx4*>(op) = v[J][it];
     }
     if constexpr (NEXT) {
-      if (J == 0) conv_w8_res_issue<TW, RES, 0>(a, rvn[0], n, cot32 + 2, x0, y0, z0, wp, lane);
-      else conv_w8_res_issue<TW, RES, 1>(a, rvn[1], n, cot32 + 2, x0, y0, z0, wp, lane);
+      if (issue_next) {
+        if (J == 0) conv_w8_res_issue<TW, RES, 0>(a, rvn[0], n, cot32 + 2, x0, y0, z0, wp, lane);
+        else conv_w8_res_issue<TW, RES, 1>(a, rvn[1], n, cot32 + 2, x0, y0, z0, wp, lane);
+      }
     }
   }
   if (want_stats) {
@@ -183,12 +189,21 @@ __device__ __forceinline__ void conv_w8_epilogue_tile(const ConvArgs& a, floatx1
   }
 }
 
-template <int TR, int TW, bool UPS>
+// NPROD = 3: the fp16 SPLIT (fp32 results).  NPROD = 1 -- BASELINE configs[4], "fp16 MFMA convs", emo_conv_igemm_f16w8: plain fp16
+// operands, the leading product only -- ONE operand plane (weights packed as the first plane of the split layout, 18 chunks per
+// half-stage; the patch's second plane stays unwritten), one accumulator set, operands saturate at +-65504 as in
+// conv_igemm_f16.h (no range word).  With a third of the matrix work the K loop is bound by what the waves ISSUE, not by the
+// pipe -- which is where a second wave per SIMD pays.  A layer with an odd number of channel tiles runs its last tile in a pair
+// whose second half recomputes the same tile and is not written (the single-tile kernel has no such mode).
+template <int TR, int TW, bool UPS, int NPROD = 3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   using Cfg = ConvCfgW8<TR, TW, UPS>;
   using opx8 = halfx8;
-  constexpr int NPL = 2, NPROD = 3;
+  static_assert(NPROD == 3 || NPROD == 1, "the split's three products, or the leading one alone");
+  constexpr int NPL = NPROD == 1 ? 1 : 2;                // operand planes in use
+  constexpr int NCHK = NPROD == 1 ? 18 : 36;             // 1 KiB weight chunks per half-stage
+  constexpr int NDM = NPROD == 1 ? 3 : 5;                // chunk copies per wave and half-stage
   constexpr int BM = Cfg::BM, TP = Cfg::TP, WGP = Cfg::WGP, KC = Cfg::KC, NTH = Cfg::NTH;
   constexpr int PR = Cfg::PR, NQ = Cfg::NQ, NQ1 = Cfg::NQ1, SUB = Cfg::SUB, CHS = Cfg::CHS, QPG = Cfg::QPG;
   constexpr int NHQ = Cfg::NHQ, TWS = Cfg::TWS, WPLANE = Cfg::WPLANE, WROW = Cfg::WROW, PPL = Cfg::PPL, PBUF = Cfg::PBUF;
@@ -216,6 +231,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   const float clamp_lo = a.relu_in ? 0.0f : -CLAMP_HI;
   const int nst = a.n_cchunks * a.KD;                    // stages of an item (no K split)
   const int nptiles = a.tiles_x * a.tiles_y * a.tiles_z;
+  const int n_cot_all = a.Cout / BM;                     // channel tiles of the layer (an odd count only with NPROD = 1)
 
   // ---- staging map: the 256 threads of a channel half (waves 0-3 / 4-7) are two 8-channel groups of 128 lanes, mapped onto the
   //      interior quads and halo pixels of the patch exactly as the 256 threads of conv_igemm_bf16x3.h; a thread stages the four
@@ -265,8 +281,10 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     P_##y0 = __builtin_amdgcn_readfirstlane(ty_ * TR);                                                \
     P_##z0 = __builtin_amdgcn_readfirstlane(bx_);                                                     \
   }
-// byte address of the packed kernel rows of (channel tile c_, stage k_): 36 contiguous chunks of 1 KiB
-#define EMO_W_WPTR(c_, k_) (reinterpret_cast<const char*>(a.wpk) + (long)((c_) * nst + (k_)) * (3 * Cfg::WROW_BYTES))
+// byte address of the packed kernel rows of (channel tile c_, stage k_): NCHK contiguous chunks of 1 KiB (a tile past the layer's
+// last one -- the second half of an odd last pair -- reads the last tile's)
+#define EMO_W_WPTR(c_, k_) (reinterpret_cast<const char*>(a.wpk) + \
+                            (long)(((c_) < n_cot_all ? (c_) : n_cot_all - 1) * nst + (k_)) * (NCHK * 1024))
 #define EMO_W_CURSOR_OF(P_, ok_, off_)                                                                \
   {                                                                                                   \
     const int x0s_ = UPS ? P_##x0 >> 1 : P_##x0, y0s_ = UPS ? P_##y0 >> 1 : P_##y0;                   \
@@ -301,6 +319,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   char* const lds_w = reinterpret_cast<char*>(smem);
   opx8 fa_[2][NPL], fb_[2][NPL][TP];         // [register set: this step / the next][plane]([position tile])
 // (wbase_: slots, compile-time; pbyte_: byte offset of the patch buffer, run-time)
+// (a kernel row of a stage buffer holds NPL planes: rows are NPL * WPLANE slots apart)
 #define EMO_W_LOAD_FRAGS_PLANE(set_, pl_, wbase_, pbyte_, r_, s_)                                      \
   {                                                                                                   \
     fa_[set_][pl_] = *reinterpret_cast<const opx8*>(lds_c + a_off + ((wbase_) + (pl_) * WPLANE + (s_) * 2 * BM) * 16); \
@@ -356,18 +375,21 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     float t_[4];                                                                                      \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                     \
       t_[k] = __fmaf_rn(qv[k][i_], q_sc[k], q_sh[k]);                                                 \
-    sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[0])), __builtin_fabsf(t_[1])); \
-    sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[2])), __builtin_fabsf(t_[3])); \
+    if constexpr (NPROD == 3) {                                                                       \
+      sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[0])), __builtin_fabsf(t_[1])); \
+      sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[2])), __builtin_fabsf(t_[3])); \
+    }                                                                                                 \
     halfx4 cvh_, cvm_;                                                                                \
     _Pragma("unroll") for (int k = 0; k < 4; k += 2)                                                  \
       emo_split_f16x2_pair(__builtin_amdgcn_fmed3f(t_[k], q_lo, q_hi), __builtin_amdgcn_fmed3f(t_[k + 1], q_lo, q_hi), \
                            cvh_, cvm_, k);                                                            \
     char* d_ = lds_w + (q_slb[i_] + (pbyte_));                                                        \
     *reinterpret_cast<halfx4*>(d_) = cvh_;                                                            \
-    *reinterpret_cast<halfx4*>(d_ + PPL * 16) = cvm_;                                                 \
+    if constexpr (NPROD == 3) *reinterpret_cast<halfx4*>(d_ + PPL * 16) = cvm_;                       \
   }
-// chunk m_ = 0 .. 4 of this wave's share of a half-stage's 36 weight chunks (header comment), to the LDS byte address dst_ + chunk KiB
-#define EMO_W_CHUNK_OF(m_) ((m_) < 4 ? wave + 8 * (m_) : 32 + wp)
+// chunk m_ = 0 .. NDM - 1 of this wave's share of a half-stage's NCHK weight chunks (header comment; 18 chunks: w, w + 8 and one of
+// 16, 17 a second time), to the LDS byte address dst_ + chunk KiB
+#define EMO_W_CHUNK_OF(m_) (NPROD == 1 ? ((m_) < 2 ? wave + 8 * (m_) : 16 + (wave & 1)) : ((m_) < 4 ? wave + 8 * (m_) : 32 + wp))
 #define EMO_W_DMA_CHUNK(ptr_, dst_, m_)                                                               \
   {                                                                                                   \
     const int c_ = EMO_W_CHUNK_OF(m_);                                                                \
@@ -378,7 +400,8 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #define EMO_W_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
 
   // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
-  constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
+  constexpr int PA3[3] = {NPROD == 1 ? 0 : 1, 0, 0}, PB3[3] = {0, 1, 0};
+  constexpr int WROWU = NPL * WPLANE;                    // slots between the kernel rows of a stage buffer
   constexpr int NTE = Cfg::SCT / NTH;
   float te_sc[NTE], te_sh[NTE], te_b = 0.0f;
 // bias table entry of channel t2_ of a tile (conv_w8_epilogue_tile: entry ch * 32 + g8 * 4 + it = channel ch * 32 + 8 it + g8)
@@ -443,7 +466,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     {
       const char* const w0_ = EMO_W_WPTR(it_cotile, 0);
 #pragma unroll
-      for (int m = 0; m < 5; ++m) EMO_W_DMA_CHUNK(w0_, EMO_W_WBUF(0), m)
+      for (int m = 0; m < NDM; ++m) EMO_W_DMA_CHUNK(w0_, EMO_W_WBUF(0), m)
     }
     ld_stage = 0; ld_cc = 0; ld_kd = 0;
     EMO_W_SET_STAGE_VARS()
@@ -537,7 +560,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         {
           const int rn = gs < 8 ? (gs + 1) / 3 : 0, sn = gs < 8 ? (gs + 1) % 3 : 0;
-          const int wbn = Cfg::OFF_W + (gs < 8 ? h : h ^ 1) * Cfg::WSTAGE + rn * WROW;
+          const int wbn = Cfg::OFF_W + (gs < 8 ? h : h ^ 1) * Cfg::WSTAGE + rn * WROWU;
           const int pbn = (gs == 8 && h == 1) ? pnxt_b : pcur_b;       // (half-stage 1 reads the same patch as half-stage 0)
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) {
@@ -548,9 +571,9 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
               const unsigned dst_ = (h == 1 && last_) ? smem_lds + (unsigned)pcur_b : EMO_W_WBUF(h);
               EMO_W_DMA_CHUNK(dma_ptr2, dst_, 0)
             }
-            // chunks 1 .. 4 of the rows of half-stage t + 1 into W[h ^ 1], one per step
-            if (gs < 4 && pl == 0) EMO_W_DMA_CHUNK(dma_ptr, EMO_W_WBUF(h ^ 1), 1 + gs)
-            if (h == 1 && gs < 2 && pl == 1) EMO_W_ISSUE_LOADS(2 * gs)
+            // chunks 1 .. NDM - 1 of the rows of half-stage t + 1 into W[h ^ 1], one per step
+            if (gs < NDM - 1 && pl == 0) EMO_W_DMA_CHUNK(dma_ptr, EMO_W_WBUF(h ^ 1), 1 + gs)
+            if (h == 1 && gs < 2 && pl == NPL - 1) EMO_W_ISSUE_LOADS(2 * gs)
           }
         }
         if (h == 0 && gs < 4) EMO_W_CONV_UNIT(pnxt_b, gs)
@@ -565,12 +588,13 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
           }
         }
         if (EMO_S_PIN) {
-          // one fragment read behind each of the six MFMAs, the step's other work spread between them
+          // one fragment read behind each of the six MFMAs, the step's other work spread between them (one operand plane: two
+          // MFMAs and three fragment reads per step)
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
+          for (int k = 0; k < 2 * NPROD; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NPROD == 1 ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NPROD == 1 ? 14 : 6, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
           }
         }
@@ -585,6 +609,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     // ---- epilogue, once per channel tile of the pair; the transposition scratch is W[1] ----
     float* const scratch = smem + (Cfg::OFF_W + Cfg::WSTAGE) * 4 + wave * Cfg::EPI_WAVE8;
     const int ep_n = it_n, ep_cot32 = 2 * it_cotile + ch, ep_x0 = it_x0, ep_y0 = it_y0, ep_z0 = it_z0;
+    const bool has_t1 = NPROD == 3 || it_cotile + 1 < n_cot_all;      // (false: the half-empty last pair of an odd tile count)
     EMO_W_WAIT(0);
     EMO_S_STAMP(5)
     __syncthreads();
@@ -600,13 +625,14 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
       conv_w8_res_issue<TW, RES_, 0>(a, rv_[0], ep_n, ep_cot32, ep_x0, ep_y0, ep_z0, wp, lane);                                    \
       conv_w8_res_issue<TW, RES_, 1>(a, rv_[1], ep_n, ep_cot32, ep_x0, ep_y0, ep_z0, wp, lane);                                    \
       EMO_S_STAMP(7)                                                                                                               \
-      conv_w8_epilogue_tile<TW, BM, Cfg::EPI_ROWF8, RES_, true>(a, acc_lo[0], acc_hi[0], rv_, rvn_, scratch,                        \
-                                                               smem + Cfg::OFF_BIAS_F + ch * 32, smem + Cfg::OFF_STAT_F, ep_n,     \
-                                                               ep_cot32, ep_x0, ep_y0, ep_z0, wp, ch, half, l32, lane);            \
+      conv_w8_epilogue_tile<TW, BM, Cfg::EPI_ROWF8, RES_, true, NPROD == 3>(                                                       \
+          a, acc_lo[0], acc_hi[0], rv_, rvn_, scratch, smem + Cfg::OFF_BIAS_F + ch * 32, smem + Cfg::OFF_STAT_F, ep_n, ep_cot32,    \
+          ep_x0, ep_y0, ep_z0, wp, ch, half, l32, lane, has_t1);                                                                   \
       EMO_S_STAMP(8)                                                                                                               \
-      conv_w8_epilogue_tile<TW, BM, Cfg::EPI_ROWF8, RES_, false>(a, acc_lo[1], acc_hi[1], rvn_, rv_, scratch,                       \
-                                                                smem + Cfg::OFF_BIAS2_F + ch * 32, smem + Cfg::OFF_STAT2_F, ep_n,  \
-                                                                ep_cot32 + 2, ep_x0, ep_y0, ep_z0, wp, ch, half, l32, lane);       \
+      if (has_t1)                                                                                                                  \
+        conv_w8_epilogue_tile<TW, BM, Cfg::EPI_ROWF8, RES_, false, NPROD == 3>(                                                    \
+            a, acc_lo[1], acc_hi[1], rvn_, rv_, scratch, smem + Cfg::OFF_BIAS2_F + ch * 32, smem + Cfg::OFF_STAT2_F, ep_n,          \
+            ep_cot32 + 2, ep_x0, ep_y0, ep_z0, wp, ch, half, l32, lane, false);                                                    \
       EMO_S_STAMP(9)                                                                                                               \
     }
     if (epi_mode == 1) EMO_W_EPI(1)
@@ -614,7 +640,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     else EMO_W_EPI(0)
 #undef EMO_W_EPI
   }
-  if (a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
+  if (NPROD == 3 && a.sat_flag != nullptr && sat_m > 65504.0f) *a.sat_flag = 1;   // (every writer stores the same value)
 #if EMO_S_TIMING
   EMO_S_STAMP(3)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -635,7 +661,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   __syncthreads();
   // tile statistics, second half (conv_igemm_f16x2_ct2.h): thread c of the first 128 combines the four position groups' (mean, M2)
   // of channel c with the equal-count update
-  if (a.gn_stats != nullptr && tid < 2 * BM) {
+  if (a.gn_stats != nullptr && tid < 2 * BM && it_cotile * BM + tid < a.Cout) {
     const int c_ = tid & (BM - 1);
     const float* const st_ = smem + (tid < BM ? Cfg::OFF_STAT_F : Cfg::OFF_STAT2_F);
     float mean = 0.0f, m2 = 0.0f;
@@ -672,16 +698,21 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 }
 
 // Launches the channel-tile PAIRS of the layer on conv_igemm_f16x2_w8_kernel under the conditions of conv_f16x2_ct2_launch (same
-// contract: *rest_cot0 = the first channel tile NOT covered).  EMO_CONV_W8=0: nothing is launched here (the caller falls through to
-// the one-wave-per-SIMD two-tile kernel).
-template <int TR, int TW, bool UPS>
+// contract: *rest_cot0 = the first channel tile NOT covered; 0: nothing was launched).
+// NPROD = 3 (fp16 split): only with EMO_CONV_W8=1 -- measured on one box, A B A B, the eight-wave kernel needs 4-7 % fewer cycles
+// per item than the four-wave one and the chip answers with a clock 8-10 % lower: the same frames per second (DESIGN.md
+// section 3.0b, profiles/r6_bench_w8_ab_same_box.jsonl); the four-wave kernel stays the default.
+// NPROD = 1 (plain fp16 operands): the whole layer, an odd last tile in a half-empty pair; EMO_F16_W8=0 turns it off.
+template <int TR, int TW, bool UPS, int NPROD = 3>
 int conv_f16x2_w8_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   using Cfg = ConvCfgW8<TR, TW, UPS>;
   *rest_cot0 = 0;
-  const char* const e_on = getenv("EMO_CONV_W8");
+  const char* const e_on = getenv(NPROD == 3 ? "EMO_CONV_W8" : "EMO_F16_W8");
   const char* const e_ct2 = getenv("EMO_CONV_CT2");
   const char* const e_min = getenv("EMO_CONV_CT2_MIN_ITEMS");
-  if ((e_on && atoi(e_on) == 0) || (e_ct2 && atoi(e_ct2) == 0) || a.ksplit != 1 || a.run_if != nullptr) return EMO_OK;
+  if (NPROD == 3 && (!(e_on && atoi(e_on) == 1) || (e_ct2 && atoi(e_ct2) == 0))) return EMO_OK;
+  if (NPROD == 1 && e_on && atoi(e_on) == 0) return EMO_OK;
+  if (a.ksplit != 1 || a.run_if != nullptr) return EMO_OK;
   if (a.act != EMO_ACT_NONE || a.Cout % Cfg::BM != 0 || (a.Wl & 3) != 0 || (long)a.Dl * a.Hl * a.Wl > (1l << 23) ||
       (reinterpret_cast<unsigned long long>(a.out) & 15ull) != 0 ||
       (a.res != nullptr && (reinterpret_cast<unsigned long long>(a.res) & (a.res_ups ? 7ull : 15ull)) != 0)) return EMO_OK;
@@ -690,12 +721,12 @@ int conv_f16x2_w8_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   if ((unsigned long long)a.Cin * a.D * a.H * a.W * 4ull >= (1ull << 32)) return EMO_OK;
   if ((reinterpret_cast<unsigned long long>(a.x) & 15ull) || (a.W & 3)) return EMO_OK;
   const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
-  const int pairs = cot / 2;
+  const int pairs = NPROD == 1 ? (cot + 1) / 2 : cot / 2;
   const long nt = (long)(a.Wl / TW) * (a.Hl / TR) * a.Dl;
   const int ncu = emo_cu_count();
   const long min_items = e_min ? atol(e_min) : 2l * ncu;
   if (pairs < 1 || nt > 0x7fffffffL || a.N > 65535 || nt * pairs * a.N > 0x7fffffffL || nt * pairs * a.N < min_items) return EMO_OK;
-  auto kern = conv_igemm_f16x2_w8_kernel<TR, TW, UPS>;
+  auto kern = conv_igemm_f16x2_w8_kernel<TR, TW, UPS, NPROD>;
   const int rc = emo_raise_dynamic_lds(kern);
   if (rc != EMO_OK) return rc;
   a.tiles_x = a.Wl / TW;
@@ -709,6 +740,6 @@ int conv_f16x2_w8_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   a.n_work = (int)(nt * pairs * a.N);
   const int grid = a.n_work > ncu ? ncu : a.n_work;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NTH), (size_t)Cfg::LDS_BYTES, s, a);
-  *rest_cot0 = 2 * pairs;
+  *rest_cot0 = NPROD == 1 ? cot : 2 * pairs;
   return emo_launch_status();
 }

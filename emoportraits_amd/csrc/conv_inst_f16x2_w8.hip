@@ -6,6 +6,20 @@ int conv_f16x2_w8_4x64(ConvArgs a, hipStream_t s, int ups, int* rest_cot0) {
   return ups ? conv_f16x2_w8_launch<4, 64, true>(a, s, rest_cot0) : conv_f16x2_w8_launch<4, 64, false>(a, s, rest_cot0);
 }
 
+// plain fp16 operands (NPROD = 1; emo_conv_igemm_f16w8): the whole layer in one launch, or EMO_ERR_UNSUPPORTED when the launch is
+// not in the kernel's form (the caller -- emoportraits_amd/pack.py mirrors the conditions -- then runs conv_igemm_f16.h)
+template <bool UPS>
+static int conv_f16_w8_4x64(ConvArgs a, hipStream_t s) {
+  int rest = 0;
+  const int rc = conv_f16x2_w8_launch<4, 64, UPS, 1>(a, s, &rest);
+  if (rc != EMO_OK) return rc;
+  return rest > 0 ? EMO_OK : EMO_ERR_UNSUPPORTED;
+}
+conv_launch_fn conv_lookup_f16w8_3x3(int Wl, int ups) {
+  if (Wl % 64 == 0) return ups ? &conv_f16_w8_4x64<true> : &conv_f16_w8_4x64<false>;
+  return nullptr;
+}
+
 #if EMO_S_TIMING
 // measurement builds only: the per-work-item phase stamps of the last launch (conv_igemm_f16x2_w8.h, EMO_S_TIMING)
 extern "C" int emo_debug_conv_timing_w8(unsigned long long* host_out, int n_items) {

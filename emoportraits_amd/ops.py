@@ -314,7 +314,8 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
                                    # (the pointwise split kernel has the straight-line epilogue only: 16-byte aligned out / res)
                                    aligned16=x.data_ptr() % 16 == 0 and (not getattr(layer, "pointwise_split", False) or (
                                        (res is None or res.data_ptr() % 16 == 0) and (out is None or out.data_ptr() % 16 == 0))),
-                                   in_elems_per_sample=x.numel() // max(1, N), act=act)
+                                   in_elems_per_sample=x.numel() // max(1, N), act=act,
+                                   io_aligned16=(res is None or res.data_ptr() % 16 == 0) and out.data_ptr() % 16 == 0)
     pointwise_split = prec == "f16x2" and getattr(layer, "pointwise_split", False)
     if ksplit is not None:
         ks = int(ksplit)
@@ -327,7 +328,7 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         stats = TileStats(torch.empty((N, D * Hl * Wl // bp, layer.cout, 2), device=x.device, dtype=torch.float32), bp)
     layer.last_plan = (cfg, ks, prec)        # which kernel ran (bench.py meters the kernels separately)
     entry = {"f32": lib.emo_conv_igemm_f32, "f16": lib.emo_conv_igemm_f16acc32, "bf16x3": lib.emo_conv_igemm_bf16x3,
-             "f16x2": lib.emo_conv_igemm_f16x2}[prec]
+             "f16x2": lib.emo_conv_igemm_f16x2, "f16w8": lib.emo_conv_igemm_f16w8}[prec]
     wpk = layer.packed(cfg, prec)
     common = (hip.ptr(layer.bias), hip.ptr(scale), hip.ptr(shift), hip.ptr(res), hip.ptr(out), N, Cin, layer.cout, D, H, W,
               layer.kd, layer.kh, layer.kw, int(ups), int(relu_in), hip.ACT[act], int(res_ups), cfg, ks, hip.ptr(ws),
@@ -371,6 +372,11 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
         if caller_out is not None:
             caller_out.copy_(out)
             out = caller_out
+    elif prec == "f16w8":
+        # plain fp16 operands on the eight-wave two-tile kernel (opt-in precision 'f16'; csrc/conv_igemm_f16x2_w8.h, NPROD = 1);
+        # the straight-line epilogue reads 16-byte aligned out / res: anything else was planned onto the older fp16 kernel
+        rc = entry(hip.ptr(x), hip.ptr(wpk), *common, layer.w_scale16)
+        hip.check(rc, f"emo_conv_igemm_f16w8[{layer.name}]")
     else:
         extra = (None,) if prec == "bf16x3" else ()
         rc = entry(hip.ptr(x), hip.ptr(wpk), *common, *extra)

@@ -208,6 +208,43 @@ def pack_weight_f16x2(w, bm=None):
     return planes.view(-1), w_scale
 
 
+def pack_weight_f16w8(w):
+    """operand layout of emo_conv_igemm_f16w8 (plain fp16 operands on the eight-wave two-tile kernel): the FIRST plane of the
+    fp16-split layout, [co_tile][cin chunk of 16][kd][kernel row][kernel column][half][64][8] fp16 of w * w_scale
+    -> (flat fp16 tensor, w_scale)"""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, kd, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("3x3 kernels only")
+    bm, kc = BF16X3_BM, BF16X3_KC
+    n_cot = -(-cout // bm)
+    n_cc = -(-cin // kc)
+    wmax = float(w.abs().max())
+    w_scale = 2.0 ** math.floor(math.log2(1023.0 / wmax)) if wmax > 0 else 1.0
+    wp = torch.zeros((n_cot * bm, n_cc * kc, kd, kh, kw), dtype=torch.float32)
+    wp[:cout, :cin] = w.float() * w_scale
+    w1 = wp.to(torch.float16)
+    # [cot, BM, cc, half, k8, kd, r, s] -> [cot, cc, kd, r, s, half, BM, k8]
+    w1 = w1.view(n_cot, bm, n_cc, 2, 8, kd, kh, kw).permute(0, 2, 5, 6, 7, 3, 1, 4).contiguous()
+    return w1.view(-1), w_scale
+
+
+F16_W8 = __import__("os").environ.get("EMO_F16_W8", "1") != "0"   # A/B switch: 0 keeps every fp16-operand layer on conv_igemm_f16.h
+
+
+def f16w8_launch_fits(cout, cin, kd, kh, kw, Hl, Wl, n_pos_tiles, act="none", positions_per_sample=0):
+    """the one launch form of emo_conv_igemm_f16w8 (conv_f16x2_w8_launch<.., NPROD = 1> -- every check of the C launcher has its
+    mirror here): 3x3 / 3x3x3, whole 64-channel tiles and 8-channel groups, 4 x 64 position tiles, no activation, at most 2^23
+    positions per sample, two pair items per CU (an odd last channel tile counts as a pair)"""
+    if not F16_W8 or (kh, kw) != (3, 3) or kd not in (1, 3) or cout % BF16X3_BM or cin % 8 or act != "none":
+        return False
+    if Hl is None or Wl % 64 or Hl % 4 or positions_per_sample > (1 << 23):
+        return False
+    min_items = int(__import__("os").environ.get("EMO_CONV_CT2_MIN_ITEMS", 2 * cu_count()))
+    return (n_pos_tiles // 2) * (-(-(cout // BF16X3_BM) // 2)) >= min_items
+
+
 F16X2_P1_KC = 32     # conv_igemm_f16x2_p1.h: input channels per stage of the pointwise kernel
 
 
@@ -501,6 +538,11 @@ class PackedConv:
 
     def packed(self, cfg, precision="f32"):
         """packed weights for a block config: fp32 layout, or the fp16 operand layout (64 x 256 and 128 x 256 tiles)"""
+        if precision == "f16w8":
+            if "f16w8" not in self._packed:
+                flat, self.w_scale16 = pack_weight_f16w8(self._weight)
+                self._packed["f16w8"] = flat.to(self.device)
+            return self._packed["f16w8"]
         if precision == "f16":
             key = ("f16", CFG_G if cfg == CFG_G else CFG_D)
             if key not in self._packed:
@@ -534,12 +576,20 @@ class PackedConv:
             return self.pinned_cfg
         return choose_cfg_for_launch(self.cout, n_pos_tiles, self.allowed)
 
-    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False, aligned16=True, in_elems_per_sample=0, act="none"):
+    def plan_for(self, n_pos_tiles, Hl=None, Wl=None, ups=False, affine=False, aligned16=True, in_elems_per_sample=0, act="none",
+                 io_aligned16=True):
         """(cfg, ksplit, precision) for a launch over n_pos_tiles 128-position tiles of an Hl x Wl output; `affine`: the
         launch carries a per-sample input scale / shift (the fp16-operand kernel keeps those in a 1024-entry LDS table);
         `aligned16`: the input pointer is 16-byte aligned (that kernel loads 16-byte quads); `in_elems_per_sample`:
         Cin*D*H*W of the input -- that kernel addresses a sample with 32-bit byte offsets (conv_igemm_f16_launch), larger
-        inputs take the exact-fp32 kernel like every other unsupported case"""
+        inputs take the exact-fp32 kernel like every other unsupported case; `io_aligned16`: output and residual pointers are
+        16-byte aligned too (the straight-line epilogue of emo_conv_igemm_f16w8 needs it)"""
+        if self.precision == "f16" and self.pinned_cfg in (None, CFG_D) and aligned16 and io_aligned16 \
+                and in_elems_per_sample * 4 < (1 << 32) and not (affine and self.cin > F16_AFFINE_MAX_CIN) \
+                and f16w8_launch_fits(self.cout, self.cin, self.kd, self.kh, self.kw, Hl, Wl, n_pos_tiles, act,
+                                      in_elems_per_sample // max(1, self.cin) * (4 if ups else 1)):
+            # the decoders' 3x3 layers in their launch form: plain fp16 operands on the eight-wave two-tile kernel (round 6)
+            return CFG_D, 1, "f16w8"
         if self.precision == "f16" and f16_launch_fits(Hl, Wl) and self.pinned_cfg in (None, CFG_D, CFG_G) and aligned16 \
                 and in_elems_per_sample * 4 < (1 << 32) \
                 and not (affine and self.cin > F16_AFFINE_MAX_CIN) and not (self.pinned_cfg == CFG_G and self.kh != 3):

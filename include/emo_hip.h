@@ -202,6 +202,20 @@ int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const float* bias
                             int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace,
                             float* gn_stats, void* stream);
 
+/* ABI 9.  The reduced-precision mode of BASELINE configs[4] ("fp16 MFMA convs") for the decoders' 3x3 / 3x3x3 layers on the
+ * eight-wave two-tile kernel (csrc/conv_igemm_f16x2_w8.h, NPROD = 1): plain fp16 operands -- the LEADING product of the fp16
+ * split alone --, fp32 accumulation, fp32 tensors; the operands saturate at +-65504 as in emo_conv_igemm_f16acc32 (no range
+ * word, no guarded recomputation).  wpk1 = emoportraits_amd.pack.pack_weight_f16w8(w): the first plane of the split layout,
+ * [channel tile][Cin chunk of 16][kd][kernel row][kernel column][half][64][8] fp16 of w * w_scale (a power of two; the result
+ * is multiplied by 1 / w_scale).  One launch form only -- the straight-line epilogue's: cfg 3, ksplit 1, no activation, whole
+ * 64-channel tiles, 4 x 64 position tiles (Wl % 64 == 0, Hl % 4 == 0), 16-byte aligned tensors, at least two pair items per CU --
+ * EMO_ERR_UNSUPPORTED otherwise (run emo_conv_igemm_f16acc32).  Replaces the same reference code as emo_conv_igemm_f32
+ * (networks/volumetric_avatar/utils.py:661-788) under notebooks/infer_s2.py:351-387's decoder. */
+int emo_conv_igemm_f16w8(const float* x, const void* wpk1, const float* bias, const float* scale, const float* shift,
+                         const float* res, float* out, int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
+                         int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace, float* gn_stats,
+                         void* stream, float w_scale);
+
 /* fp32 3x3 convolution on the bf16 matrix pipes (NOT a reduced-precision mode): every fp32 operand is the exact sum of three
  * bf16 terms (x = xh + xm + xl, 24 significand bits kept), the six partial products of order <= 2^-16 are accumulated in fp32
  * by v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-23 |x w| per product, below the fp32 accumulation error of either

@@ -110,6 +110,10 @@ class Case:
         elif mode == "f16":
             wpk = _buf(_half_bits(pack.pack_weight_f16(self.w, cfg)))
             rc = lib.emo_conv_igemm_f16acc32(_p(xa), _p(wpk), *common)
+        elif mode == "f16w8":
+            flat, ws = pack.pack_weight_f16w8(self.w)
+            wpk = _buf(_half_bits(flat))
+            rc = lib.emo_conv_igemm_f16w8(_p(xa), _p(wpk), *common, ctypes.c_float(ws))
         else:
             raise ValueError(mode)
         assert rc == 0, (mode, rc)
@@ -271,6 +275,45 @@ def test_fp16_operand_kernels(lib, k, dims):
     c = Case(1, 32, 72, dims, k=k, res=True, seed=13 + k)
     out, _ = c.launch(lib, "f16")
     assert c.err(out) < 2e-3                                                          # fp16 operands, fp32 accumulation
+
+
+F16W8_FORMS = [
+    dict(N=2, Cin=40, Cout=128, dims=(16, 64), res=True),                                  # chained items, a ragged last stage
+    dict(N=1, Cin=16, Cout=192, dims=(32, 64), res=True),                                  # three channel tiles: a half-empty last pair
+    dict(N=1, Cin=24, Cout=64, dims=(32, 64), res=False),                                  # ONE channel tile: every pair is half empty
+    dict(N=1, Cin=24, Cout=128, dims=(8, 32), ups=True, res=True, res_ups=True),           # fused upsample, half-size residual
+    dict(N=1, Cin=16, Cout=320, dims=(2, 8, 64), res=True),                                # depth taps, five tiles
+]
+
+
+@pytest.mark.parametrize("form", F16W8_FORMS)
+def test_plain_fp16_operands_on_the_eight_wave_kernel(lib, form, monkeypatch):
+    """emo_conv_igemm_f16w8 (conv_igemm_f16x2_w8.h, NPROD = 1: the reduced-precision mode of BASELINE configs[4] on the decoders'
+    launch form) against an fp64 convolution at the fp16-operand bound, against the older fp16-operand kernel (the same operand
+    rounding: they agree far inside that bound), with tile statistics; an odd last channel tile runs in a half-empty pair"""
+    kw = dict(form)
+    N, Cin, Cout, dims = kw.pop("N"), kw.pop("Cin"), kw.pop("Cout"), kw.pop("dims")
+    c = Case(N, Cin, Cout, dims, seed=Cin + Cout, **kw)
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    out, st = c.launch(lib, "f16w8", stats=True)
+    assert not np.isnan(out).any() and not np.isnan(st).any()
+    assert c.err(out) < 2e-3
+    old, _ = c.launch(lib, "f16")
+    assert np.abs(out - old).max() <= 2e-5 * max(1.0, np.abs(old).max())
+    o = torch.from_numpy(out.copy()).double().view(N, Cout, -1)
+    s = torch.from_numpy(st.copy()).double()
+    mean = s[..., 0].mean(1)
+    m2 = s[..., 1].sum(1) + 256 * ((s[..., 0] - mean[:, None]) ** 2).sum(1)
+    assert (mean - o.mean(-1)).abs().max().item() < 1e-5
+    assert (m2 - ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1)).abs().max().item() < 1e-3 * m2.abs().max().item()
+
+
+def test_plain_fp16_eight_wave_kernel_declines_other_launch_forms(lib):
+    c = Case(1, 16, 64, (16, 32), res=False, seed=1)                                      # 8 x 32 position tiles
+    wpk = _buf(_half_bits(pack.pack_weight_f16w8(c.w)[0]))
+    out = _buf(np.zeros(c.ref.shape, np.float32))
+    args = [_p(_buf(c.x)), _p(wpk), None, None, None, None, _p(out), 1, 16, 64, 1, 16, 32, 1, 3, 3, 0, 1, 0, 0, CFG_D, 1, None, None, None]
+    assert lib.emo_conv_igemm_f16w8(*args, ctypes.c_float(1.0)) == -2                      # EMO_ERR_UNSUPPORTED
 
 
 # ---- seeded random launch forms --------------------------------------------------------------------------------------------------

@@ -208,6 +208,37 @@ def test_conv_fp16_operands(case):
         pack.PackedConv("bad", torch.zeros(64, 12, 3, 3), None, DEV, precision="f16")     # Cin not a multiple of 8
 
 
+F16W8_CASES = [
+    dict(N=2, Cin=128, Cout=128, dims=(128, 128), k=3, cfg=None, affine=True, relu_in=True, res=True),
+    dict(N=2, Cin=48, Cout=192, dims=(64, 64), k=3, cfg=None, affine=True, relu_in=True),                   # odd tile count
+    dict(N=3, Cin=64, Cout=320, dims=(32, 64), k=3, cfg=None, affine=True, relu_in=True, res=True),         # five tiles, chains
+    dict(N=2, Cin=40, Cout=64, dims=(64, 128), k=3, cfg=None, affine=True, relu_in=True, res=True),         # ONE tile: half-empty pairs
+    dict(N=2, Cin=64, Cout=192, dims=(32, 32), k=3, cfg=None, ups=True, affine=True, relu_in=True, res=True, res_ups=True),
+    dict(N=1, Cin=24, Cout=128, dims=(6, 64, 64), k=3, cfg=None, affine=True, relu_in=True, res=True),      # depth taps
+    dict(N=4, Cin=512, Cout=512, dims=(64, 64), k=3, cfg=None, affine=True, relu_in=True, res=True),        # the decoder trunk's layer
+]
+
+
+@pytest.mark.parametrize("case", F16W8_CASES)
+def test_conv_fp16_operands_on_the_eight_wave_two_tile_kernel(case, monkeypatch):
+    """precision='f16' in the decoders' launch form runs emo_conv_igemm_f16w8 (round 6: conv_igemm_f16x2_w8.h with the leading
+    product alone -- plain fp16 operands, two waves per SIMD, an odd last channel tile in a half-empty pair): the fp16-operand bound
+    against torch CPU fp32, deterministic, and within accumulation-order noise of the older fp16-operand kernel (EMO_F16_W8=0),
+    which rounds the same operands"""
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    e, got, ref = run_conv(seed=12, precision="f16", **case)
+    print("PARITY conv fp16 operands, eight-wave kernel:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
+    assert e < 3e-3, e
+    layer = pack.PackedConv("t", torch.randn(case["Cout"], case["Cin"], *([3] * len(case["dims"]))), None, DEV, precision="f16")
+    Hl, Wl = [d * (2 if case.get("ups") else 1) for d in case["dims"][-2:]]
+    assert layer.plan_for(1 << 12, Hl, Wl, case.get("ups", False), in_elems_per_sample=case["Cin"] * 4096)[2] == "f16w8"
+    e2, got2, _ = run_conv(seed=12, precision="f16", **case)
+    assert torch.equal(got, got2), "two launches on the same input differ: a race in the pipeline"
+    monkeypatch.setattr(pack, "F16_W8", False)
+    e3, old, _ = run_conv(seed=12, precision="f16", **case)
+    assert (got - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_conv_fp16_layer_falls_back_to_fp32_on_narrow_maps_and_writes_tile_statistics():
     """a layer built with precision='f16' runs the fp16-operand kernel where its 64 x 256 tile fits and the exact-fp32 kernel on
     the 16- / 8-wide maps (WarpGenerator); both produce the GroupNorm tile statistics"""
@@ -622,6 +653,21 @@ def test_pose_theta_and_pack(golden_dir):
     img = torch.rand(2, 3, 16, 24, generator=torch.Generator().manual_seed(9)) * 1.4 - 0.2
     ref = img.clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1)
     assert torch.equal(ops.pack_rgb8(img.to(DEV)).cpu(), ref)
+
+
+def test_resize2d_windows_is_one_launch_of_the_per_frame_crops():
+    """ops.resize2d_windows (ABI 9): a batch of frames, each with its own crop window (notebooks/infer.py:301-352 crops every frame
+    around its own face box), in one launch -- bit for bit what ops.resize2d gives frame by frame"""
+    g = torch.Generator().manual_seed(14)
+    x = torch.rand(5, 3, 96, 128, generator=g).to(DEV)
+    wins = [(10, 5, 80, 80), (40, 16, 64, 64), (0, 0, 128, 96), (100, 60, 28, 36), (7, 9, 50, 40)]
+    got = ops.resize2d_windows(x, (64, 64), wins, "bicubic", clamp01=True)
+    for i, w in enumerate(wins):
+        assert torch.equal(got[i:i + 1], ops.resize2d(x[i:i + 1], (64, 64), "bicubic", window=w, clamp01=True))
+    dev_wins = torch.tensor(wins, dtype=torch.int32, device=DEV)
+    assert torch.equal(ops.resize2d_windows(x, (64, 64), dev_wins, "bicubic", clamp01=True), got)
+    with pytest.raises(ValueError):
+        ops.resize2d_windows(x, (64, 64), [(100, 60, 40, 36)] * 5)                      # a window that leaves the frame
 
 
 @pytest.mark.parametrize("mode", ["bilinear", "bicubic"])

@@ -148,6 +148,28 @@ def test_resize2d(lib, bicubic):
     assert np.abs(out - ref).max() < 2e-6
 
 
+@pytest.mark.parametrize("bicubic", [0, 1])
+def test_resize2d_windows_is_the_single_window_kernel_bit_for_bit(lib, bicubic):
+    """emo_resize2d_windows_f32 (ABI 9: one crop window per frame of a batch, one launch) against one emo_resize2d_f32 call per
+    frame on that frame's window, and against F.interpolate on the cropped frame"""
+    rng = np.random.default_rng(6)
+    N, C, H, W, Ho, Wo = 3, 3, 40, 56, 16, 16
+    x = rng.random((N, C, H, W)).astype(np.float32)
+    wins = np.array([[10, 5, 30, 30], [0, 0, 56, 40], [33, 17, 8, 12]], dtype=np.int32)          # (x0, y0, w, h)
+    out = np.empty((N, C, Ho, Wo), np.float32)
+    rc = lib.emo_resize2d_windows_f32(_p(x), ctypes.c_int64(H * W), ctypes.c_int64(W), _p(wins), _p(out), N, C, Ho, Wo, bicubic, 1, None)
+    assert rc == 0
+    for i, (x0, y0, w, h) in enumerate(wins.tolist()):
+        one = np.empty((C, Ho, Wo), np.float32)
+        first = ctypes.c_void_p(x[i].ctypes.data + 4 * (y0 * W + x0))
+        assert lib.emo_resize2d_f32(first, ctypes.c_int64(H * W), ctypes.c_int64(W), _p(one), ctypes.c_int64(C), h, w, Ho, Wo, bicubic, 1, None) == 0
+        assert np.array_equal(one.view(np.uint32), out[i].view(np.uint32))
+        ref = F.interpolate(torch.from_numpy(x[i:i + 1, :, y0:y0 + h, x0:x0 + w].copy()), size=(Ho, Wo),
+                            mode="bicubic" if bicubic else "bilinear", align_corners=False).clamp(0, 1)[0].numpy()
+        assert np.abs(out[i] - ref).max() < 2e-6
+    assert lib.emo_resize2d_windows_f32(_p(x), ctypes.c_int64(H * W), ctypes.c_int64(W), None, _p(out), N, C, Ho, Wo, bicubic, 1, None) == -1
+
+
 @pytest.mark.parametrize("act", ["none", "tanh", "sigmoid", "relu"])
 @pytest.mark.parametrize("N,cin,cout,dims,affine,relu_in", [
     (2, 128, 3, (16, 24), True, True),         # the image head's form

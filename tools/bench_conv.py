@@ -63,6 +63,9 @@ def main():
         x = torch.randn(B, cin, *dims, device=DEV)
         kd = k if three_d else 1
         w = torch.randn(cout, cin, *([k] * len(dims))) / math.sqrt(cin * k * k * kd)
+        if "--zeros" in sys.argv:       # all-zero operands: no toggling in the matrix pipes -- what the SCHEDULE gives when power does not bind
+            x.zero_()
+            w.zero_()
         scale = torch.rand(B, cin, device=DEV) + 0.5
         shift = torch.randn(B, cin, device=DEV) * 0.1
         odims = tuple(d * 2 for d in dims) if ups else dims
