@@ -38,7 +38,7 @@ static int shape_of_width(int Wl) {
 }
 
 static int kc_of(int KH, int KW, int cfg, int prec = PREC_F32) {
-  if (prec == PREC_H1) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;
+  if (prec == PREC_H1) return (cfg == CFG_D && KH == 3 && KW == 3) ? 32 : 0;   // two 16-channel k-blocks per stage
   if (prec == PREC_S2 && cfg == CFG_D && KH == 1 && KW == 1) return 32;   // conv_igemm_f16x2_p1.h: pointwise, 32 channels per stage
   if (prec == PREC_S2 && cfg == CFG_F && KH == 3 && KW == 3) return 16;   // fp16 split on 32-row channel tiles (conv_igemm_bf16x3.h, BMT = 32)
   if (prec == PREC_S || prec == PREC_S2) return (cfg == CFG_D && KH == 3 && KW == 3) ? 16 : 0;

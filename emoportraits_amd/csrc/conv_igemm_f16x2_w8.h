@@ -190,20 +190,25 @@ __device__ __forceinline__ void conv_w8_epilogue_tile(const ConvArgs& a, floatx1
 }
 
 // NPROD = 3: the fp16 SPLIT (fp32 results).  NPROD = 1 -- BASELINE configs[4], "fp16 MFMA convs", emo_conv_igemm_f16w8: plain fp16
-// operands, the leading product only -- ONE operand plane (weights packed as the first plane of the split layout, 18 chunks per
-// half-stage; the patch's second plane stays unwritten), one accumulator set, operands saturate at +-65504 as in
-// conv_igemm_f16.h (no range word).  With a third of the matrix work the K loop is bound by what the waves ISSUE, not by the
-// pipe -- which is where a second wave per SIMD pays.  A layer with an odd number of channel tiles runs its last tile in a pair
-// whose second half recomputes the same tile and is not written (the single-tile kernel has no such mode).
+// operands, ONE product per operand pair, one accumulator set, operands saturate at +-65504 as in conv_igemm_f16.h (no range
+// word).  The two operand PLANES of the split layout become two 16-channel K BLOCKS: a stage is 32 input channels, the LDS image,
+// the fragment reads, the weight chunks (36 per half-stage) and the schedule are those of the split -- a step is 6 fragment reads
+// and FOUR MFMAs (2 k-blocks x 2 position tiles) instead of six, a thread stages its quad of 4 channels of BOTH k-blocks (8
+// channel planes).  (A first build kept 16-channel stages with one plane: 18 MFMAs per half-stage between two barriers left the
+// latency of the weight chunks and patch loads exposed -- 535-850 TF, a tie with conv_igemm_f16.h: tools/session/r6_call3.sh.)
+// A layer with an odd number of channel tiles runs its last tile in a pair whose second half recomputes the same tile and is not
+// written (the single-tile kernel has no such mode): the host plans such layers onto conv_igemm_f16.h (pack.f16w8_launch_fits).
 template <int TR, int TW, bool UPS, int NPROD = 3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   using Cfg = ConvCfgW8<TR, TW, UPS>;
   using opx8 = halfx8;
   static_assert(NPROD == 3 || NPROD == 1, "the split's three products, or the leading one alone");
-  constexpr int NPL = NPROD == 1 ? 1 : 2;                // operand planes in use
-  constexpr int NCHK = NPROD == 1 ? 18 : 36;             // 1 KiB weight chunks per half-stage
-  constexpr int NDM = NPROD == 1 ? 3 : 5;                // chunk copies per wave and half-stage
+  constexpr int NPL = 2;                                 // operand planes (NPROD = 3) / 16-channel k-blocks of a stage (NPROD = 1)
+  constexpr int NCHK = 36;                               // 1 KiB weight chunks per half-stage
+  constexpr int NDM = 5;                                 // chunk copies per wave and half-stage
+  constexpr int NKB = NPROD == 1 ? 2 : 1;                // k-blocks a thread stages
+  constexpr int KCE = 16 * NKB;                          // input channels per stage
   constexpr int BM = Cfg::BM, TP = Cfg::TP, WGP = Cfg::WGP, KC = Cfg::KC, NTH = Cfg::NTH;
   constexpr int PR = Cfg::PR, NQ = Cfg::NQ, NQ1 = Cfg::NQ1, SUB = Cfg::SUB, CHS = Cfg::CHS, QPG = Cfg::QPG;
   constexpr int NHQ = Cfg::NHQ, TWS = Cfg::TWS, WPLANE = Cfg::WPLANE, WROW = Cfg::WROW, PPL = Cfg::PPL, PBUF = Cfg::PBUF;
@@ -332,10 +337,10 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   const unsigned lane16 = (unsigned)lane * 16u;
 
   // raw patch registers: ONE buffer of four channel planes -- converted during half-stage 0, reloaded during half-stage 1
-  floatx4 qv[4];
-  float q_lo, q_hi;
-  int q_tix;
-  floatx4 q_sc, q_sh;
+  floatx4 qv[NKB][4];
+  float q_lo[NKB], q_hi[NKB];
+  int q_tix[NKB];
+  floatx4 q_sc[NKB], q_sh[NKB];
   emo_intx4 xrs = emo_raw_buffer(a.x);
   unsigned usoff[4];
 #pragma unroll
@@ -346,50 +351,62 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   int ld_stage, ld_cc, ld_kd;   // the stage whose patch is being loaded, stepped (no division in the loop)
 #define EMO_W_SET_STAGE_VARS()                                                                        \
   {                                                                                                   \
-    n_ci0 = ld_cc * KC;                                                                               \
+    n_ci0 = ld_cc * KCE;                                                                              \
     n_zu = lq_z0 + ld_kd - padD;                                                                      \
     n_zv = (unsigned)n_zu < (unsigned)a.D;                                                            \
   }
-  unsigned q_vo;
+  unsigned q_vo[NKB];
 #define EMO_W_ISSUE_BEGIN()                                                                           \
   {                                                                                                   \
-    const int c0_ = n_ci0 + q_g * 8;                                                                  \
-    const bool cv_ = c0_ < a.Cin;                                                                     \
-    const int cs_ = cv_ ? c0_ : 0;                                                                    \
-    const bool keep_ = lq_ok && cv_ && n_zv;                                                          \
-    q_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
-    q_hi = keep_ ? CLAMP_HI : 0.0f;                                                                   \
-    q_vo = lq_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;        \
-    q_tix = ((has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2) + ch;                                  \
+    _Pragma("unroll") for (int kb = 0; kb < NKB; ++kb) {                                              \
+      const int c0_ = n_ci0 + 16 * kb + q_g * 8;                                                      \
+      const bool cv_ = c0_ < a.Cin;                                                                   \
+      const int cs_ = cv_ ? c0_ : 0;                                                                  \
+      const bool keep_ = lq_ok && cv_ && n_zv;                                                        \
+      q_lo[kb] = keep_ ? clamp_lo : 0.0f;                                                             \
+      q_hi[kb] = keep_ ? CLAMP_HI : 0.0f;                                                             \
+      q_vo[kb] = lq_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;  \
+      q_tix[kb] = ((has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2) + ch;                            \
+    }                                                                                                 \
   }
-#define EMO_W_ISSUE_LOADS(u0_) { emo_bload4x2_pinned(xrs, q_vo, usoff[u0_], usoff[(u0_) + 1], qv[u0_], qv[(u0_) + 1]); }
+// paired load v_ = 0 .. 2 NKB - 1 of a stage: channel planes 2 (v_ & 1), 2 (v_ & 1) + 1 of k-block v_ >> 1
+#define EMO_W_ISSUE_LOADS(v_)                                                                         \
+  { emo_bload4x2_pinned(xrs, q_vo[(v_) >> 1], usoff[2 * ((v_) & 1)], usoff[2 * ((v_) & 1) + 1], qv[(v_) >> 1][2 * ((v_) & 1)],  \
+                        qv[(v_) >> 1][2 * ((v_) & 1) + 1]); }
 #define EMO_W_TABLE()                                                                                 \
   {                                                                                                   \
-    const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix;                               \
-    q_sc = t4_[0]; q_sh = t4_[Cfg::SCT / 4];                                                          \
+    _Pragma("unroll") for (int kb = 0; kb < NKB; ++kb) {                                              \
+      const floatx4* t4_ = reinterpret_cast<const floatx4*>(sct) + q_tix[kb];                         \
+      q_sc[kb] = t4_[0]; q_sh[kb] = t4_[Cfg::SCT / 4];                                                \
+    }                                                                                                 \
   }
-#define EMO_W_TOUCH_QUAD() { _Pragma("unroll") for (int u = 0; u < 4; ++u) emo_touch4(qv[u]); }
-// conversion of the lane's four channels of pixel i_ (conv_igemm_bf16x3.h, SPLIT = 2); pbyte_: byte offset of the target patch buffer
-#define EMO_W_CONV_UNIT(pbyte_, i_)                                                                   \
+#define EMO_W_TOUCH_QUAD() { _Pragma("unroll") for (int kb = 0; kb < NKB; ++kb) _Pragma("unroll") for (int u = 0; u < 4; ++u) emo_touch4(qv[kb][u]); }
+// conversion of the lane's four channels (of k-block kb_) of pixel i_ (conv_igemm_bf16x3.h, SPLIT = 2); pbyte_: byte offset of the
+// target patch buffer.  NPROD = 3: both planes of the one k-block; NPROD = 1: the fp16 value into plane kb_
+#define EMO_W_CONV_UNIT(pbyte_, i_, kb_)                                                              \
   {                                                                                                   \
     float t_[4];                                                                                      \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                     \
-      t_[k] = __fmaf_rn(qv[k][i_], q_sc[k], q_sh[k]);                                                 \
+      t_[k] = __fmaf_rn(qv[kb_][k][i_], q_sc[kb_][k], q_sh[kb_][k]);                                  \
     if constexpr (NPROD == 3) {                                                                       \
       sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[0])), __builtin_fabsf(t_[1])); \
       sat_m = __builtin_fmaxf(__builtin_fmaxf(sat_m, __builtin_fabsf(t_[2])), __builtin_fabsf(t_[3])); \
     }                                                                                                 \
     halfx4 cvh_, cvm_;                                                                                \
     _Pragma("unroll") for (int k = 0; k < 4; k += 2)                                                  \
-      emo_split_f16x2_pair(__builtin_amdgcn_fmed3f(t_[k], q_lo, q_hi), __builtin_amdgcn_fmed3f(t_[k + 1], q_lo, q_hi), \
-                           cvh_, cvm_, k);                                                            \
+      emo_split_f16x2_pair(__builtin_amdgcn_fmed3f(t_[k], q_lo[kb_], q_hi[kb_]),                      \
+                           __builtin_amdgcn_fmed3f(t_[k + 1], q_lo[kb_], q_hi[kb_]), cvh_, cvm_, k);  \
     char* d_ = lds_w + (q_slb[i_] + (pbyte_));                                                        \
-    *reinterpret_cast<halfx4*>(d_) = cvh_;                                                            \
-    if constexpr (NPROD == 3) *reinterpret_cast<halfx4*>(d_ + PPL * 16) = cvm_;                       \
+    if constexpr (NPROD == 3) {                                                                       \
+      *reinterpret_cast<halfx4*>(d_) = cvh_;                                                          \
+      *reinterpret_cast<halfx4*>(d_ + PPL * 16) = cvm_;                                               \
+    } else {                                                                                          \
+      *reinterpret_cast<halfx4*>(d_ + (kb_) * PPL * 16) = cvh_;                                       \
+    }                                                                                                 \
   }
-// chunk m_ = 0 .. NDM - 1 of this wave's share of a half-stage's NCHK weight chunks (header comment; 18 chunks: w, w + 8 and one of
-// 16, 17 a second time), to the LDS byte address dst_ + chunk KiB
-#define EMO_W_CHUNK_OF(m_) (NPROD == 1 ? ((m_) < 2 ? wave + 8 * (m_) : 16 + (wave & 1)) : ((m_) < 4 ? wave + 8 * (m_) : 32 + wp))
+// chunk m_ = 0 .. NDM - 1 of this wave's share of a half-stage's NCHK weight chunks (header comment), to the LDS byte address
+// dst_ + chunk KiB
+#define EMO_W_CHUNK_OF(m_) ((m_) < 4 ? wave + 8 * (m_) : 32 + wp)
 #define EMO_W_DMA_CHUNK(ptr_, dst_, m_)                                                               \
   {                                                                                                   \
     const int c_ = EMO_W_CHUNK_OF(m_);                                                                \
@@ -400,7 +417,9 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #define EMO_W_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
 
   // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
-  constexpr int PA3[3] = {NPROD == 1 ? 0 : 1, 0, 0}, PB3[3] = {0, 1, 0};
+  // (NPROD = 1: "products" = the two k-blocks of a stage, weight block x patch block, both into the one accumulator set)
+  constexpr int NMM = NPROD == 1 ? 2 : 3;                // MFMAs per position tile and step
+  constexpr int PA3[3] = {NPROD == 1 ? 0 : 1, NPROD == 1 ? 1 : 0, 0}, PB3[3] = {0, 1, 0};
   constexpr int WROWU = NPL * WPLANE;                    // slots between the kernel rows of a stage buffer
   constexpr int NTE = Cfg::SCT / NTH;
   float te_sc[NTE], te_sh[NTE], te_b = 0.0f;
@@ -448,7 +467,9 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   } else {
     // ---- full prologue: tables, the chunks of (c0, stage 0), the patch of stage 0 converted into P[0], the loads of stage 1 ----
 #pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" : "=v"(qv[u]));
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "=v"(qv[kb][u]));
     xrs = emo_raw_buffer(a.x + (long)it_n * a.Cin * DHW);
     EMO_W_CURSOR_OF(it_, lq_ok, lq_off)
     lq_z0 = it_z0;
@@ -471,8 +492,8 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     ld_stage = 0; ld_cc = 0; ld_kd = 0;
     EMO_W_SET_STAGE_VARS()
     EMO_W_ISSUE_BEGIN()
-    EMO_W_ISSUE_LOADS(0)
-    EMO_W_ISSUE_LOADS(2)
+#pragma unroll
+    for (int v = 0; v < 2 * NKB; ++v) EMO_W_ISSUE_LOADS(v)
 #pragma unroll
     for (int k = 0; k < NTE; ++k) {       // (without an affine the index wraps at SCT: identity entries)
       const int c = tid + NTH * k;
@@ -490,15 +511,17 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     __syncthreads();   // scale / shift tables visible
     EMO_W_TABLE()
 #pragma unroll
-    for (int i = 0; i < 4; ++i) EMO_W_CONV_UNIT(Cfg::OFF_P * 16, i)
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) EMO_W_CONV_UNIT(Cfg::OFF_P * 16, i, kb)
     if (nst > 1) {                        // (one-stage item: the same patch again, a dead re-stage)
       ++ld_stage;
       if (++ld_kd == a.KD) { ld_kd = 0; ++ld_cc; }
     }
     EMO_W_SET_STAGE_VARS()
     EMO_W_ISSUE_BEGIN()
-    EMO_W_ISSUE_LOADS(0)
-    EMO_W_ISSUE_LOADS(2)
+#pragma unroll
+    for (int v = 0; v < 2 * NKB; ++v) EMO_W_ISSUE_LOADS(v)
     EMO_W_TABLE()
     {
       const char* const w1_ = EMO_W_WPTR(it_cotile + 1, 0);
@@ -573,29 +596,47 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
             }
             // chunks 1 .. NDM - 1 of the rows of half-stage t + 1 into W[h ^ 1], one per step
             if (gs < NDM - 1 && pl == 0) EMO_W_DMA_CHUNK(dma_ptr, EMO_W_WBUF(h ^ 1), 1 + gs)
-            if (h == 1 && gs < 2 && pl == NPL - 1) EMO_W_ISSUE_LOADS(2 * gs)
+            if (h == 1 && gs < 2 * NKB && pl == NPL - 1) EMO_W_ISSUE_LOADS(gs)
           }
         }
-        if (h == 0 && gs < 4) EMO_W_CONV_UNIT(pnxt_b, gs)
+        // the patch of stage cg + 1: one conversion unit per step (four channels of one pixel, of one k-block)
+        if (h == 0 && gs < 4 * NKB) EMO_W_CONV_UNIT(pnxt_b, gs / NKB, gs % NKB)
         if (h == 1 && gs == 7) { EMO_W_TABLE() }           // (what the next stage's units convert with)
 #pragma unroll
-        for (int p = 0; p < NPROD; ++p) {
+        for (int p = 0; p < NMM; ++p) {
           const int pa = PA3[p], pb = PB3[p];
 #pragma unroll
           for (int j = 0; j < TP; ++j) {
-            floatx16& acc_ = (pa == 0 && pb == 0) ? acc_lo[h][j] : acc_hi[h][j];
+            floatx16& acc_ = (NPROD == 1 || (pa == 0 && pb == 0)) ? acc_lo[h][j] : acc_hi[h][j];
             acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[fcur][pb][j], fa_[fcur][pa], acc_, 0, 0, 0);
           }
         }
         if (EMO_S_PIN) {
-          // one fragment read behind each of the six MFMAs, the step's other work spread between them (one operand plane: two
-          // MFMAs and three fragment reads per step)
+          // the step's six fragment reads and its other work spread between its MFMAs (six; plain fp16 operands: four, the first
+          // two with two reads each)
+          if constexpr (NPROD == 1) {
 #pragma unroll
-          for (int k = 0; k < 2 * NPROD; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NPROD == 1 ? 2 : 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, NPROD == 1 ? 14 : 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            for (int k = 0; k < 2; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -732,7 +773,8 @@ int conv_f16x2_w8_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   a.tiles_x = a.Wl / TW;
   a.tiles_y = a.Hl / TR;
   a.tiles_z = a.Dl;
-  a.n_cchunks = (a.Cin + Cfg::KC - 1) / Cfg::KC;
+  constexpr int KCE = NPROD == 1 ? 32 : Cfg::KC;   // (plain fp16 operands: 32 input channels per stage)
+  a.n_cchunks = (a.Cin + KCE - 1) / KCE;
   a.stages_per_split = a.n_cchunks * a.KD;
   a.partial = nullptr;
   a.cot0 = 0;

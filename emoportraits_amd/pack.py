@@ -209,15 +209,16 @@ def pack_weight_f16x2(w, bm=None):
 
 
 def pack_weight_f16w8(w):
-    """operand layout of emo_conv_igemm_f16w8 (plain fp16 operands on the eight-wave two-tile kernel): the FIRST plane of the
-    fp16-split layout, [co_tile][cin chunk of 16][kd][kernel row][kernel column][half][64][8] fp16 of w * w_scale
-    -> (flat fp16 tensor, w_scale)"""
+    """operand layout of emo_conv_igemm_f16w8 (plain fp16 operands on the eight-wave two-tile kernel): the fp16-split layout with
+    its two PLANES holding the two 16-channel K BLOCKS of a 32-channel stage,
+    [co_tile][cin chunk of 32][kd][kernel row][k-block][kernel column][half][64][8] fp16 of w * w_scale (channel in chunk =
+    16 * k-block + 8 * half + 0..7) -> (flat fp16 tensor, w_scale)"""
     if w.dim() == 4:
         w = w.unsqueeze(2)
     cout, cin, kd, kh, kw = w.shape
     if (kh, kw) != (3, 3):
         raise ValueError("3x3 kernels only")
-    bm, kc = BF16X3_BM, BF16X3_KC
+    bm, kc = BF16X3_BM, 2 * BF16X3_KC
     n_cot = -(-cout // bm)
     n_cc = -(-cin // kc)
     wmax = float(w.abs().max())
@@ -225,19 +226,24 @@ def pack_weight_f16w8(w):
     wp = torch.zeros((n_cot * bm, n_cc * kc, kd, kh, kw), dtype=torch.float32)
     wp[:cout, :cin] = w.float() * w_scale
     w1 = wp.to(torch.float16)
-    # [cot, BM, cc, half, k8, kd, r, s] -> [cot, cc, kd, r, s, half, BM, k8]
-    w1 = w1.view(n_cot, bm, n_cc, 2, 8, kd, kh, kw).permute(0, 2, 5, 6, 7, 3, 1, 4).contiguous()
+    # [cot, BM, cc, kblk, half, k8, kd, r, s] -> [cot, cc, kd, r, kblk, s, half, BM, k8]
+    w1 = w1.view(n_cot, bm, n_cc, 2, 2, 8, kd, kh, kw).permute(0, 2, 6, 7, 3, 8, 4, 1, 5).contiguous()
     return w1.view(-1), w_scale
 
 
 F16_W8 = __import__("os").environ.get("EMO_F16_W8", "1") != "0"   # A/B switch: 0 keeps every fp16-operand layer on conv_igemm_f16.h
+F16_W8_ODD = __import__("os").environ.get("EMO_F16_W8_ODD", "0") == "1"   # A/B switch: 1 also plans odd channel-tile counts onto it
 
 
 def f16w8_launch_fits(cout, cin, kd, kh, kw, Hl, Wl, n_pos_tiles, act="none", positions_per_sample=0):
     """the one launch form of emo_conv_igemm_f16w8 (conv_f16x2_w8_launch<.., NPROD = 1> -- every check of the C launcher has its
     mirror here): 3x3 / 3x3x3, whole 64-channel tiles and 8-channel groups, 4 x 64 position tiles, no activation, at most 2^23
-    positions per sample, two pair items per CU (an odd last channel tile counts as a pair)"""
+    positions per sample, two pair items per CU.  And -- a choice of the planner, not a limit of the kernel -- an EVEN number of
+    channel tiles: the kernel runs an odd last tile in a half-empty pair, which costs a whole pair's staging (measured 0.79-0.87x
+    the older kernel on the 192- and 320-channel layers, 1.14-1.16x on the even ones: tools/session/r6_call3.sh)"""
     if not F16_W8 or (kh, kw) != (3, 3) or kd not in (1, 3) or cout % BF16X3_BM or cin % 8 or act != "none":
+        return False
+    if cout % (2 * BF16X3_BM) and not F16_W8_ODD:
         return False
     if Hl is None or Wl % 64 or Hl % 4 or positions_per_sample > (1 << 23):
         return False

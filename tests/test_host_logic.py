@@ -248,10 +248,12 @@ def test_fp16_plan_falls_back_to_fp32_where_the_fp16_kernel_cannot_run():
     assert pack.PackedConv("f", torch.zeros(64, 64, 3, 3), None, "cpu").plan_for(32, 64, 64)[2] == "f32"
     # round 6: in the decoders' launch form (3x3, whole 64-channel tiles, 4 x 64 position tiles, no activation, aligned out / res,
     # two pair items per CU) the layer runs the eight-wave two-tile kernel with plain fp16 operands; every other form as before
-    big = 1 << 14                                                    # 128-position tiles: 8192 pair items of one channel tile
-    assert lay.plan_for(big, 512, 512) == (pack.CFG_D, 1, "f16w8")
-    assert lay.plan_for(big, 512, 512, act="tanh")[2] == "f16" and lay.plan_for(big, 512, 512, io_aligned16=False)[2] == "f16"
-    assert lay.plan_for(big, 32, 32)[2] == "f16"                     # 8 x 32 position tiles: the older kernel
+    big = 1 << 14                                                    # 128-position tiles: 8192 pair items per channel-tile pair
+    two = pack.PackedConv("p2", torch.zeros(128, 64, 3, 3), None, "cpu", precision="f16")
+    assert two.plan_for(big, 512, 512) == (pack.CFG_D, 1, "f16w8")
+    assert two.plan_for(big, 512, 512, act="tanh")[2] == "f16" and two.plan_for(big, 512, 512, io_aligned16=False)[2] == "f16"
+    assert two.plan_for(big, 32, 32)[2] == "f16"                     # 8 x 32 position tiles: the older kernel
+    assert lay.plan_for(big, 512, 512)[2] == "f16"                   # an odd number of channel tiles (one): the older kernel
     assert pack.PackedConv("c", torch.zeros(96, 64, 3, 3), None, "cpu", precision="f16").plan_for(big, 512, 512)[2] == "f16"
     flat, ws = pack.pack_weight_f16w8(torch.randn(70, 24, 3, 3))
     assert flat.dtype == torch.float16 and flat.numel() == 2 * 2 * 9 * 2 * 64 * 8 and ws == 2.0 ** math.floor(math.log2(ws))
