@@ -31,6 +31,7 @@
 // sets): the two are BIT-IDENTICAL (tests/test_conv_bf16x3_gpu.py).
 #pragma once
 #include "conv_igemm_bf16x3.h"
+#include "conv_split_pair_common.h"
 
 #ifndef EMO_CT2_RES_EARLY
 #define EMO_CT2_RES_EARLY 0   /* 1: the first tile's residual loads go out in front of the K loop instead of at the top of the epilogue.
@@ -115,55 +116,13 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
   unsigned lq_off = 0;
   bool lq_ok = false;
   int lq_z0 = 0;
-// (every result through readfirstlane: conv_igemm_bf16x3.h; n_cotiles counts PAIRS here, cot0 is the first tile of the launch)
-#define EMO_T_DECODE(P_, L_)                                                                          \
-  {                                                                                                   \
-    const int l_ = (L_);                                                                              \
-    const int cot_ = l_ % a.n_cotiles;                                                                \
-    const int rest_ = l_ / a.n_cotiles;                                                               \
-    const int n_ = rest_ / nptiles;                                                                   \
-    int bx_ = rest_ - n_ * nptiles;                                                                   \
-    P_##ptile = __builtin_amdgcn_readfirstlane(bx_);                                                  \
-    const int tx_ = bx_ % a.tiles_x; bx_ /= a.tiles_x;                                                \
-    const int ty_ = bx_ % a.tiles_y; bx_ /= a.tiles_y;                                                \
-    P_##cotile = __builtin_amdgcn_readfirstlane(a.cot0 + 2 * cot_);                                   \
-    P_##n = __builtin_amdgcn_readfirstlane(n_);                                                       \
-    P_##x0 = __builtin_amdgcn_readfirstlane(tx_ * TW);                                                \
-    P_##y0 = __builtin_amdgcn_readfirstlane(ty_ * TR);                                                \
-    P_##z0 = __builtin_amdgcn_readfirstlane(bx_);                                                     \
-  }
 // byte address of the packed kernel rows of (channel tile c_, stage k_)
 #define EMO_T_WPTR(c_, k_) (reinterpret_cast<const char*>(a.wpk) + (long)((c_) * nst + (k_)) * (3 * Cfg::WROW_BYTES))
-#define EMO_T_CURSOR_OF(P_, ok_, off_)                                                                \
-  {                                                                                                   \
-    const int x0s_ = UPS ? P_##x0 >> 1 : P_##x0, y0s_ = UPS ? P_##y0 >> 1 : P_##y0;                   \
-    const int q_y_ = y0s_ - 1 + q_r;                                                                  \
-    const int q_x_ = is_quad ? x0s_ + 4 * q_c : (h_side ? x0s_ + TWS : x0s_ - 4);                     \
-    ok_ = (is_quad || is_halo) && (unsigned)q_y_ < (unsigned)a.H && q_x_ >= 0 && q_x_ < a.W;          \
-    off_ = ok_ ? (unsigned)(q_y_ * a.W + q_x_) * 4u : 0u;                                             \
-  }
 
   // LDS byte offsets of the lane's operands (conv_igemm_bf16x3.h); the patch buffer of a stage is a RUN-TIME parity here (two
   // half-stages per stage make the unrolled pair of loop bodies the two channel tiles, not two stages): + pcur_b / pnxt_b
   const int a_off = (half * BM + l32) * 16;
-  constexpr int NBR = UPS ? 2 : 1;
-  int b_off[TP][NBR][3];
-#pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int p = p0 + j * 32 + l32;
-    const int col = p % TW, row = p / TW;
-#pragma unroll
-    for (int r = 0; r < NBR; ++r)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int pr = UPS ? ((row + r - 1 + 2) >> 1) - 1 + 1 : row + r;
-        const int pc = UPS ? ((col + s - 1 + 2) >> 1) - 1 : col + s - 1;
-        const int slot = pc < 0 ? pr * NQ1 + NQ : (pc >= TWS ? SUB + pr * NQ1 + NQ : (pc & 3) * SUB + pr * NQ1 + (pc >> 2));
-        b_off[j][r][s] = (half * CHS + slot) * 16;
-      }
-  }
-#define EMO_T_B_OFF(j_, r_, s_) (UPS ? ((r_) == 2 ? b_off[j_][0][s_] + NQ1 * 16 : b_off[j_][(r_) < NBR ? (r_) : 0][s_]) \
-                                     : b_off[j_][0][s_] + (r_) * NQ1 * 16)
+  EMO_P_DECLARE_B_OFF()
 
   const char* const lds_c = reinterpret_cast<const char*>(smem);
   char* const lds_w = reinterpret_cast<char*>(smem);
@@ -174,7 +133,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
       fa_[set_][pl_][i] = *reinterpret_cast<const opx8*>(lds_c + a_off + ((wbase_) + (pl_) * WPLANE + (s_) * 2 * BM + i * 32) * 16); \
     _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                    \
-      fb_[set_][pl_][j] = *reinterpret_cast<const opx8*>(lds_c + (EMO_T_B_OFF(j, r_, s_) + (pbyte_)) + ((pl_) * PPL) * 16); \
+      fb_[set_][pl_][j] = *reinterpret_cast<const opx8*>(lds_c + (EMO_P_B_OFF(j, r_, s_) + (pbyte_)) + ((pl_) * PPL) * 16); \
   }
 
   float* const sct = smem + Cfg::OFF_SCT * 4;
@@ -245,8 +204,6 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     emo_dma16_pinned_s((ptr_) + (row_ * Cfg::WROW_BYTES + j_ * 1024), lane16,                         \
                        smem_lds + (unsigned)((Cfg::OFF_W + (wb_) * Cfg::WSTAGE) * 16 + row_ * Cfg::WROW_BYTES + j_ * 1024)); \
   }
-#define EMO_T_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
-#define EMO_T_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
 
   // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
   constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
@@ -261,14 +218,14 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
   for (int k = 0; k < 12; ++k) tstamp[k] = 0;
 #endif
   EMO_S_STAMP(0)
-  EMO_T_DECODE(it_, l_base + idx8)
+  EMO_P_DECODE(it_, l_base + idx8)
   int nx_cotile = 0, nx_n = 0, nx_ptile = 0, nx_x0 = 0, nx_y0 = 0, nx_z0 = 0;
   bool chain_out = false, nxq_ok = false;
   unsigned nxq_off = 0;
   if (EMO_S_CHAIN && idx8 + l_stride < n_mine) {
-    EMO_T_DECODE(nx_, l_base + idx8 + l_stride)
+    EMO_P_DECODE(nx_, l_base + idx8 + l_stride)
     chain_out = nx_n == it_n && nst >= 2;
-    EMO_T_CURSOR_OF(nx_, nxq_ok, nxq_off)
+    EMO_P_CURSOR_OF(nx_, nxq_ok, nxq_off)
   }
   (void)nx_ptile;
   // (declared dead here: conv_igemm_bf16x3.h)
@@ -294,13 +251,13 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     const char* const w1_ = EMO_T_WPTR(it_cotile + 1, 0);
     EMO_T_DMA_PIECE(w1_, 1, 0)
     EMO_T_DMA_PIECE(w1_, 1, 1)
-    EMO_T_BARRIER(2);
+    EMO_P_BARRIER(2);
   } else {
     // ---- full prologue: tables, the nine pieces of (c0, stage 0), the patch of stage 0 converted into P[0], the loads of stage 1 ----
 #pragma unroll
     for (int u = 0; u < 8; ++u) asm volatile("" : "=v"(qv[u]));
     xrs = emo_raw_buffer(a.x + (long)it_n * a.Cin * DHW);
-    EMO_T_CURSOR_OF(it_, lq_ok, lq_off)
+    EMO_P_CURSOR_OF(it_, lq_ok, lq_off)
     lq_z0 = it_z0;
 #pragma unroll
     for (int k = 0; k < NTE; ++k) {
@@ -334,7 +291,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
       const int t2_ = tid & (BM - 1);
       smem[(tid < BM ? Cfg::OFF_BIAS_F : Cfg::OFF_BIAS2_F) + (t2_ >> 5) * 32 + (t2_ & 3) * 8 + ((t2_ & 31) >> 2)] = te_b;
     }
-    EMO_T_WAIT(0);
+    EMO_P_WAIT(0);
     EMO_T_TOUCH_QUAD()
     __syncthreads();   // scale / shift tables visible
 #pragma unroll
@@ -357,7 +314,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
       EMO_T_DMA_PIECE(w1_, 1, 0)
       EMO_T_DMA_PIECE(w1_, 1, 1)
     }
-    EMO_T_BARRIER(0);                    // (P[0] visible, W[0] and the loads of stage 1 landed)
+    EMO_P_BARRIER(0);                    // (P[0] visible, W[0] and the loads of stage 1 landed)
     EMO_T_TOUCH_QUAD()
     pp = 0;
   }
@@ -404,7 +361,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
         const int r = gs / 3, s = gs % 3;
         const int fcur = (h * 9 + gs) & 1, fnxt = fcur ^ 1;
         (void)r; (void)s;
-        if (gs == 8) { EMO_T_BARRIER(0); }
+        if (gs == 8) { EMO_P_BARRIER(0); }
         if (gs == 8 && h == 1) EMO_T_TOUCH_QUAD()          // (the loads of stage cg + 2 have landed behind the barrier)
         if (gs == 0 && h == 1) {
           // the patch loads of stage cg + 2; past the item's end: the next item's stages 0 / 1 (chained), a dead re-stage otherwise
@@ -484,7 +441,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     // ---- epilogue, once per channel tile of the pair; the transposition scratch is W[1] ----
     float* const scratch = smem + (Cfg::OFF_W + Cfg::WSTAGE) * 4 + wave * Cfg::EPI_WAVE;
     const int ep_n = it_n, ep_cotile = it_cotile, ep_ptile = it_ptile, ep_x0 = it_x0, ep_y0 = it_y0, ep_z0 = it_z0;
-    EMO_T_WAIT(0);
+    EMO_P_WAIT(0);
     EMO_S_STAMP(5)
     __syncthreads();
     EMO_S_STAMP(6)
@@ -540,27 +497,10 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
   // tile statistics, second half (conv_epilogue_rows_stats, for both tiles at once and behind the barrier above instead of one of
   // their own each): thread c of the first 128 combines the four waves' (mean, M2) of channel c with the equal-count update.
   // The exchange areas are next written by the NEXT item's epilogue, a K loop away
-  if (a.gn_stats != nullptr && tid < 2 * BM) {
-    const int c_ = tid & (BM - 1);
-    const float* const st_ = smem + (tid < BM ? Cfg::OFF_STAT_F : Cfg::OFF_STAT2_F);
-    float mean = 0.0f, m2 = 0.0f;
-#pragma unroll
-    for (int w = 0; w < WGP; ++w) mean += st_[(w * BM + c_) * 2 + 0];
-    mean *= 1.0f / (float)WGP;
-#pragma unroll
-    for (int w = 0; w < WGP; ++w) {
-      const float d = st_[(w * BM + c_) * 2 + 0] - mean;
-      m2 += st_[(w * BM + c_) * 2 + 1] + (float)(TP * 32) * d * d;
-    }
-    float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)it_n * nptiles + it_ptile) * a.Cout + it_cotile * BM + tid;
-    *dst = make_float2(mean, m2);
-  }
+  EMO_P_COMBINE_STATS(Cfg::OFF_STAT_F, Cfg::OFF_STAT2_F, true)
   chained_in = chain_out;
   }
-#undef EMO_T_DECODE
 #undef EMO_T_WPTR
-#undef EMO_T_CURSOR_OF
-#undef EMO_T_B_OFF
 #undef EMO_T_LOAD_FRAGS_PLANE
 #undef EMO_T_SET_STAGE_VARS
 #undef EMO_T_ISSUE_BEGIN
@@ -569,8 +509,6 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
 #undef EMO_T_TOUCH_QUAD
 #undef EMO_T_CONV_HALF
 #undef EMO_T_DMA_PIECE
-#undef EMO_T_WAIT
-#undef EMO_T_BARRIER
 }
 
 // Launches the channel-tile PAIRS of the layer on conv_igemm_bf16x3_ct2_kernel when that fills the chip; *rest_cot0 = the first
@@ -610,7 +548,7 @@ int conv_f16x2_ct2_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   a.stages_per_split = a.n_cchunks * a.KD;
   a.partial = nullptr;
   a.cot0 = 0;
-  a.n_cotiles = pairs;                         // (pairs: EMO_T_DECODE)
+  a.n_cotiles = pairs;                         // (pairs: EMO_P_DECODE)
   a.n_work = (int)(nt * pairs * a.N);
   const int grid = a.n_work > ncu ? ncu : a.n_work;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)Cfg::LDS_BYTES, s, a);

@@ -29,6 +29,7 @@
 // one-wave-per-SIMD kernel (A/B).
 #pragma once
 #include "conv_igemm_bf16x3.h"
+#include "conv_split_pair_common.h"
 
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
@@ -269,56 +270,14 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   unsigned lq_off = 0;
   bool lq_ok = false;
   int lq_z0 = 0;
-// (every result through readfirstlane: conv_igemm_bf16x3.h; n_cotiles counts PAIRS here, cot0 is the first tile of the launch)
-#define EMO_W_DECODE(P_, L_)                                                                          \
-  {                                                                                                   \
-    const int l_ = (L_);                                                                              \
-    const int cot_ = l_ % a.n_cotiles;                                                                \
-    const int rest_ = l_ / a.n_cotiles;                                                               \
-    const int n_ = rest_ / nptiles;                                                                   \
-    int bx_ = rest_ - n_ * nptiles;                                                                   \
-    P_##ptile = __builtin_amdgcn_readfirstlane(bx_);                                                  \
-    const int tx_ = bx_ % a.tiles_x; bx_ /= a.tiles_x;                                                \
-    const int ty_ = bx_ % a.tiles_y; bx_ /= a.tiles_y;                                                \
-    P_##cotile = __builtin_amdgcn_readfirstlane(a.cot0 + 2 * cot_);                                   \
-    P_##n = __builtin_amdgcn_readfirstlane(n_);                                                       \
-    P_##x0 = __builtin_amdgcn_readfirstlane(tx_ * TW);                                                \
-    P_##y0 = __builtin_amdgcn_readfirstlane(ty_ * TR);                                                \
-    P_##z0 = __builtin_amdgcn_readfirstlane(bx_);                                                     \
-  }
 // byte address of the packed kernel rows of (channel tile c_, stage k_): NCHK contiguous chunks of 1 KiB (a tile past the layer's
 // last one -- the second half of an odd last pair -- reads the last tile's)
 #define EMO_W_WPTR(c_, k_) (reinterpret_cast<const char*>(a.wpk) + \
                             (long)(((c_) < n_cot_all ? (c_) : n_cot_all - 1) * nst + (k_)) * (NCHK * 1024))
-#define EMO_W_CURSOR_OF(P_, ok_, off_)                                                                \
-  {                                                                                                   \
-    const int x0s_ = UPS ? P_##x0 >> 1 : P_##x0, y0s_ = UPS ? P_##y0 >> 1 : P_##y0;                   \
-    const int q_y_ = y0s_ - 1 + q_r;                                                                  \
-    const int q_x_ = is_quad ? x0s_ + 4 * q_c : (h_side ? x0s_ + TWS : x0s_ - 4);                     \
-    ok_ = (is_quad || is_halo) && (unsigned)q_y_ < (unsigned)a.H && q_x_ >= 0 && q_x_ < a.W;          \
-    off_ = ok_ ? (unsigned)(q_y_ * a.W + q_x_) * 4u : 0u;                                             \
-  }
 
   // LDS byte offsets of the lane's operands (conv_igemm_f16x2_ct2.h): the wave's weight rows are ch * 32 + l32 of the tile's 64
   const int a_off = (half * BM + ch * 32 + l32) * 16;
-  constexpr int NBR = UPS ? 2 : 1;
-  int b_off[TP][NBR][3];
-#pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int p = p0 + j * 32 + l32;
-    const int col = p % TW, row = p / TW;
-#pragma unroll
-    for (int r = 0; r < NBR; ++r)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int pr = UPS ? ((row + r - 1 + 2) >> 1) - 1 + 1 : row + r;
-        const int pc = UPS ? ((col + s - 1 + 2) >> 1) - 1 : col + s - 1;
-        const int slot = pc < 0 ? pr * NQ1 + NQ : (pc >= TWS ? SUB + pr * NQ1 + NQ : (pc & 3) * SUB + pr * NQ1 + (pc >> 2));
-        b_off[j][r][s] = (half * CHS + slot) * 16;
-      }
-  }
-#define EMO_W_B_OFF(j_, r_, s_) (UPS ? ((r_) == 2 ? b_off[j_][0][s_] + NQ1 * 16 : b_off[j_][(r_) < NBR ? (r_) : 0][s_]) \
-                                     : b_off[j_][0][s_] + (r_) * NQ1 * 16)
+  EMO_P_DECLARE_B_OFF()
 
   const char* const lds_c = reinterpret_cast<const char*>(smem);
   char* const lds_w = reinterpret_cast<char*>(smem);
@@ -329,7 +288,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   {                                                                                                   \
     fa_[set_][pl_] = *reinterpret_cast<const opx8*>(lds_c + a_off + ((wbase_) + (pl_) * WPLANE + (s_) * 2 * BM) * 16); \
     _Pragma("unroll") for (int j = 0; j < TP; ++j)                                                    \
-      fb_[set_][pl_][j] = *reinterpret_cast<const opx8*>(lds_c + (EMO_W_B_OFF(j, r_, s_) + (pbyte_)) + ((pl_) * PPL) * 16); \
+      fb_[set_][pl_][j] = *reinterpret_cast<const opx8*>(lds_c + (EMO_P_B_OFF(j, r_, s_) + (pbyte_)) + ((pl_) * PPL) * 16); \
   }
 
   float* const sct = smem + Cfg::OFF_SCT * 4;
@@ -413,8 +372,6 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     emo_dma16_pinned_s((ptr_) + c_ * 1024, lane16, (dst_) + (unsigned)(c_ * 1024));                   \
   }
 #define EMO_W_WBUF(wb_) (smem_lds + (unsigned)((Cfg::OFF_W + (wb_) * Cfg::WSTAGE) * 16))
-#define EMO_W_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
-#define EMO_W_BARRIER(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
 
   // the partial products, smallest first: (weight plane, patch plane); the last one is the leading product
   // (NPROD = 1: "products" = the two k-blocks of a stage, weight block x patch block, both into the one accumulator set)
@@ -434,14 +391,14 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   for (int k = 0; k < 12; ++k) tstamp[k] = 0;
 #endif
   EMO_S_STAMP(0)
-  EMO_W_DECODE(it_, l_base + idx8)
+  EMO_P_DECODE(it_, l_base + idx8)
   int nx_cotile = 0, nx_n = 0, nx_ptile = 0, nx_x0 = 0, nx_y0 = 0, nx_z0 = 0;
   bool chain_out = false, nxq_ok = false;
   unsigned nxq_off = 0;
   if (EMO_S_CHAIN && idx8 + l_stride < n_mine) {
-    EMO_W_DECODE(nx_, l_base + idx8 + l_stride)
+    EMO_P_DECODE(nx_, l_base + idx8 + l_stride)
     chain_out = nx_n == it_n && nst >= 2;
-    EMO_W_CURSOR_OF(nx_, nxq_ok, nxq_off)
+    EMO_P_CURSOR_OF(nx_, nxq_ok, nxq_off)
   }
   (void)nx_ptile;
   // (declared dead here: conv_igemm_bf16x3.h)
@@ -453,6 +410,11 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < TP; ++j) asm volatile("" : "=v"(fb_[st_][pl][j]));
     }
+  // (the scale / shift entries of the patch under conversion are NOT carried from item to item: a chained item reads them again --
+  // two LDS reads -- instead of holding 8 / 16 registers through the epilogue, where the plain-fp16 build spilled landed residual
+  // values to scratch behind a vmcnt(0) each: epilogue 28 k cycles per item against 11.5 k, profiles/r6_conv_phase_timing_f16w8_first.jsonl)
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) { asm volatile("" : "=v"(q_sc[kb])); asm volatile("" : "=v"(q_sh[kb])); }
   if (EMO_S_CHAIN && chained_in) {
     // P[pp] holds the converted patch of stage 0, W[0] the kernel rows of (c0, stage 0), qv the landed loads of stage 1, q_sc /
     // q_sh its table entries; the tables are the sample's.  What is left: bias entries, the first chunk of (c0 + 1, 0)
@@ -463,7 +425,8 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     }
     const char* const w1_ = EMO_W_WPTR(it_cotile + 1, 0);
     EMO_W_DMA_CHUNK(w1_, EMO_W_WBUF(1), 0)
-    EMO_W_BARRIER(1);
+    EMO_W_TABLE()
+    EMO_P_BARRIER(1);
   } else {
     // ---- full prologue: tables, the chunks of (c0, stage 0), the patch of stage 0 converted into P[0], the loads of stage 1 ----
 #pragma unroll
@@ -471,7 +434,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) asm volatile("" : "=v"(qv[kb][u]));
     xrs = emo_raw_buffer(a.x + (long)it_n * a.Cin * DHW);
-    EMO_W_CURSOR_OF(it_, lq_ok, lq_off)
+    EMO_P_CURSOR_OF(it_, lq_ok, lq_off)
     lq_z0 = it_z0;
 #pragma unroll
     for (int k = 0; k < NTE; ++k) {
@@ -506,7 +469,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
       const int t2_ = tid & (BM - 1);
       smem[(tid < BM ? Cfg::OFF_BIAS_F : Cfg::OFF_BIAS2_F) + EMO_W_BIAS_SLOT(t2_)] = te_b;
     }
-    EMO_W_WAIT(0);
+    EMO_P_WAIT(0);
     EMO_W_TOUCH_QUAD()
     __syncthreads();   // scale / shift tables visible
     EMO_W_TABLE()
@@ -527,7 +490,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
       const char* const w1_ = EMO_W_WPTR(it_cotile + 1, 0);
       EMO_W_DMA_CHUNK(w1_, EMO_W_WBUF(1), 0)
     }
-    EMO_W_BARRIER(0);                    // (P[0] visible, W[0] and the loads of stage 1 landed)
+    EMO_P_BARRIER(0);                    // (P[0] visible, W[0] and the loads of stage 1 landed)
     EMO_W_TOUCH_QUAD()
     pp = 0;
   }
@@ -562,7 +525,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #pragma unroll
       for (int gs = 0; gs < 9; ++gs) {
         const int fcur = (h * 9 + gs) & 1, fnxt = fcur ^ 1;
-        if (gs == 8) { EMO_W_BARRIER(0); }
+        if (gs == 8) { EMO_P_BARRIER(0); }
         if (gs == 8 && h == 1) EMO_W_TOUCH_QUAD()          // (the loads of stage cg + 2 have landed behind the barrier)
         if (gs == 0 && h == 1) {
           // the patch loads of stage cg + 2; past the item's end: the next item's stages 0 / 1 (chained), a dead re-stage otherwise
@@ -651,7 +614,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
     float* const scratch = smem + (Cfg::OFF_W + Cfg::WSTAGE) * 4 + wave * Cfg::EPI_WAVE8;
     const int ep_n = it_n, ep_cot32 = 2 * it_cotile + ch, ep_x0 = it_x0, ep_y0 = it_y0, ep_z0 = it_z0;
     const bool has_t1 = NPROD == 3 || it_cotile + 1 < n_cot_all;      // (false: the half-empty last pair of an odd tile count)
-    EMO_W_WAIT(0);
+    EMO_P_WAIT(0);
     EMO_S_STAMP(5)
     __syncthreads();
     EMO_S_STAMP(6)
@@ -666,14 +629,20 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
       conv_w8_res_issue<TW, RES_, 0>(a, rv_[0], ep_n, ep_cot32, ep_x0, ep_y0, ep_z0, wp, lane);                                    \
       conv_w8_res_issue<TW, RES_, 1>(a, rv_[1], ep_n, ep_cot32, ep_x0, ep_y0, ep_z0, wp, lane);                                    \
       EMO_S_STAMP(7)                                                                                                               \
-      conv_w8_epilogue_tile<TW, BM, Cfg::EPI_ROWF8, RES_, true, NPROD == 3>(                                                       \
+      conv_w8_epilogue_tile<TW, BM, Cfg::EPI_ROWF8, RES_, NPROD == 3, NPROD == 3>(                                                 \
           a, acc_lo[0], acc_hi[0], rv_, rvn_, scratch, smem + Cfg::OFF_BIAS_F + ch * 32, smem + Cfg::OFF_STAT_F, ep_n, ep_cot32,    \
           ep_x0, ep_y0, ep_z0, wp, ch, half, l32, lane, has_t1);                                                                   \
       EMO_S_STAMP(8)                                                                                                               \
-      if (has_t1)                                                                                                                  \
+      if (has_t1) {                                                                                                                \
+        /* (plain fp16 operands: more raw patch registers live across the epilogue -- the second tile's residual goes out here) */ \
+        if constexpr (NPROD == 1) {                                                                                                \
+          conv_w8_res_issue<TW, RES_, 0>(a, rvn_[0], ep_n, ep_cot32 + 2, ep_x0, ep_y0, ep_z0, wp, lane);                           \
+          conv_w8_res_issue<TW, RES_, 1>(a, rvn_[1], ep_n, ep_cot32 + 2, ep_x0, ep_y0, ep_z0, wp, lane);                           \
+        }                                                                                                                          \
         conv_w8_epilogue_tile<TW, BM, Cfg::EPI_ROWF8, RES_, false, NPROD == 3>(                                                    \
             a, acc_lo[1], acc_hi[1], rvn_, rv_, scratch, smem + Cfg::OFF_BIAS2_F + ch * 32, smem + Cfg::OFF_STAT2_F, ep_n,          \
             ep_cot32 + 2, ep_x0, ep_y0, ep_z0, wp, ch, half, l32, lane, false);                                                    \
+      }                                                                                                                            \
       EMO_S_STAMP(9)                                                                                                               \
     }
     if (epi_mode == 1) EMO_W_EPI(1)
@@ -702,27 +671,10 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   __syncthreads();
   // tile statistics, second half (conv_igemm_f16x2_ct2.h): thread c of the first 128 combines the four position groups' (mean, M2)
   // of channel c with the equal-count update
-  if (a.gn_stats != nullptr && tid < 2 * BM && it_cotile * BM + tid < a.Cout) {
-    const int c_ = tid & (BM - 1);
-    const float* const st_ = smem + (tid < BM ? Cfg::OFF_STAT_F : Cfg::OFF_STAT2_F);
-    float mean = 0.0f, m2 = 0.0f;
-#pragma unroll
-    for (int w = 0; w < WGP; ++w) mean += st_[(w * BM + c_) * 2 + 0];
-    mean *= 1.0f / (float)WGP;
-#pragma unroll
-    for (int w = 0; w < WGP; ++w) {
-      const float d = st_[(w * BM + c_) * 2 + 0] - mean;
-      m2 += st_[(w * BM + c_) * 2 + 1] + (float)(TP * 32) * d * d;
-    }
-    float2* dst = reinterpret_cast<float2*>(a.gn_stats) + ((long)it_n * nptiles + it_ptile) * a.Cout + it_cotile * BM + tid;
-    *dst = make_float2(mean, m2);
-  }
+  EMO_P_COMBINE_STATS(Cfg::OFF_STAT_F, Cfg::OFF_STAT2_F, it_cotile * BM + tid < a.Cout)
   chained_in = chain_out;
   }
-#undef EMO_W_DECODE
 #undef EMO_W_WPTR
-#undef EMO_W_CURSOR_OF
-#undef EMO_W_B_OFF
 #undef EMO_W_LOAD_FRAGS_PLANE
 #undef EMO_W_SET_STAGE_VARS
 #undef EMO_W_ISSUE_BEGIN
@@ -733,8 +685,6 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #undef EMO_W_CHUNK_OF
 #undef EMO_W_DMA_CHUNK
 #undef EMO_W_WBUF
-#undef EMO_W_WAIT
-#undef EMO_W_BARRIER
 #undef EMO_W_BIAS_SLOT
 }
 
@@ -778,7 +728,7 @@ int conv_f16x2_w8_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   a.stages_per_split = a.n_cchunks * a.KD;
   a.partial = nullptr;
   a.cot0 = 0;
-  a.n_cotiles = pairs;                         // (pairs: EMO_W_DECODE)
+  a.n_cotiles = pairs;                         // (pairs: EMO_P_DECODE)
   a.n_work = (int)(nt * pairs * a.N);
   const int grid = a.n_work > ncu ? ncu : a.n_work;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NTH), (size_t)Cfg::LDS_BYTES, s, a);

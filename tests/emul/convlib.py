@@ -28,7 +28,8 @@ GEN = os.path.join(HERE, "_build", "gen_convlib")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 PRODUCT_LIB = os.path.join(ROOT, "emoportraits_amd", "lib", "libemoportraits_hip.so")
 
-HEADERS = ["conv_igemm.h", "conv_igemm_f16.h", "conv_igemm_bf16x3.h", "conv_igemm_f16x2_ct2.h", "conv_igemm_f16x2_w8.h", "conv_igemm_f16x2_p1.h",
+HEADERS = ["conv_igemm.h", "conv_igemm_f16.h", "conv_igemm_bf16x3.h", "conv_split_pair_common.h", "conv_igemm_f16x2_ct2.h", "conv_igemm_f16x2_w8.h",
+           "conv_igemm_f16x2_p1.h",
            "conv_dispatch.h"]
 UNITS = ["conv_api.hip"] + sorted(f for f in os.listdir(CSRC) if f.startswith("conv_inst_") and f.endswith(".hip"))
 

@@ -91,6 +91,9 @@ def main():
     for cin, cout, dims, ups in shapes:
         x = torch.randn(B, cin, *dims, device=DEV)
         w = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
+        if "--zeros" in sys.argv:                                # all-zero operands: the schedule without the power limit
+            x.zero_()
+            w.zero_()
         scale = torch.rand(B, cin, device=DEV) + 0.5
         shift = torch.randn(B, cin, device=DEV) * 0.1
         odims = tuple(d * 2 for d in dims) if ups else dims
@@ -100,16 +103,17 @@ def main():
         # epilogue stamps 8 / 9 are the first / second tile's; f16x2: the single-tile kernel alone (EMO_CONV_CT2=0)
         # w8: the two-tile kernel with two waves per SIMD (conv_igemm_f16x2_w8.h); its stamps are those of ct2 (7: first tile's
         # residual loads issued, 8 / 9: first / second tile written)
-        modes = (("bf16x3", "bf16x3"), ("f16x2", "f16x2"), ("ct2", "f16x2"), ("w8", "f16x2"))
+        # f16w8: the same kernel with plain fp16 operands (NPROD = 1, 32-channel stages: precision 'f16' in the decoders' launch form)
+        modes = (("bf16x3", "bf16x3"), ("f16x2", "f16x2"), ("ct2", "f16x2"), ("w8", "f16x2"), ("f16w8", "f16"))
         if "--modes" in sys.argv:
             want = sys.argv[sys.argv.index("--modes") + 1].split(",")
             modes = tuple(m for m in modes if m[0] in want)
         for mode, prec in modes:
-            if mode in ("ct2", "w8") and (cout // 64) < 2:
+            if mode in ("ct2", "w8", "f16w8") and ((cout // 64) < 2 or (mode == "f16w8" and (cout // 64) % 2)):
                 continue
             os.environ["EMO_CONV_CT2"] = "1" if mode in ("ct2", "w8") else "0"
             os.environ["EMO_CONV_W8"] = "1" if mode == "w8" else "0"
-            n_items = B * (math.prod(odims) // 256) * (cout // 128) if mode in ("ct2", "w8") else n_tiles
+            n_items = B * (math.prod(odims) // 256) * (cout // 128) if mode in ("ct2", "w8", "f16w8") else n_tiles
             layer = pack.PackedConv("t", w, None, DEV, precision=prec)
             gn = None
             real = "--real" in sys.argv          # as the decoder launches it: residual + GroupNorm tile statistics
@@ -129,9 +133,9 @@ def main():
             torch.cuda.synchronize()
             ms = a.elapsed_time(b)
             rec = dict(B=B, cin=cin, cout=cout, dims=dims, ups=ups, mode=mode, real=real, residual=with_res, statistics=with_stats, stagger=os.environ.get("EMO_CONV_STAGGER", "0"),
-                       ms=round(ms, 3), tflops=round(flops / ms / 1e9, 1), tiles_per_item=2 if mode in ("ct2", "w8") else 1,
-                       stages=(-(-cin // 16)))
-            full = stamps(lib, mode, 65536)
+                       ms=round(ms, 3), tflops=round(flops / ms / 1e9, 1), tiles_per_item=2 if mode in ("ct2", "w8", "f16w8") else 1,
+                       stages=(-(-cin // (32 if mode == "f16w8" else 16))))
+            full = stamps(lib, "w8" if mode == "f16w8" else mode, 65536)
             rec.update(analyse(full[:min(n_items, 65536)]))
             waves = analyse_waves(full, n_items)
             if waves is not None:

@@ -5,7 +5,7 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ("conv_igemm.h", "conv_igemm_f16.h", "conv_igemm_bf16x3.h", "conv_igemm_f16x2_ct2.h", "conv_igemm_f16x2_w8.h", "conv_igemm_f16x2_p1.h",
+FILES = ("conv_igemm.h", "conv_igemm_f16.h", "conv_igemm_bf16x3.h", "conv_split_pair_common.h", "conv_igemm_f16x2_ct2.h", "conv_igemm_f16x2_w8.h", "conv_igemm_f16x2_p1.h",
          "conv_api.hip")
 
 
