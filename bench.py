@@ -794,9 +794,12 @@ def main():
     # host cores of every rank (parallel.pin_to_local_cores: next to the rank's GPU), for the record
     affinity = [parallel.affinity_record()]
     if world > 1:
-        gathered = [None] * world
-        torch.distributed.all_gather_object(gathered, affinity[0])
-        affinity = gathered
+        try:
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, affinity[0])
+            affinity = gathered
+        except Exception as e:                                    # a record, never a reason to lose the line
+            affinity = [affinity[0], f"all_gather_object failed: {e!r}"]
     if rank != 0:
         return
     sustained = None
@@ -821,32 +824,41 @@ def main():
 
     def conv_roofline(k):
         ms, fl, n = by_k[k]
-        if k == "head_stream":
-            gbps = conv_meter.stream_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"bound": "hbm", "kernel": "conv_head_kernel<3> (the image head 128 -> 3, 1x1, GroupNorm affine + ReLU on the way in, "
-                                              "sigmoid on the way out, as a stream: no LDS, fp32 FMAs)",
-                    "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                    "traffic": None, "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
-                    "share_of_step": round(ms / (elapsed_metered * 1e3), 3),
-                    "note": "achieved = 4 bytes x (Cin + Cout) x positions / event time"}
-        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM traffic per launch: a PMC figure of this command from separate rocprofv3 --pmc passes (it cannot be measured inside
-        # the run).  Only a profile taken on THESE kernel sources is quoted: the file records the hash of the conv kernel headers
-        # (tools/kernel_source_hash.py); with another hash -- or none: profiles of earlier rounds -- the field is null
-        pmc, pmc_path, stale = None, "", None
-        pat = {"bf16x3": "r*_pmc_conv_bf16x3_traffic.json", "f16x2": "r*_pmc_conv_f16x2_traffic.json"}.get(k, "r*_pmc_conv_traffic.json")
-        found = [] if k == "f16x2_pointwise" else sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", pat)))[-1:]
-        if found:
+        def pmc_traffic(pat):
+            """HBM bytes per launch from a counter profile of this command (separate rocprofv3 --pmc passes: it cannot be measured
+            inside the run) -- quoted only from a profile taken on THESE kernel sources (the file records their hash,
+            tools/kernel_source_hash.py); with another hash, or none, the field is null"""
+            found = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", pat)))[-1:]
+            if not found:
+                return None, "", None
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 from kernel_source_hash import kernel_source_hash
                 pj = json.load(open(found[0]))
                 if pj.get("kernel_source_sha16") == kernel_source_hash():
-                    pmc, pmc_path = pj.get("hbm_bytes_per_launch"), found[0]
-                else:
-                    stale = os.path.relpath(found[0], ROOT)
+                    return pj.get("hbm_bytes_per_launch"), found[0], None
+                return None, "", os.path.relpath(found[0], ROOT)
             except Exception:
-                pmc = None
+                return None, "", None
+
+        def traffic_source(pmc, pmc_path, stale):
+            return (f"{os.path.relpath(pmc_path, ROOT)}: rocprofv3 --pmc passes of this command (guide-corrected HBM bytes per launch) on "
+                    "these kernel sources, NOT measured in this run" if pmc is not None else
+                    (f"{stale} was taken on other kernel sources: not quoted" if stale else None))
+
+        if k == "head_stream":
+            gbps = conv_meter.stream_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            pmc, pmc_path, stale = pmc_traffic("r*_pmc_conv_head_traffic.json")
+            return {"bound": "hbm", "kernel": "conv_head_kernel<3> (the image head 128 -> 3, 1x1, GroupNorm affine + ReLU on the way in, "
+                                              "sigmoid on the way out, as a stream: no LDS, fp32 FMAs)",
+                    "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                    "traffic": pmc, "traffic_source": traffic_source(pmc, pmc_path, stale),
+                    "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
+                    "share_of_step": round(ms / (elapsed_metered * 1e3), 3),
+                    "note": "achieved = 4 bytes x (Cin + Cout) x positions / event time"}
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        pmc, pmc_path, stale = pmc_traffic({"bf16x3": "r*_pmc_conv_bf16x3_traffic.json", "f16x2": "r*_pmc_conv_f16x2_traffic.json",
+                                            "f16x2_pointwise": "r*_pmc_conv_f16x2_p1_traffic.json"}.get(k, "r*_pmc_conv_traffic.json"))
         if k == "f16x2":
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             name = ("conv_igemm_bf16x3_ct2_kernel + conv_igemm_bf16x3_kernel<SPLIT = 2> (fp32 3x3 conv on the fp16 matrix pipes: scaled "
@@ -878,10 +890,7 @@ def main():
                     "conv_igemm_f16_kernel (fp16 operands)")
             note = None
         r = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-             "frac": round(tf / peak, 4), "traffic": pmc,
-             "traffic_source": (f"{os.path.relpath(pmc_path, ROOT)}: rocprofv3 --pmc passes of this command (guide-corrected "
-                                "HBM bytes per launch) on these kernel sources, NOT measured in this run" if pmc is not None else
-                                (f"{stale} was taken on other kernel sources: not quoted" if stale else None)),
+             "frac": round(tf / peak, 4), "traffic": pmc, "traffic_source": traffic_source(pmc, pmc_path, stale),
              "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
              "share_of_step": round(ms / (elapsed_metered * 1e3), 3)}
         if note:

@@ -53,6 +53,12 @@ for n, d in (("fetch", f), ("write", w), ("mfma", m)):
 rows = list(csv.DictReader(open(p + f"{tag}_bench_kernel_stats.csv")))
 
 
+def _ksh():
+    sys.path.insert(0, "tools")
+    from kernel_source_hash import kernel_source_hash
+    return kernel_source_hash()
+
+
 def traffic(prefix, label, dst, suffix=None):
     """per-launch HBM traffic + MFMA utilisation of the kernels whose name starts with `prefix` (all instantiations; `suffix`
     narrows them to one template argument list ending, e.g. the SPLIT = 2 instantiations of the split kernel)"""
@@ -72,6 +78,8 @@ def traffic(prefix, label, dst, suffix=None):
         "pmc_run": "rocprofv3 --pmc <one counter set> (separate passes for FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE) "
                    "-- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-source-pass (batch 16, as the bench)",
         "git_head": os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip(),
+        # (bench.py quotes the file as `traffic` only while the kernel sources still hash to this: tools/kernel_source_hash.py)
+        "kernel_source_sha16": _ksh(),
         "launches": n, "fetch_size_kib_per_launch": tf / n, "write_size_kib_per_launch": tw / n,
         "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream "
                       "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated (it equals the output tensor bytes exactly on the large layers)",
@@ -86,6 +94,9 @@ def traffic(prefix, label, dst, suffix=None):
 
 
 traffic("conv_igemm_kernel", "conv_igemm_kernel (fp32 MFMA, all instantiations)", f"{tag}_pmc_conv_traffic.json")
+# round 6: the same passes hold the pointwise kernel and the image head's stream kernel
+traffic("conv_igemm_bf16x3_p1_kernel", "conv_igemm_bf16x3_p1_kernel (1x1 layers on the fp16 split)", f"{tag}_pmc_conv_f16x2_p1_traffic.json")
+traffic("conv_head_kernel", "conv_head_kernel (the image head as a stream)", f"{tag}_pmc_conv_head_traffic.json")
 # the split kernel's two operand modes are instantiations of one template: <TR, TW, UPS, SPLIT>.  A default (f16x2) run also holds
 # the guarded bf16x3 launches, which leave at once: they would dilute a per-launch figure, so only a bf16x3 run's trace is used
 if any(k.startswith("conv_igemm_bf16x3_ct2_kernel") or __import__("re").match(r"conv_igemm_bf16x3_kernel<\d+, \d+, (?:true|false), 2", k) for k in f):

@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r3}
 mkdir -p $R/gpurun_out; cd $R
 if [ $PART = all ] || [ $PART = tests ]; then
-timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${TAG}_pytest_full.log
+timeout 2700 python -m pytest tests -m gpu -q --timeout=900 -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/${TAG}_pytest_full.log
 grep -a "PARITY\|passed\|failed\|Error\|FAILED" gpurun_out/${TAG}_pytest_full.log > gpurun_out/${TAG}_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_smoke.log
 tail -3 gpurun_out/${TAG}_pytest.log; tail -1 gpurun_out/${TAG}_smoke.log
