@@ -79,3 +79,34 @@ def test_rccl_single_rank_group_runs_the_exchange_path():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_rccl_two_ranks_two_gpus():
     _run(2)
+
+
+def test_numa_local_cores_of_this_box():
+    """parallel.pin_to_local_cores on the real topology of the box (a child process: the affinity is the process's): the GPU's NUMA
+    node is found through sysfs, the rank is bound to cores of THAT node (all of them for one rank; its share of them for two
+    ranks on GPUs of one node), and the record says so.  On a box whose sysfs does not tell, the even split is what it reports."""
+    code = (
+        "import os, sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "from emoportraits_amd import parallel\n"
+        "import torch\n"
+        "torch.cuda.init()\n"
+        "nodes, cpus = parallel._gpu_numa_nodes(), parallel._node_cpus()\n"
+        "before = sorted(os.sched_getaffinity(0))\n"
+        "rec = parallel.pin_to_local_cores(local_rank=0, n_local=1)\n"
+        "after = sorted(os.sched_getaffinity(0))\n"
+        "two = parallel.plan_affinity(1, 2, [nodes[0], nodes[0]], cpus, before)[0]\n"
+        "print(json.dumps(dict(nodes=nodes, n_nodes=len(cpus), rec=rec, n_before=len(before), n_after=len(after), after_in_node="
+        "bool(nodes and nodes[0] is not None and nodes[0] in cpus and set(after) <= set(cpus[nodes[0]])), two=len(two))))\n") % ROOT
+    env = dict(os.environ)
+    for k in ("EMO_FORCE_DEVICE", "EMO_PIN_CORES", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print("PARITY host affinity on this box:", out)
+    assert len(out["nodes"]) == torch.cuda.device_count() and out["rec"]["pinned"] and 0 < out["n_after"] <= out["n_before"]
+    if out["nodes"][0] is not None and out["nodes"][0] >= 0 and out["n_nodes"] > 1:
+        assert out["after_in_node"] and "numa node" in out["rec"]["how"] and out["n_after"] < out["n_before"]
+        assert 0 < out["two"] <= out["n_after"] // 2 + 1
