@@ -519,7 +519,7 @@ class InferenceWrapper:
             span i is handed out -- i.e. before its kernels are enqueued -- so that a host chunk's H2D copy (12.6 MB per 16 frames
             at 512^2: 0.25 ms) runs beside the previous batch's compute instead of in front of its own (on the compute stream the
             copy serialises with the kernels).  Device-resident chunks pass through."""
-            pending = None
+            ahead = None
             for span in list(spans) + [None]:
                 nxt = None
                 if span is not None:
@@ -533,13 +533,13 @@ class InferenceWrapper:
                             ev = torch.cuda.Event()
                             ev.record(upload_stream)
                         nxt = (b0, b1, t, ev)
-                if pending is not None:
-                    p0, p1, t, ev = pending
+                if ahead is not None:
+                    p0, p1, t, ev = ahead
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                         t.record_stream(torch.cuda.current_stream())
                     yield p0, p1, t
-                pending = nxt
+                ahead = nxt
 
         def crops_of(u8, base, b0, b1):
             x = ops.unpack_rgb8(u8)

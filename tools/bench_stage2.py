@@ -14,7 +14,10 @@ DEV = "cuda:0"
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    only = sys.argv[2] if len(sys.argv) > 2 else None         # "f16" / "f32": that operand mode alone (kernel traces of one mode)
     for variant, precision in (("bn", "f32"), ("gn_ws", "f32"), ("bn", "f16"), ("gn_ws", "f16")):
+        if only is not None and precision != only:
+            continue
         over = dict(output_size_s2=512)
         if variant == "gn_ws":
             over.update(norm_layer_type="gn", use_ws=True)

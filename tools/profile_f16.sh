@@ -6,7 +6,7 @@ TAG=${1:-r2}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $R/tools/bench_stage2.py 8"
+CMD="python $R/tools/bench_stage2.py 8 f16"   # the fp16-operand mode alone (both norm variants)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_f16_kt -o s2 -- $CMD > $R/gpurun_out/${TAG}_f16_prof_kt.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_f16_mfma -o s2 -- $CMD > $R/gpurun_out/${TAG}_f16_prof_mfma.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_f16_fetch -o s2 -- $CMD > $R/gpurun_out/${TAG}_f16_prof_fetch.log 2>&1
