@@ -39,6 +39,16 @@
                                  barrier (vmcnt(0): loads complete in order) then waits for them -- K loop + 3.8 k, prologue + 2.2 k: off */
 #endif
 
+// measurement builds: 1 = every weight piece re-reads the FIRST KiB of the packed weights (resident in the CU's L1: WRONG
+// results) -- what the weight stream out of the L2 costs a power-managed chip (tools/session/r6_call16.sh)
+#ifndef EMO_CT2_W_CONST
+#define EMO_CT2_W_CONST 0
+#endif
+// ... and 1 = every stage of an item re-reads the patch of input channel 0 (L1 / L2 hits after the first stage: WRONG results)
+#ifndef EMO_CT2_X_CONST
+#define EMO_CT2_X_CONST 0
+#endif
+
 template <int TR, int TW, bool UPS>
 struct ConvCfgS2 : ConvCfgS<TR, TW, UPS, 2> {
   using Base = ConvCfgS<TR, TW, UPS, 2>;
@@ -149,7 +159,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
   emo_intx4 xrs = emo_raw_buffer(a.x);
   unsigned usoff[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)u * (unsigned)DHW * 4u));
+  for (int u = 0; u < 8; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)u * (unsigned)DHW * 4u * (EMO_CT2_X_CONST ? 0u : 1u)));
 
   int n_ci0, n_zu;
   bool n_zv;
@@ -169,7 +179,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
     const bool keep_ = lq_ok && cv_ && n_zv;                                                          \
     q_lo = keep_ ? clamp_lo : 0.0f;                                                                   \
     q_hi = keep_ ? CLAMP_HI : 0.0f;                                                                   \
-    q_vo = lq_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;        \
+    q_vo = lq_off + (EMO_CT2_X_CONST ? 0u : ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u);   \
     q_tix = (has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2;                                         \
   }
 #define EMO_T_ISSUE_LOADS(u0_, u1_)                                                                   \
@@ -197,11 +207,12 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
       *reinterpret_cast<opx8*>(d_ + PPL * 16) = cv_m;                                                 \
     }                                                                                                 \
   }
+#define EMO_T_WSRC(p_) (EMO_CT2_W_CONST ? reinterpret_cast<const char*>(a.wpk) : (p_))
 // piece k = 0 .. 8 of a half-stage's kernel rows (wave w copies pieces w, w + 4, w + 8 of each of the three rows) into W[wb_]
 #define EMO_T_DMA_PIECE(ptr_, wb_, k_)                                                                \
   {                                                                                                   \
     const int row_ = (k_) / 3, j_ = wave + 4 * ((k_) % 3);                                            \
-    emo_dma16_pinned_s((ptr_) + (row_ * Cfg::WROW_BYTES + j_ * 1024), lane16,                         \
+    emo_dma16_pinned_s(EMO_T_WSRC((ptr_) + (row_ * Cfg::WROW_BYTES + j_ * 1024)), lane16,             \
                        smem_lds + (unsigned)((Cfg::OFF_W + (wb_) * Cfg::WSTAGE) * 16 + row_ * Cfg::WROW_BYTES + j_ * 1024)); \
   }
 
@@ -393,7 +404,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
               const int j_ = wave + 4 * pl;
               const unsigned dst_ = smem_lds + ((h == 1 && last_) ? (unsigned)(pcur_b + j_ * 1024)
                                                                    : (unsigned)((Cfg::OFF_W + h * Cfg::WSTAGE) * 16 + j_ * 1024));
-              emo_dma16_pinned_s(dma_ptr2 + j_ * 1024, lane16, dst_);
+              emo_dma16_pinned_s(EMO_T_WSRC(dma_ptr2 + j_ * 1024), lane16, dst_);
             }
             if (gs < 4 && pl == 0) EMO_T_DMA_PIECE(dma_ptr, h ^ 1, 2 + gs)
             if (h == 1 && gs < 4 && pl == 1) EMO_T_ISSUE_LOADS(2 * gs, 2 * gs + 2)
@@ -509,6 +520,7 @@ void conv_igemm_bf16x3_ct2_kernel(const ConvArgs a) {
 #undef EMO_T_TOUCH_QUAD
 #undef EMO_T_CONV_HALF
 #undef EMO_T_DMA_PIECE
+#undef EMO_T_WSRC
 }
 
 // Launches the channel-tile PAIRS of the layer on conv_igemm_bf16x3_ct2_kernel when that fills the chip; *rest_cot0 = the first
