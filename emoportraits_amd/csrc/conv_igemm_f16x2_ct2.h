@@ -39,16 +39,6 @@
                                  barrier (vmcnt(0): loads complete in order) then waits for them -- K loop + 3.8 k, prologue + 2.2 k: off */
 #endif
 
-// measurement builds: 1 = every weight piece re-reads the FIRST KiB of the packed weights (resident in the CU's L1: WRONG
-// results) -- what the weight stream out of the L2 costs a power-managed chip (tools/session/r6_call16.sh)
-#ifndef EMO_CT2_W_CONST
-#define EMO_CT2_W_CONST 0
-#endif
-// ... and 1 = every stage of an item re-reads the patch of input channel 0 (L1 / L2 hits after the first stage: WRONG results)
-#ifndef EMO_CT2_X_CONST
-#define EMO_CT2_X_CONST 0
-#endif
-
 template <int TR, int TW, bool UPS>
 struct ConvCfgS2 : ConvCfgS<TR, TW, UPS, 2> {
   using Base = ConvCfgS<TR, TW, UPS, 2>;

@@ -303,7 +303,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   emo_intx4 xrs = emo_raw_buffer(a.x);
   unsigned usoff[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(4 * ch + u) * (unsigned)DHW * 4u));
+  for (int u = 0; u < 4; ++u) usoff[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(4 * ch + u) * (unsigned)DHW * 4u * (EMO_CT2_X_CONST ? 0u : 1u)));
 
   int n_ci0, n_zu;
   bool n_zv;
@@ -324,7 +324,7 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
       const bool keep_ = lq_ok && cv_ && n_zv;                                                        \
       q_lo[kb] = keep_ ? clamp_lo : 0.0f;                                                             \
       q_hi[kb] = keep_ ? CLAMP_HI : 0.0f;                                                             \
-      q_vo[kb] = lq_off + ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u;  \
+      q_vo[kb] = lq_off + (EMO_CT2_X_CONST ? 0u : ((unsigned)cs_ * (unsigned)DHW + (unsigned)((n_zv ? n_zu : 0) * HW)) * 4u);  \
       q_tix[kb] = ((has_affine ? cs_ : (cs_ & (Cfg::SCT - 1))) >> 2) + ch;                            \
     }                                                                                                 \
   }
@@ -369,7 +369,8 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #define EMO_W_DMA_CHUNK(ptr_, dst_, m_)                                                               \
   {                                                                                                   \
     const int c_ = EMO_W_CHUNK_OF(m_);                                                                \
-    emo_dma16_pinned_s((ptr_) + c_ * 1024, lane16, (dst_) + (unsigned)(c_ * 1024));                   \
+    emo_dma16_pinned_s(EMO_CT2_W_CONST ? reinterpret_cast<const char*>(a.wpk) : (ptr_) + c_ * 1024, lane16, \
+                       (dst_) + (unsigned)(c_ * 1024));   /* (EMO_CT2_W_CONST / _X_CONST: measurement builds, conv_igemm_f16x2_ct2.h) */ \
   }
 #define EMO_W_WBUF(wb_) (smem_lds + (unsigned)((Cfg::OFF_W + (wb_) * Cfg::WSTAGE) * 16))
 

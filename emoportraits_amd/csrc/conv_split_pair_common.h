@@ -7,6 +7,18 @@
 // their own files.
 #pragma once
 
+// measurement builds: 1 = every weight piece re-reads the FIRST KiB of the packed weights (resident in the CU's L1: WRONG
+// results) -- what the weight stream out of the L2 costs a power-managed chip (both paired kernels;
+// tools/session/r6_call16.sh, r6_call19.sh)
+#ifndef EMO_CT2_W_CONST
+#define EMO_CT2_W_CONST 0
+#endif
+// ... and 1 = every stage of an item re-reads the patch of input channel 0 (L1 / L2 hits after the first stage: WRONG results)
+#ifndef EMO_CT2_X_CONST
+#define EMO_CT2_X_CONST 0
+#endif
+
+
 // work item l -> (sample, position tile, channel-tile PAIR): XCD-contiguous order, pair fastest.  Every result through
 // readfirstlane (conv_igemm_bf16x3.h); n_cotiles counts PAIRS here, cot0 is the first tile of the launch
 #define EMO_P_DECODE(P_, L_)                                                                          \
