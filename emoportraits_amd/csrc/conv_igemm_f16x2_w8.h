@@ -31,6 +31,13 @@
 #include "conv_igemm_bf16x3.h"
 #include "conv_split_pair_common.h"
 
+#ifndef EMO_W8_EARLY_LOADS
+#define EMO_W8_EARLY_LOADS 1   /* 0: A/B builds (loads of stage cg + 2 in half-stage 1, as the fp16 split) */
+#endif
+#ifndef EMO_W8_EARLY_STEPS
+#define EMO_W8_EARLY_STEPS 4
+#endif
+
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 template <int TR, int TW, bool UPS>
@@ -497,6 +504,13 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
   }
 
   // ---- K loop: one stage = two half-stages (conv_igemm_f16x2_ct2.h, header comment there) ----
+  // EARLY (plain fp16 operands): a half-stage is a third of the split's matrix work, so the raw patch loads of stage cg + 2 --
+  // issued in the first steps of half-stage 1 and awaited at its end -- had five to eight steps (1.5-2 k cycles) to come back:
+  // less than a loaded L2 miss.  The conversion of stage cg + 1 (12 VALU per unit here) runs two units per step in steps 0-3 of
+  // half-stage 0, the loads go out in its steps 4-7 and fly across its barrier: 10-13 steps of cover, same registers, same
+  // invariants at the stage boundary (prologue, chaining and epilogue unchanged)
+  constexpr bool EARLY = NPROD == 1 && EMO_W8_EARLY_LOADS;
+  constexpr int ESTEPS = EMO_W8_EARLY_STEPS;              // steps the conversion takes (4: one pixel per step, 2: two)
   EMO_S_STAMP(1)
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -526,9 +540,12 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
 #pragma unroll
       for (int gs = 0; gs < 9; ++gs) {
         const int fcur = (h * 9 + gs) & 1, fnxt = fcur ^ 1;
-        if (gs == 8) { EMO_P_BARRIER(0); }
+        if (gs == 8) {
+          // (EARLY: the patch loads issued in this half-stage 0 -- 2 NKB pairs, younger than its weight chunks -- stay in flight)
+          if (EARLY && h == 0) { EMO_P_BARRIER(4 * NKB); } else { EMO_P_BARRIER(0); }
+        }
         if (gs == 8 && h == 1) EMO_W_TOUCH_QUAD()          // (the loads of stage cg + 2 have landed behind the barrier)
-        if (gs == 0 && h == 1) {
+        if (EARLY ? (gs == ESTEPS && h == 0) : (gs == 0 && h == 1)) {
           // the patch loads of stage cg + 2; past the item's end: the next item's stages 0 / 1 (chained), a dead re-stage otherwise
           const bool sw_ = chain_out && cg + 2 == nst;
           const int tgt_ = (chain_out && cg + 2 > nst) ? 1 : ((cg + 2) < nst ? cg + 2 : nst - 1);
@@ -560,11 +577,18 @@ void conv_igemm_f16x2_w8_kernel(const ConvArgs a) {
             }
             // chunks 1 .. NDM - 1 of the rows of half-stage t + 1 into W[h ^ 1], one per step
             if (gs < NDM - 1 && pl == 0) EMO_W_DMA_CHUNK(dma_ptr, EMO_W_WBUF(h ^ 1), 1 + gs)
-            if (h == 1 && gs < 2 * NKB && pl == NPL - 1) EMO_W_ISSUE_LOADS(gs)
+            if (!EARLY && h == 1 && gs < 2 * NKB && pl == NPL - 1) EMO_W_ISSUE_LOADS(gs)
+            if (EARLY && h == 0 && gs >= ESTEPS && gs < ESTEPS + 2 * NKB && pl == NPL - 1) EMO_W_ISSUE_LOADS(gs - ESTEPS)
           }
         }
         // the patch of stage cg + 1: one conversion unit per step (four channels of one pixel, of one k-block)
-        if (h == 0 && gs < 4 * NKB) EMO_W_CONV_UNIT(pnxt_b, gs / NKB, gs % NKB)
+        if (!EARLY && h == 0 && gs < 4 * NKB) EMO_W_CONV_UNIT(pnxt_b, gs / NKB, gs % NKB)
+        if (EARLY && h == 0 && gs < ESTEPS) {              // (all of it in the first steps: the registers are free for the loads)
+#pragma unroll
+          for (int i = gs * (4 / ESTEPS); i < (gs + 1) * (4 / ESTEPS); ++i)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) EMO_W_CONV_UNIT(pnxt_b, i, kb)
+        }
         if (h == 1 && gs == 7) { EMO_W_TABLE() }           // (what the next stage's units convert with)
 #pragma unroll
         for (int p = 0; p < NMM; ++p) {
