@@ -232,18 +232,21 @@ def pack_weight_f16w8(w):
 
 
 F16_W8 = __import__("os").environ.get("EMO_F16_W8", "1") != "0"   # A/B switch: 0 keeps every fp16-operand layer on conv_igemm_f16.h
-F16_W8_ODD = __import__("os").environ.get("EMO_F16_W8_ODD", "0") == "1"   # A/B switch: 1 also plans odd channel-tile counts onto it
+# odd channel-tile counts on it (the last pair half empty): "5" (default) from five tiles on -- a sixth of the launch's staging is
+# wasted, and it wins (320 outputs: +8 / +17 % with the early patch loads, tools/session/r6_call24.sh); "1": every odd count
+# (three tiles waste a quarter: 0.9-1.0x the older kernel; one tile half of everything); "0": even counts only
+F16_W8_ODD = {"0": 0, "1": 1, "5": 5}.get(__import__("os").environ.get("EMO_F16_W8_ODD", "5"), 5)
 
 
 def f16w8_launch_fits(cout, cin, kd, kh, kw, Hl, Wl, n_pos_tiles, act="none", positions_per_sample=0):
     """the one launch form of emo_conv_igemm_f16w8 (conv_f16x2_w8_launch<.., NPROD = 1> -- every check of the C launcher has its
     mirror here): 3x3 / 3x3x3, whole 64-channel tiles and 8-channel groups, 4 x 64 position tiles, no activation, at most 2^23
-    positions per sample, two pair items per CU.  And -- a choice of the planner, not a limit of the kernel -- an EVEN number of
-    channel tiles: the kernel runs an odd last tile in a half-empty pair, which costs a whole pair's staging (measured 0.79-0.87x
-    the older kernel on the 192- and 320-channel layers, 1.14-1.16x on the even ones: tools/session/r6_call3.sh)"""
+    positions per sample, two pair items per CU.  And -- a choice of the planner, not a limit of the kernel -- an even number of
+    channel tiles, or an odd one from F16_W8_ODD tiles on: the kernel runs an odd last tile in a half-empty pair, which costs a
+    whole pair's staging"""
     if not F16_W8 or (kh, kw) != (3, 3) or kd not in (1, 3) or cout % BF16X3_BM or cin % 8 or act != "none":
         return False
-    if cout % (2 * BF16X3_BM) and not F16_W8_ODD:
+    if cout % (2 * BF16X3_BM) and not (F16_W8_ODD and cout // BF16X3_BM >= F16_W8_ODD):
         return False
     if Hl is None or Wl % 64 or Hl % 4 or positions_per_sample > (1 << 23):
         return False
