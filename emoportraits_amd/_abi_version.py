@@ -1,1 +1,1 @@
-EMO_ABI_VERSION = 9   # must equal EMO_ABI_VERSION in include/emo_hip.h
+EMO_ABI_VERSION = 10   # must equal EMO_ABI_VERSION in include/emo_hip.h

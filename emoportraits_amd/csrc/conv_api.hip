@@ -134,7 +134,8 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
                                const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D, int H,
                                int W, int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups, int cfg,
                                int ksplit, float* workspace, float* gn_stats, void* stream, float in_scale = 1.0f,
-                               float w_scale = 1.0f, int* sat_flag = nullptr, const int* run_if = nullptr) {
+                               float w_scale = 1.0f, int* sat_flag = nullptr, const int* run_if = nullptr, int cot0 = 0,
+                               int cot_end = 0) {
   if (!x || !wpk || !out) return EMO_ERR_BAD_ARG;
   if (gn_stats && ksplit > 1) return EMO_ERR_UNSUPPORTED;   // tile statistics come from the single-pass epilogue
   if ((long)D * H * W >= (1L << 30)) return EMO_ERR_UNSUPPORTED;                 // 32-bit byte offsets inside one channel
@@ -154,7 +155,8 @@ static int conv_igemm_dispatch(int prec, const float* x, const void* wpk, const 
   a.Dl = D; a.Hl = ups ? 2 * H : H; a.Wl = ups ? 2 * W : W;
   a.KD = KD; a.relu_in = relu_in; a.act = act; a.res_ups = res_ups;
   a.gn_stats = gn_stats;
-  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0; a.cot0 = 0;
+  a.n_cchunks = 0; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.n_cotiles = 0; a.n_work = 0; a.cot0 = cot0; a.cot_end = cot_end;
+  if ((cot0 != 0 && !(prec == PREC_F16 && cfg == CFG_D && ksplit == 1)) || (cot_end != 0 && prec != PREC_H1)) return EMO_ERR_BAD_ARG;
   a.in_scale = in_scale; a.out_scale = 1.0f / (in_scale * w_scale);
   a.sat_flag = sat_flag; a.run_if = run_if;
   const int shape = shape_of_width(a.Wl);
@@ -260,6 +262,23 @@ extern "C" int emo_conv_igemm_f16acc32(const float* x, const void* wpk16, const 
                                        int cfg, int ksplit, float* workspace, float* gn_stats, void* stream) {
   return conv_igemm_dispatch(PREC_F16, x, wpk16, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups,
                              relu_in, act, res_ups, cfg, ksplit, workspace, gn_stats, stream);
+}
+
+// ABI 10.  A layer with an ODD number of 64-channel tiles in the plain-fp16 mode: its whole pairs on the eight-wave two-tile
+// kernel (wpk1), the last tile on the older fp16-operand kernel (wpk16, that kernel's layout for block config 3) -- two
+// launches, one call, every output element written once: see include/emo_hip.h
+extern "C" int emo_conv_igemm_f16w8_rest(const float* x, const void* wpk1, const void* wpk16, const float* bias,
+                                         const float* scale, const float* shift, const float* res, float* out, int N, int Cin,
+                                         int Cout, int D, int H, int W, int KD, int KH, int KW, int ups, int relu_in, int act,
+                                         int res_ups, int cfg, int ksplit, float* workspace, float* gn_stats, void* stream,
+                                         float w_scale) {
+  const int cot = (Cout + 63) / 64;
+  if (!wpk16 || Cout % 64 || cot < 3 || !(cot & 1)) return EMO_ERR_UNSUPPORTED;
+  int rc = conv_igemm_dispatch(PREC_H1, x, wpk1, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups, relu_in,
+                               act, res_ups, cfg, ksplit, workspace, gn_stats, stream, 1.0f, w_scale, nullptr, nullptr, 0, cot - 1);
+  if (rc != EMO_OK) return rc;
+  return conv_igemm_dispatch(PREC_F16, x, wpk16, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups, relu_in,
+                             act, res_ups, cfg, ksplit, workspace, gn_stats, stream, 1.0f, 1.0f, nullptr, nullptr, cot - 1, 0);
 }
 
 // ABI 9.  Plain fp16 operands (BASELINE configs[4]) on the eight-wave two-tile kernel: see include/emo_hip.h

@@ -72,8 +72,10 @@ struct ConvArgs {
   int n_cchunks;       // ceil(Cin / KC)
   int tiles_x, tiles_y, tiles_z;
   int n_cotiles;       // ceil(Cout / BM)
-  int cot0;            // conv_igemm_bf16x3.h / conv_igemm_f16x2_ct2.h only: first channel tile of the launch (n_cotiles tiles from there:
-                       // a layer's tile pairs run the two-tile kernel, an odd last tile the single-tile one); 0 elsewhere
+  int cot0;            // conv_igemm_bf16x3.h / conv_igemm_f16x2_ct2.h / conv_igemm_f16.h: first channel tile of the launch (n_cotiles
+                       // tiles from there: a layer's tile pairs run a two-tile kernel, an odd last tile a single-tile one); 0 elsewhere
+  int cot_end;         // conv_igemm_f16x2_w8.h with plain fp16 operands: one past the last channel tile of the launch (even), or 0 =
+                       // all of them, an odd last one in a half-empty pair (emo_conv_igemm_f16w8_rest, conv_api.hip)
   float in_scale, out_scale;   // conv_igemm_bf16x3.h, fp16 two-term split only: power of two applied to the staged input, and
                        // 1 / (in_scale * weight scale) applied to the accumulators before the epilogue
   int n_work;          // conv_igemm_bf16x3.h only: output tiles x K splits of the launch (a block walks the tiles of its

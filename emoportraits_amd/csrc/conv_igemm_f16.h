@@ -158,7 +158,7 @@ void conv_igemm_f16_kernel(const ConvArgs a) {
   const int q8 = total >> 3, r8 = total & 7;
   const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
   const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
-  const int cotile = L % a.n_cotiles;
+  const int cotile = L % a.n_cotiles + a.cot0;      // (cot0 > 0: the odd last tile behind the eight-wave kernel's pairs)
   int rest = L / a.n_cotiles;
   if (a.ksplit > 1) {
     ks = rest % a.ksplit;
@@ -494,11 +494,13 @@ int conv_igemm_f16_launch(ConvArgs a, hipStream_t s) {
     const int rc = emo_raise_dynamic_lds(kern);
     if (rc != EMO_OK) return rc;
   }
-  a.n_cotiles = cot;
+  if (a.cot0 < 0 || a.cot0 >= cot) return EMO_ERR_BAD_ARG;
+  const int ncot = cot - a.cot0;
+  a.n_cotiles = ncot;
   if (a.ksplit < 1 || (a.ksplit > 1 && !a.partial)) return EMO_ERR_BAD_ARG;
   if (a.ksplit == 1) { a.stages_per_split = a.n_cchunks * a.KD; a.partial = nullptr; }
   if (a.ksplit > 1 && a.gn_stats) return EMO_ERR_BAD_ARG;
-  if (nt * cot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nt * cot * a.N * a.ksplit)), dim3(256), lds, s, a);
+  if (nt * ncot * a.N * a.ksplit > 0x7fffffffL) return EMO_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nt * ncot * a.N * a.ksplit)), dim3(256), lds, s, a);
   return emo_launch_status();
 }

@@ -736,7 +736,9 @@ int conv_f16x2_w8_launch(ConvArgs a, hipStream_t s, int* rest_cot0) {
   if (a.scale && a.Cin > Cfg::SCT) return EMO_OK;
   if ((unsigned long long)a.Cin * a.D * a.H * a.W * 4ull >= (1ull << 32)) return EMO_OK;
   if ((reinterpret_cast<unsigned long long>(a.x) & 15ull) || (a.W & 3)) return EMO_OK;
-  const int cot = (a.Cout + Cfg::BM - 1) / Cfg::BM;
+  const int cot_all = (a.Cout + Cfg::BM - 1) / Cfg::BM;
+  if (a.cot_end != 0 && (NPROD != 1 || a.cot_end < 2 || a.cot_end > cot_all || (a.cot_end & 1))) return EMO_ERR_BAD_ARG;
+  const int cot = a.cot_end != 0 ? a.cot_end : cot_all;          // (cot_end: whole pairs only, the rest is the caller's)
   const int pairs = NPROD == 1 ? (cot + 1) / 2 : cot / 2;
   const long nt = (long)(a.Wl / TW) * (a.Hl / TR) * a.Dl;
   const int ncu = emo_cu_count();

@@ -40,6 +40,7 @@ SIGNATURES = {
     "emo_conv_pack_info_f16": [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
     "emo_conv_igemm_f16acc32": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void],
     "emo_conv_igemm_f16w8": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, ctypes.c_float],
+    "emo_conv_igemm_f16w8_rest": [_c_void] * 8 + [_c_int] * 15 + [_c_void, _c_void, _c_void, ctypes.c_float],
     "emo_conv_pack_info_bf16x3": [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
     "emo_conv_igemm_bf16x3": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, _c_void],
     "emo_conv_igemm_f16x2": [_c_void] * 7 + [_c_int] * 15 + [_c_void, _c_void, _c_void, ctypes.c_float, ctypes.c_float, _c_void],

@@ -375,8 +375,14 @@ def conv_igemm(x, layer, scale=None, shift=None, relu_in=False, ups=False, res=N
     elif prec == "f16w8":
         # plain fp16 operands on the eight-wave two-tile kernel (opt-in precision 'f16'; csrc/conv_igemm_f16x2_w8.h, NPROD = 1);
         # the straight-line epilogue reads 16-byte aligned out / res: anything else was planned onto the older fp16 kernel
-        rc = entry(hip.ptr(x), hip.ptr(wpk), *common, layer.w_scale16)
-        hip.check(rc, f"emo_conv_igemm_f16w8[{layer.name}]")
+        if pack_mod.f16w8_rest_fits(layer.cout, Hl, Wl):
+            # an odd tile count: the pairs on that kernel, the last tile on the older fp16-operand kernel (ABI 10) -- no half-empty pair
+            rc = lib.emo_conv_igemm_f16w8_rest(hip.ptr(x), hip.ptr(wpk), hip.ptr(layer.packed(pack_mod.CFG_D, "f16")), *common,
+                                               layer.w_scale16)
+            hip.check(rc, f"emo_conv_igemm_f16w8_rest[{layer.name}]")
+        else:
+            rc = entry(hip.ptr(x), hip.ptr(wpk), *common, layer.w_scale16)
+            hip.check(rc, f"emo_conv_igemm_f16w8[{layer.name}]")
     else:
         extra = (None,) if prec == "bf16x3" else ()
         rc = entry(hip.ptr(x), hip.ptr(wpk), *common, *extra)

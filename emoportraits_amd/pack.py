@@ -238,6 +238,18 @@ F16_W8 = __import__("os").environ.get("EMO_F16_W8", "1") != "0"   # A/B switch: 
 F16_W8_ODD = {"0": 0, "1": 1, "5": 5}.get(__import__("os").environ.get("EMO_F16_W8_ODD", "5"), 5)
 
 
+# an odd channel-tile count >= 3: the whole pairs on the eight-wave kernel, the last tile on conv_igemm_f16.h
+# (emo_conv_igemm_f16w8_rest, ABI 10) -- no half-empty pair; 0: A/B switch (F16_W8_ODD then decides as before)
+F16_W8_REST = __import__("os").environ.get("EMO_F16_W8_REST", "1") != "0"
+
+
+def f16w8_rest_fits(cout, Hl, Wl):
+    """emo_conv_igemm_f16w8_rest takes the layer: an odd tile count >= 3 and an output plane that is in the older kernel's
+    launch form too (f16_launch_fits: its 2 x 128 / 4 x 64 tiles)"""
+    cot = cout // BF16X3_BM
+    return F16_W8_REST and cout % BF16X3_BM == 0 and cot >= 3 and cot % 2 == 1 and Hl is not None and f16_launch_fits(Hl, Wl)
+
+
 def f16w8_launch_fits(cout, cin, kd, kh, kw, Hl, Wl, n_pos_tiles, act="none", positions_per_sample=0):
     """the one launch form of emo_conv_igemm_f16w8 (conv_f16x2_w8_launch<.., NPROD = 1> -- every check of the C launcher has its
     mirror here): 3x3 / 3x3x3, whole 64-channel tiles and 8-channel groups, 4 x 64 position tiles, no activation, at most 2^23
@@ -246,12 +258,15 @@ def f16w8_launch_fits(cout, cin, kd, kh, kw, Hl, Wl, n_pos_tiles, act="none", po
     whole pair's staging"""
     if not F16_W8 or (kh, kw) != (3, 3) or kd not in (1, 3) or cout % BF16X3_BM or cin % 8 or act != "none":
         return False
-    if cout % (2 * BF16X3_BM) and not (F16_W8_ODD and cout // BF16X3_BM >= F16_W8_ODD):
+    if cout % (2 * BF16X3_BM) and not (F16_W8_ODD and cout // BF16X3_BM >= F16_W8_ODD) \
+            and not f16w8_rest_fits(cout, Hl, Wl):
         return False
     if Hl is None or Wl % 64 or Hl % 4 or positions_per_sample > (1 << 23):
         return False
     min_items = int(__import__("os").environ.get("EMO_CONV_CT2_MIN_ITEMS", 2 * cu_count()))
-    return (n_pos_tiles // 2) * (-(-(cout // BF16X3_BM) // 2)) >= min_items
+    cot = cout // BF16X3_BM
+    pairs = cot // 2 if f16w8_rest_fits(cout, Hl, Wl) else -(-cot // 2)
+    return (n_pos_tiles // 2) * pairs >= min_items
 
 
 F16X2_P1_KC = 32     # conv_igemm_f16x2_p1.h: input channels per stage of the pointwise kernel

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define EMO_ABI_VERSION 9
+#define EMO_ABI_VERSION 10
 
 #define EMO_OK 0
 #define EMO_ERR_BAD_ARG (-1)       /* null pointer / non-positive size / unknown enum          */
@@ -215,6 +215,18 @@ int emo_conv_igemm_f16w8(const float* x, const void* wpk1, const float* bias, co
                          const float* res, float* out, int N, int Cin, int Cout, int D, int H, int W, int KD, int KH, int KW,
                          int ups, int relu_in, int act, int res_ups, int cfg, int ksplit, float* workspace, float* gn_stats,
                          void* stream, float w_scale);
+
+/* ABI 10.  The same mode for a layer with an ODD number (>= 3) of 64-channel tiles (the decoder's 192- and 320-channel layers,
+ * networks/volumetric_avatar/decoder.py:277): emo_conv_igemm_f16w8 would run the last tile in a half-empty pair that costs a
+ * whole pair's staging; here the whole pairs run that kernel (wpk1, as above) and the last tile runs
+ * emo_conv_igemm_f16acc32's kernel on the same arguments (wpk16: THAT entry's layout for cfg 3, the whole layer's weights) --
+ * two launches on `stream`, every output element and every gn_stats entry written once.  The launch must be in the form of
+ * BOTH kernels (emo_conv_igemm_f16w8's above; emo_conv_igemm_f16acc32's: Wl % 128 == 0 or Wl == 64); EMO_ERR_UNSUPPORTED
+ * otherwise and for an even or single tile count. */
+int emo_conv_igemm_f16w8_rest(const float* x, const void* wpk1, const void* wpk16, const float* bias, const float* scale,
+                              const float* shift, const float* res, float* out, int N, int Cin, int Cout, int D, int H, int W,
+                              int KD, int KH, int KW, int ups, int relu_in, int act, int res_ups, int cfg, int ksplit,
+                              float* workspace, float* gn_stats, void* stream, float w_scale);
 
 /* fp32 3x3 convolution on the bf16 matrix pipes (NOT a reduced-precision mode): every fp32 operand is the exact sum of three
  * bf16 terms (x = xh + xm + xl, 24 significand bits kept), the six partial products of order <= 2^-16 are accumulated in fp32

@@ -114,6 +114,10 @@ class Case:
             flat, ws = pack.pack_weight_f16w8(self.w)
             wpk = _buf(_half_bits(flat))
             rc = lib.emo_conv_igemm_f16w8(_p(xa), _p(wpk), *common, ctypes.c_float(ws))
+        elif mode == "f16w8r":        # ABI 10: the pairs on the eight-wave kernel, the odd last tile on the older fp16-operand kernel
+            flat, ws = pack.pack_weight_f16w8(self.w)
+            wpk, wold = _buf(_half_bits(flat)), _buf(_half_bits(pack.pack_weight_f16(self.w, cfg)))
+            rc = lib.emo_conv_igemm_f16w8_rest(_p(xa), _p(wpk), _p(wold), *common, ctypes.c_float(ws))
         else:
             raise ValueError(mode)
         assert rc == 0, (mode, rc)
@@ -306,6 +310,49 @@ def test_plain_fp16_operands_on_the_eight_wave_kernel(lib, form, monkeypatch):
     m2 = s[..., 1].sum(1) + 256 * ((s[..., 0] - mean[:, None]) ** 2).sum(1)
     assert (mean - o.mean(-1)).abs().max().item() < 1e-5
     assert (m2 - ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1)).abs().max().item() < 1e-3 * m2.abs().max().item()
+
+
+F16W8_REST_FORMS = [
+    dict(N=2, Cin=40, Cout=192, dims=(8, 64), res=True),                                   # three tiles: one pair + the last tile
+    dict(N=1, Cin=16, Cout=320, dims=(4, 128), res=False),                                 # five tiles; the older kernel tiles 2 x 128
+    dict(N=1, Cin=24, Cout=192, dims=(4, 32), ups=True, res=True, res_ups=True),           # fused upsample, half-size residual
+    dict(N=1, Cin=16, Cout=192, dims=(2, 4, 64), res=True),                                # depth taps
+]
+
+
+@pytest.mark.parametrize("form", F16W8_REST_FORMS)
+def test_plain_fp16_odd_tile_count_pairs_and_rest(lib, form, monkeypatch):
+    """emo_conv_igemm_f16w8_rest (ABI 10): a layer with an odd number of channel tiles -- its pairs on the eight-wave kernel, its last
+    tile on the older fp16-operand kernel (ConvArgs::cot0 there, ::cot_end here), every output element and every tile statistic
+    written exactly once (the buffers start as NaN) -- against fp64 at the fp16-operand bound and against the one-launch form
+    with the half-empty last pair"""
+    kw = dict(form)
+    N, Cin, Cout, dims = kw.pop("N"), kw.pop("Cin"), kw.pop("Cout"), kw.pop("dims")
+    c = Case(N, Cin, Cout, dims, seed=Cin + Cout + 1, **kw)
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    out, st = c.launch(lib, "f16w8r", stats=True)
+    assert not np.isnan(out).any() and not np.isnan(st).any()
+    assert c.err(out) < 2e-3
+    one, st1 = c.launch(lib, "f16w8", stats=True)
+    assert np.abs(out - one).max() <= 2e-5 * max(1.0, np.abs(one).max())
+    assert np.array_equal(out[:, :Cout - 64], one[:, :Cout - 64])                          # the pairs: the same kernel, the same items
+    o = torch.from_numpy(out.copy()).double().view(N, Cout, -1)
+    s = torch.from_numpy(st.copy()).double()
+    mean = s[..., 0].mean(1)
+    m2 = s[..., 1].sum(1) + 256 * ((s[..., 0] - mean[:, None]) ** 2).sum(1)
+    assert (mean - o.mean(-1)).abs().max().item() < 1e-5
+    assert (m2 - ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1)).abs().max().item() < 1e-3 * m2.abs().max().item()
+
+
+def test_plain_fp16_pairs_and_rest_declines_even_and_single_tile_counts(lib, monkeypatch):
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    for cout in (64, 128):
+        c = Case(1, 16, cout, (4, 64), res=False, seed=3)
+        wpk = _buf(_half_bits(pack.pack_weight_f16w8(c.w)[0]))
+        wold = _buf(_half_bits(pack.pack_weight_f16(c.w, CFG_D)))
+        out = _buf(np.zeros(c.ref.shape, np.float32))
+        args = [_p(_buf(c.x)), _p(wpk), _p(wold), None, None, None, None, _p(out), 1, 16, cout, 1, 4, 64, 1, 3, 3, 0, 1, 0, 0, CFG_D, 1, None, None, None]
+        assert lib.emo_conv_igemm_f16w8_rest(*args, ctypes.c_float(1.0)) == -2             # EMO_ERR_UNSUPPORTED
 
 
 def test_plain_fp16_eight_wave_kernel_declines_other_launch_forms(lib):

@@ -255,9 +255,15 @@ def test_fp16_plan_falls_back_to_fp32_where_the_fp16_kernel_cannot_run():
     assert two.plan_for(big, 32, 32)[2] == "f16"                     # 8 x 32 position tiles: the older kernel
     assert lay.plan_for(big, 512, 512)[2] == "f16"                   # an odd number of channel tiles (one): the older kernel
     assert pack.PackedConv("c", torch.zeros(96, 64, 3, 3), None, "cpu", precision="f16").plan_for(big, 512, 512)[2] == "f16"
-    # ... three tiles too (a quarter of the staging wasted in the half-empty last pair); from five tiles on the eight-wave kernel wins
-    assert pack.PackedConv("t3", torch.zeros(192, 64, 3, 3), None, "cpu", precision="f16").plan_for(big, 512, 512)[2] == "f16"
-    assert pack.PackedConv("t5", torch.zeros(320, 64, 3, 3), None, "cpu", precision="f16").plan_for(big, 512, 512)[2] == "f16w8"
+    # ... an odd count >= 3: the pairs on the eight-wave kernel, the last tile on the older one (emo_conv_igemm_f16w8_rest, ABI 10) where
+    # the plane is in BOTH kernels' launch form; elsewhere (192-wide: 4 x 64 tiles fit, 2 x 128 do not) a half-empty last pair from
+    # five tiles on, the older kernel below that
+    t3 = pack.PackedConv("t3", torch.zeros(192, 64, 3, 3), None, "cpu", precision="f16")
+    t5 = pack.PackedConv("t5", torch.zeros(320, 64, 3, 3), None, "cpu", precision="f16")
+    assert t3.plan_for(big, 512, 512)[2] == "f16w8" and pack.f16w8_rest_fits(192, 512, 512)
+    assert t5.plan_for(big, 512, 512)[2] == "f16w8" and pack.f16w8_rest_fits(320, 512, 512)
+    assert not pack.f16w8_rest_fits(192, 192, 192) and not pack.f16w8_rest_fits(128, 512, 512) and not pack.f16w8_rest_fits(64, 512, 512)
+    assert t3.plan_for(big, 192, 192)[2] == "f32" and t5.plan_for(big, 192, 192)[2] == "f16w8"
     flat, ws = pack.pack_weight_f16w8(torch.randn(70, 24, 3, 3))
     assert flat.dtype == torch.float16 and flat.numel() == 2 * 2 * 9 * 2 * 64 * 8 and ws == 2.0 ** math.floor(math.log2(ws))
 

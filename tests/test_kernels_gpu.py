@@ -219,14 +219,19 @@ F16W8_CASES = [
 ]
 
 
+@pytest.mark.parametrize("rest", [True, False])
 @pytest.mark.parametrize("case", F16W8_CASES)
-def test_conv_fp16_operands_on_the_eight_wave_two_tile_kernel(case, monkeypatch):
+def test_conv_fp16_operands_on_the_eight_wave_two_tile_kernel(case, rest, monkeypatch):
     """precision='f16' in the decoders' launch form runs emo_conv_igemm_f16w8 (round 6: conv_igemm_f16x2_w8.h with the leading
-    product alone -- plain fp16 operands, two waves per SIMD, an odd last channel tile in a half-empty pair): the fp16-operand bound
-    against torch CPU fp32, deterministic, and within accumulation-order noise of the older fp16-operand kernel (EMO_F16_W8=0),
-    which rounds the same operands"""
+    product alone -- plain fp16 operands, two waves per SIMD): the fp16-operand bound against torch CPU fp32, deterministic, and
+    within accumulation-order noise of the older fp16-operand kernel (EMO_F16_W8=0), which rounds the same operands.  An odd
+    channel-tile count runs its last tile on that older kernel (rest: emo_conv_igemm_f16w8_rest, ABI 10 -- the planner's choice)
+    or in a half-empty pair of the eight-wave kernel (EMO_F16_W8_REST=0)"""
+    if not rest and (case["Cout"] // 64) % 2 == 0:
+        pytest.skip("even tile count: one launch form")
     monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
     monkeypatch.setattr(pack, "F16_W8_ODD", 1)           # (every odd tile count: the planner takes them from five tiles on only)
+    monkeypatch.setattr(pack, "F16_W8_REST", rest)
     e, got, ref = run_conv(seed=12, precision="f16", **case)
     print("PARITY conv fp16 operands, eight-wave kernel:", case["Cin"], case["Cout"], case["dims"], f"{e:.2e}")
     assert e < 3e-3, e
@@ -238,6 +243,25 @@ def test_conv_fp16_operands_on_the_eight_wave_two_tile_kernel(case, monkeypatch)
     monkeypatch.setattr(pack, "F16_W8", False)
     e3, old, _ = run_conv(seed=12, precision="f16", **case)
     assert (got - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_conv_fp16_odd_tile_count_tile_statistics_come_from_both_kernels(monkeypatch):
+    """a 192-channel layer in the plain-fp16 mode: two channel tiles from the eight-wave kernel, the third from the older kernel
+    (emo_conv_igemm_f16w8_rest) -- the GroupNorm scale / shift from the fused tile statistics equal the ones from a pass over
+    the output"""
+    monkeypatch.setenv("EMO_CONV_CT2_MIN_ITEMS", "1")
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(192, 64, 3, 3, generator=g) / 24
+    layer = pack.PackedConv("l3", w, None, DEV, precision="f16")
+    x = torch.randn(2, 64, 64, 128, generator=g)
+    assert pack.f16w8_rest_fits(192, 64, 128)
+    out, st = ops.conv_igemm(x.to(DEV), layer, want_stats=True, ksplit=1)
+    assert layer.last_plan[2] == "f16w8" and st is not None and st.cnt == 256
+    assert 1e-5 < rel_err(out, F.conv2d(x, w, padding=1)) < 3e-3
+    s1, h1 = ops.groupnorm_affine(out, stats=st)
+    s0, h0 = ops.groupnorm_affine(out)
+    assert (s1 - s0).abs().max().item() <= 2e-6 * s0.abs().max().item()
+    assert (h1 - h0).abs().max().item() <= 2e-6 * max(1.0, h0.abs().max().item())
 
 
 def test_conv_fp16_layer_falls_back_to_fp32_on_narrow_maps_and_writes_tile_statistics():
