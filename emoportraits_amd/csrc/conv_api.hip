@@ -274,6 +274,11 @@ extern "C" int emo_conv_igemm_f16w8_rest(const float* x, const void* wpk1, const
                                          float w_scale) {
   const int cot = (Cout + 63) / 64;
   if (!wpk16 || Cout % 64 || cot < 3 || !(cot & 1)) return EMO_ERR_UNSUPPORTED;
+  // the plane must be in the OLDER kernel's form too (its 2 x 128 / 4 x 64 position tiles) -- checked before anything is launched
+  // (today shape_of_width admits no other width that the eight-wave kernel takes; this keeps the two launches all-or-nothing if
+  // that changes): whatever else that launcher refuses, the eight-wave launcher in front of it refuses first
+  const int Wl = ups ? 2 * W : W, Hl = ups ? 2 * H : H;
+  if (!((Wl % 128 == 0 && Hl % 2 == 0) || (Wl == 64 && Hl % 4 == 0))) return EMO_ERR_UNSUPPORTED;
   int rc = conv_igemm_dispatch(PREC_H1, x, wpk1, bias, scale, shift, res, out, N, Cin, Cout, D, H, W, KD, KH, KW, ups, relu_in,
                                act, res_ups, cfg, ksplit, workspace, gn_stats, stream, 1.0f, w_scale, nullptr, nullptr, 0, cot - 1);
   if (rc != EMO_OK) return rc;

@@ -256,8 +256,8 @@ def test_fp16_plan_falls_back_to_fp32_where_the_fp16_kernel_cannot_run():
     assert lay.plan_for(big, 512, 512)[2] == "f16"                   # an odd number of channel tiles (one): the older kernel
     assert pack.PackedConv("c", torch.zeros(96, 64, 3, 3), None, "cpu", precision="f16").plan_for(big, 512, 512)[2] == "f16"
     # ... an odd count >= 3: the pairs on the eight-wave kernel, the last tile on the older one (emo_conv_igemm_f16w8_rest, ABI 10) where
-    # the plane is in BOTH kernels' launch form; elsewhere (192-wide: 4 x 64 tiles fit, 2 x 128 do not) a half-empty last pair from
-    # five tiles on, the older kernel below that
+    # the plane is in BOTH kernels' launch form; elsewhere (planner logic only: the C entry points admit widths that are multiples of
+    # 128, or 64 / 32 / 16 / 8) a half-empty last pair from five tiles on
     t3 = pack.PackedConv("t3", torch.zeros(192, 64, 3, 3), None, "cpu", precision="f16")
     t5 = pack.PackedConv("t5", torch.zeros(320, 64, 3, 3), None, "cpu", precision="f16")
     assert t3.plan_for(big, 512, 512)[2] == "f16w8" and pack.f16w8_rest_fits(192, 512, 512)
