@@ -15,7 +15,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE>   // 0: 32x32x16 f16, 1: 16x16x32 f16, 2: 32x32x16 bf16
+template <int SHAPE>   // 0: 32x32x16 f16, 1: 16x16x32 f16, 2: 32x32x16 bf16; 3 / 4: 32x32x16 f16 with one / both operands held
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void stream_kernel(const unsigned* __restrict__ operands, float* __restrict__ sink, int iters) {
   const int tid = threadIdx.x;
@@ -54,9 +54,12 @@ void stream_kernel(const unsigned* __restrict__ operands, float* __restrict__ si
       for (int r = 0; r < 4; ++r)      // 4 x 8 = 32 MFMAs of 32 cycles = 1024 matrix cycles per iteration
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          if (SHAPE == 0) {
-            const halfx8 a = __builtin_bit_cast(halfx8, *reinterpret_cast<const uint4*>(raw[(t + r) & 7]));
-            const halfx8 b = __builtin_bit_cast(halfx8, *reinterpret_cast<const uint4*>(raw[(t + 2 * r + 1) & 7]));
+          if (SHAPE == 0 || SHAPE == 3 || SHAPE == 4) {
+            // SHAPE 3: operand A stays for the 8 consecutive MFMAs of the t loop (only B changes from one instruction to the next);
+            // SHAPE 4: both operands stay (8 x the same product into 8 accumulators): how much of the energy is operand TOGGLING
+            const int ia = SHAPE == 0 ? (t + r) & 7 : r, ib = SHAPE == 4 ? (r + 4) & 7 : (t + 2 * r + 1) & 7;
+            const halfx8 a = __builtin_bit_cast(halfx8, *reinterpret_cast<const uint4*>(raw[ia]));
+            const halfx8 b = __builtin_bit_cast(halfx8, *reinterpret_cast<const uint4*>(raw[ib]));
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
           } else {
             const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(raw[(t + r) & 7]));
@@ -85,9 +88,11 @@ int main() {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  const char* shapes[3] = {"v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_f16", "v_mfma_f32_32x32x16_bf16"};
+  const char* shapes[5] = {"v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_f16", "v_mfma_f32_32x32x16_bf16",
+                           "v_mfma_f32_32x32x16_f16, operand A held over 8 consecutive instructions",
+                           "v_mfma_f32_32x32x16_f16, both operands held over 8 consecutive instructions"};
   const char* datas[3] = {"random", "small", "zeros"};
-  for (int shape = 0; shape < 3; ++shape)
+  for (int shape = 0; shape < 5; ++shape)
     for (int data = 0; data < 3; ++data) {
       std::vector<unsigned> h(8192);
       unsigned st = 12345u + 77u * data;
@@ -107,6 +112,8 @@ int main() {
         if (shape == 0) hipLaunchKernelGGL(stream_kernel<0>, dim3(ncu), dim3(256), 0, 0, d_op, d_sink, iters);
         if (shape == 1) hipLaunchKernelGGL(stream_kernel<1>, dim3(ncu), dim3(256), 0, 0, d_op, d_sink, iters);
         if (shape == 2) hipLaunchKernelGGL(stream_kernel<2>, dim3(ncu), dim3(256), 0, 0, d_op, d_sink, iters);
+        if (shape == 3) hipLaunchKernelGGL(stream_kernel<3>, dim3(ncu), dim3(256), 0, 0, d_op, d_sink, iters);
+        if (shape == 4) hipLaunchKernelGGL(stream_kernel<4>, dim3(ncu), dim3(256), 0, 0, d_op, d_sink, iters);
       };
       const int iters = 400000;     // x 1024 matrix cycles: ~0.2-0.3 s per launch
       launch(iters);                // warm: the clock settles under load
